@@ -1,0 +1,126 @@
+/* av1o.h - CPU oracle ("golden model") for the MI355X AV1 chunk-encode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or executed by the
+ * product path (av1-base_amd/, include/).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may use it, and only as the checker.
+ *
+ * What it restates: the reference (IONIQ6000/av1-base) has NO codec arithmetic of its own -
+ * its hot path is `run_av1an` (crates/daemon/src/encode/av1an.rs:126-139) which forks the
+ * external av1an -> SVT-AV1 stack.  This oracle is therefore
+ * a plain-C restatement of (1) the encoder algorithm this build defines for that path
+ *  and (2) the NORMATIVE AV1 decoding processes the encoder must mirror
+ * (AV1 Bitstream & Decoding Process Specification: §5.5 sequence header, §5.9 frame header,
+ * §5.11 tile/block syntax, §7.11.2 intra prediction, §7.12 dequant, §7.13 inverse
+ * transforms, §7.15 CDEF, §8.2 symbol coder).
+ *
+ * PARITY PIN: parity with SVT-AV1 output is UNPINNED (no av1an/SVT-AV1 anywhere, the
+ * reference holds no media fixtures: SURVEY.md §8c).  The normative half IS pinned: streams
+ * produced by this oracle are decoded by dav1d 1.5.3 (inside the container's Pillow/libavif)
+ * and must reproduce the oracle's reconstruction bit-exactly; those streams + dav1d outputs are
+ * committed under tests/golden/ (tools/make_golden.py).
+ */
+#ifndef AV1O_H
+#define AV1O_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (AV1 spec §6.10.x symbol values) ------------------------------------------ */
+enum { DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED, D67_PRED,
+       SMOOTH_PRED, SMOOTH_V_PRED, SMOOTH_H_PRED, PAETH_PRED, UV_CFL_PRED, N_INTRA_MODES = 13 };
+enum { PARTITION_NONE, PARTITION_HORZ, PARTITION_VERT, PARTITION_SPLIT };
+enum { DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST, FLIPADST_DCT, DCT_FLIPADST, FLIPADST_FLIPADST,
+       ADST_FLIPADST, FLIPADST_ADST, IDTX, V_DCT, H_DCT, V_ADST, H_ADST, V_FLIPADST, H_FLIPADST };
+/* square transform sizes only in this build: log2 size 2..6 */
+enum { TX_4X4, TX_8X8, TX_16X16, TX_32X32, TX_64X64 };
+
+/* ---- encoder configuration ------------------------------------------------------------- */
+typedef struct {
+  int width, height;      /* luma; multiples of 8 */
+  int bit_depth;          /* 8 or 10 */
+  int base_q_idx;         /* CQ 30 <-> 120 */
+  int tile_w_sb, tile_h_sb; /* tile size in 64x64 superblocks */
+  int min_bs_log2, max_bs_log2; /* leaf block size range, log2 (3..6) */
+  int cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping; /* one strength set; cdef_bits = 0 */
+  int enable_cdef;
+  uint32_t mode_mask;     /* bit m set -> luma intra mode m is a candidate */
+  int still_picture;      /* 1: reduced still-picture headers (AVIF style) */
+  /* test hooks (fuzzing the normative paths against dav1d) */
+  int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
+  int fuzz_density;       /* 1/N chance a coefficient is nonzero */
+  int fuzz_maxlevel;
+  int fuzz_modes;         /* !=0: choose modes pseudo-randomly instead of by cost */
+} Av1oConfig;
+
+void av1o_default_config(Av1oConfig *c, int w, int h, int bit_depth);
+
+/* planes are uint16_t for every bit depth (8-bit data stored in the low byte) */
+typedef struct {
+  int w, h;               /* luma dims */
+  uint16_t *p[3];
+  int stride[3];
+} Av1oFrame;
+
+Av1oFrame *av1o_frame_alloc(int w, int h);
+void av1o_frame_free(Av1oFrame *f);
+
+typedef struct {
+  uint64_t n_symbols;     /* arithmetic-coded symbols incl. literal bits */
+  uint64_t n_blocks;
+  uint64_t n_skip_blocks;
+  uint64_t sse[3];        /* reconstruction vs source */
+  uint64_t mode_hist[13];
+  uint64_t bs_hist[7];
+} Av1oStats;
+
+/* Encode one key frame.  Writes a temporal unit (TD [+ sequence header] + OBU_FRAME) to out.
+ * recon (may be NULL) receives the decoder-identical reconstruction (post-CDEF).
+ * Returns bytes written, or <0 on error. */
+long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq_hdr,
+                       uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats);
+
+/* size of the sequence header OBU etc. helpers used by the tests */
+long av1o_write_sequence_header(const Av1oConfig *cfg, uint8_t *out, size_t cap);
+
+/* ---- exported building blocks (tested individually / compared with the HIP kernels) ---- */
+void av1o_fwd_txfm2d(const int32_t *resid, int stride, int32_t *coef, int log2n, int tx_type, int bd);
+void av1o_inv_txfm2d_add(const int32_t *dq, uint16_t *dst, int stride, int log2n, int tx_type, int bd, int eob);
+void av1o_inv_txfm2d(const int32_t *dq, int32_t *resid, int log2n, int tx_type, int bd);
+void av1o_idct1d(int32_t *x, int log2n);
+void av1o_fdct1d(int32_t *x, int log2n);
+const int16_t *av1o_default_scan(int log2n); /* n*n entries (n<=32) */
+
+/* edge arrays: above[-1..2n-1], left[-1..2n-1] (index 0 of the passed pointer = element -1) */
+void av1o_predict_intra(uint16_t *dst, int stride, int log2n, int mode, int angle_delta,
+                        const uint16_t *above, const uint16_t *left, int have_above, int have_left, int bd);
+
+void av1o_cdef_frame(const Av1oConfig *cfg, const Av1oFrame *in, Av1oFrame *out,
+                     const uint8_t *skip_mi, int mi_stride, const int8_t *cdef_idx_sb);
+
+/* ---- synthclip v1: deterministic integer-only synthetic clip ------------ */
+void av1o_synthclip_frame(Av1oFrame *f, int bit_depth, uint64_t seed, int t, int scene_len);
+
+/* ---- range coder (exposed for the known-answer tests) ------------------------------------ */
+typedef struct {
+  uint32_t low;
+  uint32_t rng;
+  int cnt;
+  uint8_t *buf;
+  size_t cap, offs;
+  int error;
+  uint64_t nsym;
+} Av1oRangeEnc;
+void av1o_ec_init(Av1oRangeEnc *e, uint8_t *buf, size_t cap);
+/* icdf: inverted cdf (32768 - cdf), n-1 entries + terminating 0 + counter; adapts in place */
+void av1o_ec_encode_symbol(Av1oRangeEnc *e, int s, uint16_t *icdf, int nsyms);
+void av1o_ec_encode_bool(Av1oRangeEnc *e, int val, unsigned f_q15);
+void av1o_ec_encode_literal(Av1oRangeEnc *e, unsigned v, int bits);
+size_t av1o_ec_finish(Av1oRangeEnc *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,132 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libav1o.so).
+
+TEST INFRASTRUCTURE ONLY (see oracle/av1o.h): imported by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg - never by the product
+package under av1-base_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libav1o.so")
+
+
+def build(force=False):
+    srcs = [f for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    newest = max(os.path.getmtime(os.path.join(HERE, f)) for f in srcs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return LIB_PATH
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "width", "height", "bit_depth", "base_q_idx", "tile_w_sb", "tile_h_sb", "min_bs_log2", "max_bs_log2",
+        "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping", "enable_cdef")] + [
+        ("mode_mask", C.c_uint32), ("still_picture", C.c_int), ("fuzz_coeffs", C.c_int), ("fuzz_density", C.c_int),
+        ("fuzz_maxlevel", C.c_int), ("fuzz_modes", C.c_int)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("p", C.POINTER(C.c_uint16) * 3), ("stride", C.c_int * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_symbols", C.c_uint64), ("n_blocks", C.c_uint64), ("n_skip_blocks", C.c_uint64),
+                ("sse", C.c_uint64 * 3), ("mode_hist", C.c_uint64 * 13), ("bs_hist", C.c_uint64 * 7)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.av1o_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int]
+        L.av1o_frame_alloc.restype = C.POINTER(Frame)
+        L.av1o_frame_alloc.argtypes = [C.c_int, C.c_int]
+        L.av1o_frame_free.argtypes = [C.POINTER(Frame)]
+        L.av1o_encode_frame.restype = C.c_long
+        L.av1o_encode_frame.argtypes = [C.POINTER(Config), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_size_t,
+                                        C.POINTER(Frame), C.POINTER(Stats)]
+        L.av1o_synthclip_frame.argtypes = [C.POINTER(Frame), C.c_int, C.c_uint64, C.c_int, C.c_int]
+        L.av1o_fwd_txfm2d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.av1o_inv_txfm2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.av1o_default_scan.restype = C.POINTER(C.c_int16)
+        L.av1o_default_scan.argtypes = [C.c_int]
+        L.av1o_predict_intra.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def default_config(w, h, bit_depth=8, **kw):
+    c = Config()
+    lib().av1o_default_config(C.byref(c), w, h, bit_depth)
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def _frame_to_planes(fp):
+    f = fp.contents
+    out = []
+    for p in range(3):
+        pw, ph = (f.w, f.h) if p == 0 else (f.w // 2, f.h // 2)
+        a = np.ctypeslib.as_array(f.p[p], shape=(ph, f.stride[p]))[:, :pw].copy()
+        out.append(a)
+    return out
+
+
+def _planes_to_frame(planes):
+    h, w = planes[0].shape
+    fp = lib().av1o_frame_alloc(w, h)
+    f = fp.contents
+    for p in range(3):
+        pw, ph = (w, h) if p == 0 else (w // 2, h // 2)
+        dst = np.ctypeslib.as_array(f.p[p], shape=(ph, f.stride[p]))
+        dst[:, :pw] = planes[p].astype(np.uint16)
+    return fp
+
+
+def synthclip_frame(w, h, bit_depth=8, seed=1080, t=0, scene_len=0):
+    fp = lib().av1o_frame_alloc(w, h)
+    lib().av1o_synthclip_frame(fp, bit_depth, seed, t, scene_len)
+    planes = _frame_to_planes(fp)
+    lib().av1o_frame_free(fp)
+    return planes
+
+
+def encode_frame(cfg, planes, with_seq_hdr=True):
+    """Returns (temporal-unit bytes, [Y,U,V] reconstruction (uint16), Stats)."""
+    src = _planes_to_frame(planes)
+    rec = lib().av1o_frame_alloc(cfg.width, cfg.height)
+    cap = cfg.width * cfg.height * 6 + (1 << 16)
+    buf = C.create_string_buffer(cap)
+    st = Stats()
+    n = lib().av1o_encode_frame(C.byref(cfg), src, 1 if with_seq_hdr else 0, buf, cap, rec, C.byref(st))
+    recon = _frame_to_planes(rec)
+    lib().av1o_frame_free(src)
+    lib().av1o_frame_free(rec)
+    if n < 0:
+        raise RuntimeError("av1o_encode_frame failed: %d" % n)
+    return buf.raw[:n], recon, st
+
+
+def psnr(stats, cfg):
+    import math
+    mx = (1 << cfg.bit_depth) - 1
+    out = []
+    for p in range(3):
+        npx = cfg.width * cfg.height // (1 if p == 0 else 4)
+        mse = stats.sse[p] / npx
+        out.append(99.0 if mse == 0 else 10 * math.log10(mx * mx / mse))
+    return out

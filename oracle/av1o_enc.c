@@ -1,0 +1,1014 @@
+/* av1o_enc.c - oracle key-frame encoder: bitstream syntax + closed-loop reconstruction.
+ *
+ * Boundary restated: one call = one frame of one scene-chunk, i.e. the unit of work the
+ * reference hands to an external SVT-AV1 worker via av1an (`run_av1an`,
+ * /root/reference/crates/daemon/src/encode/av1an.rs:126-139; operating point string
+ * av1an.rs:14, here CQ=30 <-> base_q_idx 120).
+ *
+ * Normative syntax mirrored (AV1 spec section numbers):
+ *   §5.3 OBU header, §5.5 sequence_header_obu, §5.9 uncompressed_header (key frame),
+ *   §5.9.15 tile_info, §5.9.12 quantization_params, §5.9.11 loop_filter_params (levels 0),
+ *   §5.9.19 cdef_params, §5.9.21 read_tx_mode (TX_MODE_LARGEST), §5.11.1 tile_group_obu,
+ *   §5.11.4 decode_partition, §5.11.5 decode_block, §5.11.7 intra_frame_mode_info,
+ *   §5.11.34 residual, §5.11.35 transform_block, §5.11.39 coeffs, §5.11.47 transform_type;
+ *   context derivations §8.3.2; dequant §7.12.3; prediction edges §7.11.2.
+ * Encoder decisions (non-normative, defined by this build): block size,
+ * intra mode by SAD of the closed-loop prediction, tx type by mode, dead-zone quantiser.
+ * Oracle code (test infrastructure): see av1o.h.
+ */
+#include "av1o.h"
+#include "../av1-base_amd/csrc/av1_tables.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------ bit writer (headers) */
+typedef struct {
+  uint8_t *buf;
+  size_t cap, pos; /* pos in bits */
+} BitW;
+
+static void bw_put(BitW *b, uint32_t v, int n) {
+  int i;
+  for (i = n - 1; i >= 0; i--) {
+    size_t byte = b->pos >> 3;
+    if (byte < b->cap) {
+      if ((b->pos & 7) == 0) b->buf[byte] = 0;
+      b->buf[byte] |= (uint8_t)(((v >> i) & 1) << (7 - (b->pos & 7)));
+    }
+    b->pos++;
+  }
+}
+static void bw_trailing(BitW *b) {
+  bw_put(b, 1, 1);
+  while (b->pos & 7) bw_put(b, 0, 1);
+}
+static void bw_align(BitW *b) {
+  while (b->pos & 7) bw_put(b, 0, 1);
+}
+static int leb128_size(uint64_t v) {
+  int n = 1;
+  while (v >>= 7) n++;
+  return n;
+}
+static size_t put_leb128(uint8_t *p, uint64_t v) {
+  size_t n = 0;
+  do {
+    uint8_t b = v & 0x7F;
+    v >>= 7;
+    if (v) b |= 0x80;
+    p[n++] = b;
+  } while (v);
+  return n;
+}
+static int floor_log2(unsigned v) { return 31 - __builtin_clz(v); }
+static int tile_log2(int blk, int target) {
+  int k = 0;
+  while ((blk << k) < target) k++;
+  return k;
+}
+/* ns(n) non-symmetric unsigned (spec §4.10.7) */
+static void bw_put_ns(BitW *b, int n, int v) {
+  int w = floor_log2((unsigned)n) + 1;
+  int m = (1 << w) - n;
+  if (v < m) bw_put(b, (uint32_t)v, w - 1);
+  else {
+    int extra = v + m;
+    bw_put(b, (uint32_t)(extra >> 1), w - 1);
+    bw_put(b, (uint32_t)(extra & 1), 1);
+  }
+}
+
+void av1o_default_config(Av1oConfig *c, int w, int h, int bit_depth) {
+  memset(c, 0, sizeof(*c));
+  c->width = w;
+  c->height = h;
+  c->bit_depth = bit_depth;
+  c->base_q_idx = 120;
+  c->tile_w_sb = 1;
+  c->tile_h_sb = 1;
+  c->min_bs_log2 = 4;
+  c->max_bs_log2 = 4;
+  c->enable_cdef = 1;
+  c->cdef_y_pri = 2;
+  c->cdef_y_sec = 1;
+  c->cdef_uv_pri = 1;
+  c->cdef_uv_sec = 1;
+  c->cdef_damping = 5;
+  c->mode_mask = 0x1FFF;
+  c->fuzz_density = 8;
+  c->fuzz_maxlevel = 40;
+}
+
+Av1oFrame *av1o_frame_alloc(int w, int h) {
+  Av1oFrame *f = (Av1oFrame *)calloc(1, sizeof(*f));
+  int p;
+  f->w = w;
+  f->h = h;
+  for (p = 0; p < 3; p++) {
+    int pw = p ? w / 2 : w, ph = p ? h / 2 : h;
+    f->stride[p] = pw;
+    f->p[p] = (uint16_t *)calloc((size_t)pw * ph, sizeof(uint16_t));
+  }
+  return f;
+}
+void av1o_frame_free(Av1oFrame *f) {
+  if (!f) return;
+  free(f->p[0]);
+  free(f->p[1]);
+  free(f->p[2]);
+  free(f);
+}
+
+/* ------------------------------------------------------------------ sequence header §5.5 */
+static void write_color_config(BitW *b, const Av1oConfig *cfg) {
+  bw_put(b, cfg->bit_depth > 8, 1); /* high_bitdepth (profile 0: no twelve_bit) */
+  bw_put(b, 0, 1);                  /* mono_chrome */
+  bw_put(b, 0, 1);                  /* color_description_present_flag */
+  bw_put(b, 1, 1);                  /* color_range: full */
+  bw_put(b, 0, 2);                  /* chroma_sample_position (4:2:0): unknown */
+  bw_put(b, 0, 1);                  /* separate_uv_delta_q */
+}
+
+static size_t seq_header_payload(const Av1oConfig *cfg, uint8_t *buf, size_t cap) {
+  BitW b = { buf, cap, 0 };
+  int wbits = floor_log2((unsigned)(cfg->width - 1) | 1) + 1, hbits = floor_log2((unsigned)(cfg->height - 1) | 1) + 1;
+  bw_put(&b, 0, 3);                   /* seq_profile */
+  bw_put(&b, cfg->still_picture, 1);  /* still_picture */
+  bw_put(&b, cfg->still_picture, 1);  /* reduced_still_picture_header */
+  if (cfg->still_picture) {
+    bw_put(&b, 31, 5);                /* seq_level_idx[0] */
+  } else {
+    bw_put(&b, 0, 1);  /* timing_info_present_flag */
+    bw_put(&b, 0, 1);  /* initial_display_delay_present_flag */
+    bw_put(&b, 0, 5);  /* operating_points_cnt_minus_1 */
+    bw_put(&b, 0, 12); /* operating_point_idc[0] */
+    bw_put(&b, 31, 5); /* seq_level_idx[0] = 31 (maximum parameters) */
+    bw_put(&b, 0, 1);  /* seq_tier[0] (present because level > 7) */
+  }
+  bw_put(&b, (uint32_t)(wbits - 1), 4);
+  bw_put(&b, (uint32_t)(hbits - 1), 4);
+  bw_put(&b, (uint32_t)(cfg->width - 1), wbits);
+  bw_put(&b, (uint32_t)(cfg->height - 1), hbits);
+  if (!cfg->still_picture) bw_put(&b, 0, 1); /* frame_id_numbers_present_flag */
+  bw_put(&b, 0, 1); /* use_128x128_superblock */
+  bw_put(&b, 0, 1); /* enable_filter_intra */
+  bw_put(&b, 0, 1); /* enable_intra_edge_filter */
+  if (!cfg->still_picture) {
+    bw_put(&b, 0, 1); /* enable_interintra_compound */
+    bw_put(&b, 0, 1); /* enable_masked_compound */
+    bw_put(&b, 0, 1); /* enable_warped_motion */
+    bw_put(&b, 0, 1); /* enable_dual_filter */
+    bw_put(&b, 0, 1); /* enable_order_hint */
+    bw_put(&b, 0, 1); /* seq_choose_screen_content_tools */
+    bw_put(&b, 0, 1); /* seq_force_screen_content_tools = 0 */
+  }
+  bw_put(&b, 0, 1);               /* enable_superres */
+  bw_put(&b, cfg->enable_cdef, 1); /* enable_cdef */
+  bw_put(&b, 0, 1);               /* enable_restoration */
+  write_color_config(&b, cfg);
+  bw_put(&b, 0, 1); /* film_grain_params_present */
+  bw_trailing(&b);
+  return b.pos >> 3;
+}
+
+long av1o_write_sequence_header(const Av1oConfig *cfg, uint8_t *out, size_t cap) {
+  uint8_t tmp[64];
+  size_t n = seq_header_payload(cfg, tmp, sizeof(tmp)), k;
+  if (cap < n + 3) return -1;
+  out[0] = (1 << 3) | 2; /* OBU_SEQUENCE_HEADER, has_size_field */
+  k = put_leb128(out + 1, n);
+  memcpy(out + 1 + k, tmp, n);
+  return (long)(1 + k + n);
+}
+
+/* ------------------------------------------------------------------ tile geometry */
+typedef struct {
+  int mi_rows, mi_cols, sb_rows, sb_cols;
+  int tile_cols, tile_rows;
+  int col_start_sb[65], row_start_sb[65];
+} Geom;
+
+static void make_geom(const Av1oConfig *cfg, Geom *g) {
+  int i, s;
+  g->mi_rows = cfg->height / 4;
+  g->mi_cols = cfg->width / 4;
+  g->sb_rows = (g->mi_rows + 15) >> 4;
+  g->sb_cols = (g->mi_cols + 15) >> 4;
+  for (i = 0, s = 0; s < g->sb_cols; i++, s += cfg->tile_w_sb) g->col_start_sb[i] = s;
+  g->tile_cols = i;
+  g->col_start_sb[i] = g->sb_cols;
+  for (i = 0, s = 0; s < g->sb_rows; i++, s += cfg->tile_h_sb) g->row_start_sb[i] = s;
+  g->tile_rows = i;
+  g->row_start_sb[i] = g->sb_rows;
+}
+
+/* ------------------------------------------------------------------ frame header §5.9 */
+#define TILE_SIZE_BYTES 4
+
+static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, uint8_t *buf, size_t cap) {
+  BitW b = { buf, cap, 0 };
+  int i;
+  if (!cfg->still_picture) {
+    bw_put(&b, 0, 1); /* show_existing_frame */
+    bw_put(&b, 0, 2); /* frame_type = KEY_FRAME */
+    bw_put(&b, 1, 1); /* show_frame */
+    /* error_resilient_mode = 1 implied (key frame shown) */
+  }
+  bw_put(&b, 0, 1); /* disable_cdf_update */
+  /* allow_screen_content_tools = seq_force_screen_content_tools = 0 (still: SELECT -> coded) */
+  if (cfg->still_picture) bw_put(&b, 0, 1); /* allow_screen_content_tools */
+  if (!cfg->still_picture) bw_put(&b, 0, 1); /* frame_size_override_flag */
+  /* order_hint: 0 bits; primary_ref_frame = NONE (intra) ; refresh_frame_flags = 0xFF implied */
+  /* frame_size(): from sequence; superres_params(): none */
+  bw_put(&b, 0, 1); /* render_and_frame_size_different */
+  /* allow_intrabc not coded (allow_screen_content_tools = 0) */
+  if (!cfg->still_picture) bw_put(&b, 1, 1); /* disable_frame_end_update_cdf */
+  /* tile_info() */
+  {
+    int sb_cols = g->sb_cols, sb_rows = g->sb_rows;
+    int max_tile_width_sb = 4096 >> 6, max_tile_area_sb = (4096 * 2304) >> 12;
+    int min_log2_tile_cols = tile_log2(max_tile_width_sb, sb_cols);
+    int min_log2_tiles = tile_log2(max_tile_area_sb, sb_rows * sb_cols);
+    int start, widest = 0, max_tile_height_sb, tile_cols_log2, tile_rows_log2;
+    if (min_log2_tiles < min_log2_tile_cols) min_log2_tiles = min_log2_tile_cols;
+    bw_put(&b, 0, 1); /* uniform_tile_spacing_flag = 0 */
+    for (i = 0, start = 0; start < sb_cols; i++) {
+      int max_w = sb_cols - start < max_tile_width_sb ? sb_cols - start : max_tile_width_sb;
+      int sz = g->col_start_sb[i + 1] - g->col_start_sb[i];
+      bw_put_ns(&b, max_w, sz - 1);
+      if (sz > widest) widest = sz;
+      start += sz;
+    }
+    {
+      int area = sb_rows * sb_cols;
+      if (min_log2_tiles > 0) area >>= (min_log2_tiles + 1);
+      max_tile_height_sb = area / widest;
+      if (max_tile_height_sb < 1) max_tile_height_sb = 1;
+    }
+    for (i = 0, start = 0; start < sb_rows; i++) {
+      int max_h = sb_rows - start < max_tile_height_sb ? sb_rows - start : max_tile_height_sb;
+      int sz = g->row_start_sb[i + 1] - g->row_start_sb[i];
+      bw_put_ns(&b, max_h, sz - 1);
+      start += sz;
+    }
+    tile_cols_log2 = tile_log2(1, g->tile_cols);
+    tile_rows_log2 = tile_log2(1, g->tile_rows);
+    if (tile_cols_log2 > 0 || tile_rows_log2 > 0) {
+      bw_put(&b, 0, tile_cols_log2 + tile_rows_log2); /* context_update_tile_id */
+      bw_put(&b, TILE_SIZE_BYTES - 1, 2);              /* tile_size_bytes_minus_1 */
+    }
+  }
+  /* quantization_params() */
+  bw_put(&b, (uint32_t)cfg->base_q_idx, 8);
+  bw_put(&b, 0, 1); /* DeltaQYDc delta_coded */
+  bw_put(&b, 0, 1); /* DeltaQUDc */
+  bw_put(&b, 0, 1); /* DeltaQUAc */
+  bw_put(&b, 0, 1); /* using_qmatrix */
+  bw_put(&b, 0, 1); /* segmentation_enabled */
+  if (cfg->base_q_idx > 0) bw_put(&b, 0, 1); /* delta_q_present */
+  /* loop_filter_params(): levels 0 => deblocking off */
+  bw_put(&b, 0, 6);
+  bw_put(&b, 0, 6);
+  bw_put(&b, 0, 3); /* loop_filter_sharpness */
+  bw_put(&b, 0, 1); /* loop_filter_delta_enabled */
+  /* cdef_params() */
+  if (cfg->enable_cdef) {
+    bw_put(&b, (uint32_t)(cfg->cdef_damping - 3), 2);
+    bw_put(&b, 0, 2); /* cdef_bits */
+    bw_put(&b, (uint32_t)cfg->cdef_y_pri, 4);
+    bw_put(&b, (uint32_t)cfg->cdef_y_sec, 2);
+    bw_put(&b, (uint32_t)cfg->cdef_uv_pri, 4);
+    bw_put(&b, (uint32_t)cfg->cdef_uv_sec, 2);
+  }
+  /* lr_params(): enable_restoration = 0 */
+  bw_put(&b, 0, 1); /* tx_mode_select = 0 -> TX_MODE_LARGEST */
+  /* reference_select / skip_mode / warped motion: not coded for intra frames */
+  bw_put(&b, 0, 1); /* reduced_tx_set */
+  /* global_motion_params: none for intra; film grain: not present */
+  return b.pos;
+}
+
+/* ------------------------------------------------------------------ per-tile coding state */
+typedef struct {
+  uint16_t partition[20][11];
+  uint16_t kf_y_mode[5][5][14];
+  uint16_t uv_mode[2][13][15];
+  uint16_t angle_delta[8][8];
+  uint16_t skip[3][3];
+  uint16_t intra_tx_set1[2][13][8];
+  uint16_t intra_tx_set2[3][13][6];
+  uint16_t txb_skip[5][13][3];
+  uint16_t eob_pt_16[2][2][6], eob_pt_32[2][2][7], eob_pt_64[2][2][8], eob_pt_128[2][2][9];
+  uint16_t eob_pt_256[2][2][10], eob_pt_512[2][2][11], eob_pt_1024[2][2][12];
+  uint16_t eob_extra[5][2][9][3];
+  uint16_t dc_sign[2][3][3];
+  uint16_t coeff_base_eob[5][2][4][4];
+  uint16_t coeff_base[5][2][42][5];
+  uint16_t coeff_br[5][2][21][5];
+} TileCdfs;
+
+static void load_cdf(uint16_t *dst, const uint16_t *src, int nsym) {
+  int i;
+  for (i = 0; i < nsym - 1; i++) dst[i] = (uint16_t)(32768 - src[i]);
+  dst[nsym - 1] = 0;
+  dst[nsym] = 0;
+}
+
+static void init_cdfs(TileCdfs *c, int qidx) {
+  int q = qidx <= 20 ? 0 : (qidx <= 60 ? 1 : (qidx <= 120 ? 2 : 3));
+  int i, j, k, l;
+  for (i = 0; i < 20; i++) load_cdf(c->partition[i], av1_default_partition_cdf[i], i < 4 ? 4 : (i < 16 ? 10 : 8));
+  for (i = 0; i < 5; i++)
+    for (j = 0; j < 5; j++) load_cdf(c->kf_y_mode[i][j], av1_default_kf_y_mode_cdf[i][j], 13);
+  for (i = 0; i < 13; i++) {
+    load_cdf(c->uv_mode[0][i], av1_default_uv_mode_nocfl_cdf[i], 13);
+    load_cdf(c->uv_mode[1][i], av1_default_uv_mode_cfl_cdf[i], 14);
+  }
+  for (i = 0; i < 8; i++) load_cdf(c->angle_delta[i], av1_default_angle_delta_cdf[i], 7);
+  for (i = 0; i < 3; i++) load_cdf(c->skip[i], av1_default_skip_cdf[i], 2);
+  for (i = 0; i < 2; i++)
+    for (j = 0; j < 13; j++) load_cdf(c->intra_tx_set1[i][j], av1_default_intra_tx_set1_cdf[i][j], 7);
+  for (i = 0; i < 3; i++)
+    for (j = 0; j < 13; j++) load_cdf(c->intra_tx_set2[i][j], av1_default_intra_tx_set2_cdf[i][j], 5);
+  for (i = 0; i < 5; i++)
+    for (j = 0; j < 13; j++) load_cdf(c->txb_skip[i][j], av1_default_txb_skip_cdf[q][i][j], 2);
+  for (i = 0; i < 2; i++)
+    for (j = 0; j < 2; j++) {
+      load_cdf(c->eob_pt_16[i][j], av1_default_eob_multi16_cdf[q][i][j], 5);
+      load_cdf(c->eob_pt_32[i][j], av1_default_eob_multi32_cdf[q][i][j], 6);
+      load_cdf(c->eob_pt_64[i][j], av1_default_eob_multi64_cdf[q][i][j], 7);
+      load_cdf(c->eob_pt_128[i][j], av1_default_eob_multi128_cdf[q][i][j], 8);
+      load_cdf(c->eob_pt_256[i][j], av1_default_eob_multi256_cdf[q][i][j], 9);
+      load_cdf(c->eob_pt_512[i][j], av1_default_eob_multi512_cdf[q][i][j], 10);
+      load_cdf(c->eob_pt_1024[i][j], av1_default_eob_multi1024_cdf[q][i][j], 11);
+    }
+  for (i = 0; i < 5; i++)
+    for (j = 0; j < 2; j++) {
+      for (k = 0; k < 9; k++) load_cdf(c->eob_extra[i][j][k], av1_default_eob_extra_cdf[q][i][j][k], 2);
+      for (k = 0; k < 4; k++) load_cdf(c->coeff_base_eob[i][j][k], av1_default_coeff_base_eob_cdf[q][i][j][k], 3);
+      for (k = 0; k < 42; k++) load_cdf(c->coeff_base[i][j][k], av1_default_coeff_base_cdf[q][i][j][k], 4);
+      for (k = 0; k < 21; k++) load_cdf(c->coeff_br[i][j][k], av1_default_coeff_br_cdf[q][i][j][k], 4);
+    }
+  for (j = 0; j < 2; j++)
+    for (l = 0; l < 3; l++) load_cdf(c->dc_sign[j][l], av1_default_dc_sign_cdf[q][j][l], 2);
+}
+
+typedef struct {
+  const Av1oConfig *cfg;
+  const Geom *g;
+  const Av1oFrame *src;
+  Av1oFrame *rec;      /* pre-CDEF reconstruction */
+  /* frame-level per-mi maps */
+  uint8_t *mi_bsl;     /* log2 of block size in pixels of the block covering the mi, 0 = not coded */
+  uint8_t *mi_skip;
+  uint8_t *mi_ymode;
+  int8_t *cdef_idx_sb;
+  /* tile state */
+  int mi_row_start, mi_row_end, mi_col_start, mi_col_end;
+  TileCdfs cdf;
+  Av1oRangeEnc ec;
+  uint8_t *above_lvl[3], *above_dc[3]; /* indexed by absolute 4x4 column of the plane */
+  uint8_t left_lvl[3][16], left_dc[3][16]; /* indexed by 4x4 row within the SB (plane units) */
+  uint8_t block_decoded[3][19][19];    /* [plane][y+1][x+1], y,x in -1..17 (plane 4x4 units in SB) */
+  int dc_q, ac_q;
+  Av1oStats *stats;
+  uint32_t rng_state;
+} Enc;
+
+static uint32_t fuzz_rand(Enc *e) {
+  /* xorshift32 */
+  uint32_t x = e->rng_state;
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  e->rng_state = x;
+  return x;
+}
+
+/* ------------------------------------------------------------------ tables */
+static const uint8_t intra_mode_context[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };
+static const uint8_t mode_to_txfm[14] = { DCT_DCT, ADST_DCT, DCT_ADST, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST,
+                                          DCT_ADST, ADST_DCT, ADST_ADST, ADST_DCT, DCT_ADST, ADST_ADST, DCT_DCT };
+/* symbol index of a tx type inside the intra sets (Tx_Type_Intra_Inv_Set1/2 inverted) */
+static int tx_type_to_sym(int set, int tx_type) {
+  static const int8_t s1[16] = { 1, 5, 6, 4, -1, -1, -1, -1, -1, 0, 2, 3, -1, -1, -1, -1 };
+  static const int8_t s2[16] = { 1, 3, 4, 2, -1, -1, -1, -1, -1, 0, -1, -1, -1, -1, -1, -1 };
+  return set == 1 ? s1[tx_type] : s2[tx_type];
+}
+/* Coeff_Base_Ctx_Offset for square transforms (spec §8.3.2 table) */
+static int coeff_base_ctx_offset(int log2n, int row, int col) {
+  static const uint8_t off[5][5] = { { 0, 1, 6, 6, 21 }, { 1, 6, 6, 21, 21 }, { 6, 6, 21, 21, 21 }, { 6, 21, 21, 21, 21 }, { 21, 21, 21, 21, 21 } };
+  (void)log2n;
+  if (row > 4) row = 4;
+  if (col > 4) col = 4;
+  return off[row][col];
+}
+
+static int is_inside(const Enc *e, int r, int c) {
+  return c >= e->mi_col_start && c < e->mi_col_end && r >= e->mi_row_start && r < e->mi_row_end;
+}
+
+#define WRITE_SYM(e, s, cdf, n) av1o_ec_encode_symbol(&(e)->ec, (s), (cdf), (n))
+
+/* ------------------------------------------------------------------ coefficient coding §5.11.39 */
+typedef struct {
+  int32_t level[1024]; /* signed quantised levels, row-major in the (<=32)x(<=32) coded area */
+  int eob;
+  int tx_type;
+} TxbCoefs;
+
+static void write_golomb(Enc *e, unsigned x) {
+  /* x >= 0; codes x+1 as in read_golomb (spec §5.11.39) */
+  unsigned v = x + 1;
+  int len = floor_log2(v) + 1, i;
+  for (i = 0; i < len - 1; i++) av1o_ec_encode_literal(&e->ec, 0, 1);
+  for (i = len - 1; i >= 0; i--) av1o_ec_encode_literal(&e->ec, (v >> i) & 1, 1);
+}
+
+static void write_coeffs(Enc *e, int plane, int log2n, int x4, int y4_sb, int y4_abs, const TxbCoefs *t, int ymode, int bw_eq_tx) {
+  /* x4: absolute 4x4 column (plane units); y4_sb: 4x4 row within SB (plane units) */
+  const int ptype = plane > 0;
+  const int txs_ctx = log2n - 2; /* square: (sqr + sqr_up + 1) >> 1 */
+  const int n = 1 << log2n, w4 = n >> 2;
+  const int bwl = log2n > 5 ? 5 : log2n; /* coded area is at most 32x32 */
+  const int cw = 1 << bwl;
+  const int max_x4 = plane ? e->g->mi_cols >> 1 : e->g->mi_cols;
+  const int max_y4 = plane ? e->g->mi_rows >> 1 : e->g->mi_rows;
+  int k, ctx, c;
+  TileCdfs *cdf = &e->cdf;
+  const int16_t *scan = av1o_default_scan(bwl);
+  /* --- all_zero (txb_skip) context */
+  if (plane == 0) {
+    int top = 0, left = 0;
+    for (k = 0; k < w4; k++) {
+      if (x4 + k < max_x4 && e->above_lvl[0][x4 + k] > top) top = e->above_lvl[0][x4 + k];
+      if (y4_abs + k < max_y4 && e->left_lvl[0][y4_sb + k] > left) left = e->left_lvl[0][y4_sb + k];
+    }
+    if (bw_eq_tx) ctx = 0;
+    else if (top == 0 && left == 0) ctx = 1;
+    else if (top == 0 || left == 0) ctx = 2 + ((top > left ? top : left) > 3);
+    else if ((top > left ? top : left) <= 3) ctx = 4;
+    else if ((top < left ? top : left) <= 3) ctx = 5;
+    else ctx = 6;
+  } else {
+    int above = 0, left = 0;
+    for (k = 0; k < w4; k++) {
+      if (x4 + k < max_x4) above |= e->above_lvl[plane][x4 + k] | e->above_dc[plane][x4 + k];
+      if (y4_abs + k < max_y4) left |= e->left_lvl[plane][y4_sb + k] | e->left_dc[plane][y4_sb + k];
+    }
+    ctx = 7 + (above != 0) + (left != 0);
+    /* (+3 when the plane block is larger than the transform: never with TX_MODE_LARGEST squares) */
+  }
+  WRITE_SYM(e, t->eob == 0, cdf->txb_skip[txs_ctx][ctx], 2);
+  if (t->eob == 0) {
+    for (k = 0; k < w4; k++) {
+      if (x4 + k < max_x4) { e->above_lvl[plane][x4 + k] = 0; e->above_dc[plane][x4 + k] = 0; }
+      if (y4_abs + k < max_y4) { e->left_lvl[plane][y4_sb + k] = 0; e->left_dc[plane][y4_sb + k] = 0; }
+    }
+    return;
+  }
+  /* --- transform_type (luma only, sets with more than one type) */
+  if (plane == 0 && log2n <= 4 && e->cfg->base_q_idx > 0) {
+    if (log2n <= 3) WRITE_SYM(e, tx_type_to_sym(1, t->tx_type), cdf->intra_tx_set1[log2n - 2][ymode], 7);
+    else WRITE_SYM(e, tx_type_to_sym(2, t->tx_type), cdf->intra_tx_set2[log2n - 2][ymode], 5);
+  }
+  /* --- eob */
+  {
+    int eob = t->eob;
+    int eob_pt = eob <= 2 ? eob : floor_log2((unsigned)(eob - 1)) + 2;
+    int base = eob_pt < 2 ? eob_pt : ((1 << (eob_pt - 2)) + 1);
+    int extra = eob - base;
+    int msz = 2 * bwl - 4; /* eobMultisize */
+    int mctx = 0;          /* TX_CLASS_2D */
+    switch (msz) {
+      case 0: WRITE_SYM(e, eob_pt - 1, cdf->eob_pt_16[ptype][mctx], 5); break;
+      case 1: WRITE_SYM(e, eob_pt - 1, cdf->eob_pt_32[ptype][mctx], 6); break;
+      case 2: WRITE_SYM(e, eob_pt - 1, cdf->eob_pt_64[ptype][mctx], 7); break;
+      case 3: WRITE_SYM(e, eob_pt - 1, cdf->eob_pt_128[ptype][mctx], 8); break;
+      case 4: WRITE_SYM(e, eob_pt - 1, cdf->eob_pt_256[ptype][mctx], 9); break;
+      case 5: WRITE_SYM(e, eob_pt - 1, cdf->eob_pt_512[ptype][mctx], 10); break;
+      default: WRITE_SYM(e, eob_pt - 1, cdf->eob_pt_1024[ptype][mctx], 11); break;
+    }
+    if (eob_pt >= 3) {
+      int nbits = eob_pt - 2, i;
+      int bit = (extra >> (nbits - 1)) & 1;
+      WRITE_SYM(e, bit, cdf->eob_extra[txs_ctx][ptype][eob_pt - 3], 2);
+      for (i = 1; i < nbits; i++) av1o_ec_encode_literal(&e->ec, (unsigned)((extra >> (nbits - 1 - i)) & 1), 1);
+    }
+  }
+  /* --- levels, reverse scan order */
+  for (c = t->eob - 1; c >= 0; c--) {
+    int pos = scan[c];
+    int row = pos >> bwl, col = pos & (cw - 1);
+    int level = abs(t->level[pos]);
+#define LV(r_, c_) (((r_) < cw && (c_) < cw) ? abs(t->level[((r_) << bwl) + (c_)]) : 0)
+    if (c == t->eob - 1) {
+      int cctx = c == 0 ? 0 : (c <= (cw * cw) / 8 ? 1 : (c <= (cw * cw) / 4 ? 2 : 3));
+      WRITE_SYM(e, (level > 3 ? 3 : level) - 1, cdf->coeff_base_eob[txs_ctx][ptype][cctx], 3);
+    } else {
+      int mag, cctx;
+#define M3(v) ((v) > 3 ? 3 : (v))
+      mag = M3(LV(row, col + 1)) + M3(LV(row + 1, col)) + M3(LV(row + 1, col + 1)) + M3(LV(row, col + 2)) + M3(LV(row + 2, col));
+      if (row == 0 && col == 0) cctx = 0;
+      else {
+        cctx = (mag + 1) >> 1;
+        if (cctx > 4) cctx = 4;
+        cctx += coeff_base_ctx_offset(log2n, row, col);
+      }
+      WRITE_SYM(e, level > 3 ? 3 : level, cdf->coeff_base[txs_ctx][ptype][cctx], 4);
+    }
+    if (level > 2) {
+      int mag, bctx, idx;
+#define M15(v) ((v) > 15 ? 15 : (v))
+      mag = M15(LV(row, col + 1)) + M15(LV(row + 1, col)) + M15(LV(row + 1, col + 1));
+      mag = (mag + 1) >> 1;
+      if (mag > 6) mag = 6;
+      if (pos == 0) bctx = mag;
+      else if (row < 2 && col < 2) bctx = mag + 7;
+      else bctx = mag + 14;
+      for (idx = 0; idx < 4; idx++) {
+        int rem = level - 3 - idx * 3;
+        int k3 = rem > 3 ? 3 : rem;
+        WRITE_SYM(e, k3, cdf->coeff_br[txs_ctx > 3 ? 3 : txs_ctx][ptype][bctx], 4);
+        if (k3 < 3) break;
+      }
+    }
+  }
+  /* --- signs + golomb, forward scan order; context bookkeeping */
+  {
+    int cul = 0, dc_cat = 0;
+    for (c = 0; c < t->eob; c++) {
+      int pos = scan[c];
+      int v = t->level[pos], level = abs(v);
+      if (!level) continue;
+      if (c == 0) {
+        int dsum = 0, dctx;
+        for (k = 0; k < w4; k++) {
+          if (x4 + k < max_x4) { int s = e->above_dc[plane][x4 + k]; dsum += s == 1 ? -1 : (s == 2 ? 1 : 0); }
+          if (y4_abs + k < max_y4) { int s = e->left_dc[plane][y4_sb + k]; dsum += s == 1 ? -1 : (s == 2 ? 1 : 0); }
+        }
+        dctx = dsum < 0 ? 1 : (dsum > 0 ? 2 : 0);
+        WRITE_SYM(e, v < 0, cdf->dc_sign[ptype][dctx], 2);
+      } else {
+        av1o_ec_encode_literal(&e->ec, v < 0, 1);
+      }
+      if (level > 14) write_golomb(e, (unsigned)(level - 15));
+      cul += level;
+      if (pos == 0) dc_cat = v < 0 ? 1 : 2;
+    }
+    if (cul > 63) cul = 63;
+    for (k = 0; k < w4; k++) {
+      if (x4 + k < max_x4) { e->above_lvl[plane][x4 + k] = (uint8_t)cul; e->above_dc[plane][x4 + k] = (uint8_t)dc_cat; }
+      if (y4_abs + k < max_y4) { e->left_lvl[plane][y4_sb + k] = (uint8_t)cul; e->left_dc[plane][y4_sb + k] = (uint8_t)dc_cat; }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ prediction edges §7.11.2 */
+static void prepare_edges(const Enc *e, int plane, int x, int y, int n, int have_left, int have_above,
+                          int have_above_rt, int have_below_lft, uint16_t *above_m1, uint16_t *left_m1) {
+  const uint16_t *f = e->rec->p[plane];
+  const int stride = e->rec->stride[plane];
+  const int bd = e->cfg->bit_depth;
+  const int max_x = (plane ? e->cfg->width / 2 : e->cfg->width) - 1;
+  const int max_y = (plane ? e->cfg->height / 2 : e->cfg->height) - 1;
+  uint16_t *A = above_m1 + 1, *L = left_m1 + 1;
+  int i;
+  if (!have_above && have_left) {
+    for (i = 0; i < 2 * n; i++) A[i] = f[y * stride + x - 1];
+  } else if (!have_above && !have_left) {
+    for (i = 0; i < 2 * n; i++) A[i] = (uint16_t)((1 << (bd - 1)) - 1);
+  } else {
+    int lim = x + (have_above_rt ? 2 * n : n) - 1;
+    if (lim > max_x) lim = max_x;
+    for (i = 0; i < 2 * n; i++) A[i] = f[(y - 1) * stride + (x + i < lim ? x + i : lim)];
+  }
+  if (!have_left && have_above) {
+    for (i = 0; i < 2 * n; i++) L[i] = f[(y - 1) * stride + x];
+  } else if (!have_left && !have_above) {
+    for (i = 0; i < 2 * n; i++) L[i] = (uint16_t)((1 << (bd - 1)) + 1);
+  } else {
+    int lim = y + (have_below_lft ? 2 * n : n) - 1;
+    if (lim > max_y) lim = max_y;
+    for (i = 0; i < 2 * n; i++) L[i] = f[(y + i < lim ? y + i : lim) * stride + x - 1];
+  }
+  if (have_above && have_left) A[-1] = f[(y - 1) * stride + x - 1];
+  else if (have_above) A[-1] = f[(y - 1) * stride + x];
+  else if (have_left) A[-1] = f[y * stride + x - 1];
+  else A[-1] = (uint16_t)(1 << (bd - 1));
+  L[-1] = A[-1];
+}
+
+/* ------------------------------------------------------------------ quantiser */
+static int tx_scale_shift(int log2n) { return log2n >= 6 ? 2 : (log2n == 5 ? 1 : 0); }
+
+/* forward transform + dead-zone quantise -> levels; dequantise + inverse -> recon in place.
+ * Returns eob.  DESIGN.md §3.5: level = ((|coef| << s) + (3q >> 3)) * ceil(2^32/q) >> 32. */
+static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type, TxbCoefs *t) {
+  const int n = 1 << log2n, bd = e->cfg->bit_depth;
+  const int cw = n > 32 ? 32 : n, bwl = log2n > 5 ? 5 : log2n;
+  const int sh = tx_scale_shift(log2n);
+  const uint16_t *src = e->src->p[plane] + (size_t)y * e->src->stride[plane] + x;
+  uint16_t *rec = e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x;
+  const int sstride = e->src->stride[plane], rstride = e->rec->stride[plane];
+  int32_t *resid = (int32_t *)malloc(sizeof(int32_t) * n * n * 2);
+  int32_t *coef = resid + n * n;
+  const int16_t *scan = av1o_default_scan(bwl);
+  int i, j, eob = 0, c;
+  t->tx_type = tx_type;
+  memset(t->level, 0, sizeof(int32_t) * cw * cw);
+  for (i = 0; i < n; i++)
+    for (j = 0; j < n; j++) resid[i * n + j] = (int32_t)src[i * sstride + j] - (int32_t)rec[i * rstride + j];
+  if (e->cfg->fuzz_coeffs) {
+    for (c = 0; c < cw * cw; c++) {
+      if (fuzz_rand(e) % (unsigned)e->cfg->fuzz_density == 0) {
+        int lv = 1 + (int)(fuzz_rand(e) % (unsigned)e->cfg->fuzz_maxlevel);
+        if (fuzz_rand(e) & 1) lv = 1 + (lv & 1);
+        t->level[scan[c]] = (fuzz_rand(e) & 1) ? -lv : lv;
+      }
+      if ((fuzz_rand(e) & 63) == 0) break; /* vary eob */
+    }
+  } else {
+    av1o_fwd_txfm2d(resid, n, coef, log2n, tx_type, bd);
+    for (i = 0; i < cw; i++)
+      for (j = 0; j < cw; j++) {
+        int32_t v = coef[i * n + j];
+        uint32_t q = (uint32_t)((i | j) ? e->ac_q : e->dc_q);
+        uint32_t recip = (uint32_t)((((uint64_t)1 << 32) + q - 1) / q);
+        uint32_t a = ((uint32_t)abs(v) << sh) + ((3 * q) >> 3);
+        uint32_t lv = (uint32_t)(((uint64_t)a * recip) >> 32);
+        if (lv > 0x7FFF) lv = 0x7FFF;
+        t->level[(i << bwl) + j] = v < 0 ? -(int32_t)lv : (int32_t)lv;
+      }
+  }
+  for (c = 0; c < cw * cw; c++)
+    if (t->level[scan[c]]) eob = c + 1;
+  t->eob = eob;
+  if (eob) {
+    /* normative dequant §7.12.3 */
+    int32_t *dq = coef;
+    memset(dq, 0, sizeof(int32_t) * n * n);
+    for (i = 0; i < cw; i++)
+      for (j = 0; j < cw; j++) {
+        int32_t lv = t->level[(i << bwl) + j];
+        if (lv) {
+          uint32_t q = (uint32_t)((i | j) ? e->ac_q : e->dc_q);
+          int64_t d = ((int64_t)abs(lv) * q) & 0xFFFFFF;
+          int64_t lim = (int64_t)1 << (7 + bd);
+          d >>= sh;
+          if (lv < 0) d = -d;
+          if (d < -lim) d = -lim;
+          if (d > lim - 1) d = lim - 1;
+          dq[i * n + j] = (int32_t)d;
+        }
+      }
+    av1o_inv_txfm2d_add(dq, rec, rstride, log2n, tx_type, bd, eob);
+  }
+  free(resid);
+  return eob;
+}
+
+/* ------------------------------------------------------------------ block coding §5.11.5 */
+typedef struct { int ymode, yangle, uvmode, uvangle; } ModeDec;
+
+static int block_sad(const uint16_t *a, int as, const uint16_t *b, int bs, int n) {
+  int i, j, s = 0;
+  for (i = 0; i < n; i++)
+    for (j = 0; j < n; j++) s += abs((int)a[i * as + j] - (int)b[i * bs + j]);
+  return s;
+}
+
+static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size in px */) {
+  const Av1oConfig *cfg = e->cfg;
+  const Geom *g = e->g;
+  const int n = 1 << bsl, bw4 = n >> 2;
+  const int bd = cfg->bit_depth;
+  const int avail_u = is_inside(e, mi_r - 1, mi_c), avail_l = is_inside(e, mi_r, mi_c - 1);
+  const int sb_r = mi_r & 15, sb_c = mi_c & 15; /* within SB, luma 4x4 units */
+  uint16_t edge_a[2 * 64 + 16], edge_l[2 * 64 + 16];
+  uint16_t *pred = (uint16_t *)malloc(sizeof(uint16_t) * n * n);
+  TxbCoefs *ty = (TxbCoefs *)malloc(sizeof(TxbCoefs) * 3);
+  TxbCoefs *tu = ty + 1, *tv = ty + 2;
+  ModeDec md = { DC_PRED, 0, DC_PRED, 0 };
+  int plane, i, j, skip;
+  int have_ar[2], have_bl[2];
+  const int log2n_y = bsl, log2n_uv = bsl - 1 > 5 ? 5 : bsl - 1;
+  int tx_y, tx_uv;
+
+  /* haveAboveRt / haveBelowLft from BlockDecoded (§5.11.35), luma and chroma */
+  for (plane = 0; plane < 2; plane++) {
+    int ss = plane;
+    int step = (plane ? (1 << log2n_uv) : n) >> 2;
+    int r4 = sb_r >> ss, c4 = sb_c >> ss;
+    have_ar[plane] = e->block_decoded[plane][r4 - 1 + 1][c4 + step + 1];
+    have_bl[plane] = e->block_decoded[plane][r4 + step + 1][c4 - 1 + 1];
+  }
+
+  /* ---- luma mode decision: closed-loop prediction SAD */
+  {
+    int x = mi_c * 4, y = mi_r * 4, best = -1, m;
+    const uint16_t *src = e->src->p[0] + (size_t)y * e->src->stride[0] + x;
+    prepare_edges(e, 0, x, y, n, avail_l, avail_u, have_ar[0], have_bl[0], edge_a, edge_l);
+    if (cfg->fuzz_modes) {
+      md.ymode = (int)(fuzz_rand(e) % 13);
+      while (!((cfg->mode_mask >> md.ymode) & 1)) md.ymode = (md.ymode + 1) % 13;
+      md.yangle = (md.ymode >= V_PRED && md.ymode <= D67_PRED) ? (int)(fuzz_rand(e) % 7) - 3 : 0;
+      md.uvmode = (int)(fuzz_rand(e) % 13);
+      while (!((cfg->mode_mask >> md.uvmode) & 1)) md.uvmode = (md.uvmode + 1) % 13;
+      md.uvangle = (md.uvmode >= V_PRED && md.uvmode <= D67_PRED) ? (int)(fuzz_rand(e) % 7) - 3 : 0;
+    } else {
+      for (m = 0; m < 13; m++) {
+        int sad;
+        if (!((cfg->mode_mask >> m) & 1)) continue;
+        av1o_predict_intra(pred, n, bsl, m, 0, edge_a, edge_l, avail_u, avail_l, bd);
+        sad = block_sad(src, e->src->stride[0], pred, n, n);
+        if (best < 0 || sad < best) { best = sad; md.ymode = m; }
+      }
+      md.uvmode = md.ymode;
+    }
+    av1o_predict_intra(e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0], bsl, md.ymode, md.yangle,
+                       edge_a, edge_l, avail_u, avail_l, bd);
+  }
+  tx_y = log2n_y <= 4 ? mode_to_txfm[md.ymode] : DCT_DCT;
+  tx_uv = log2n_uv <= 4 ? mode_to_txfm[md.uvmode] : DCT_DCT;
+  code_tx_block(e, 0, mi_c * 4, mi_r * 4, log2n_y, tx_y, ty);
+  /* ---- chroma */
+  for (plane = 1; plane < 3; plane++) {
+    int nc = 1 << log2n_uv, x = mi_c * 2, y = mi_r * 2;
+    prepare_edges(e, plane, x, y, nc, avail_l, avail_u, have_ar[1], have_bl[1], edge_a, edge_l);
+    av1o_predict_intra(e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane], log2n_uv,
+                       md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd);
+    code_tx_block(e, plane, x, y, log2n_uv, tx_uv, plane == 1 ? tu : tv);
+  }
+  skip = ty->eob == 0 && tu->eob == 0 && tv->eob == 0;
+
+  /* ---- syntax: intra_frame_mode_info */
+  {
+    int ctx = 0;
+    if (avail_u) ctx += e->mi_skip[(mi_r - 1) * g->mi_cols + mi_c];
+    if (avail_l) ctx += e->mi_skip[mi_r * g->mi_cols + mi_c - 1];
+    WRITE_SYM(e, skip, e->cdf.skip[ctx], 2);
+  }
+  /* read_cdef: cdef_bits == 0 -> no literal, but remember that this SB has a coded cdef_idx */
+  if (!skip && cfg->enable_cdef) e->cdef_idx_sb[(mi_r >> 4) * g->sb_cols + (mi_c >> 4)] = 0;
+  {
+    int am = intra_mode_context[avail_u ? e->mi_ymode[(mi_r - 1) * g->mi_cols + mi_c] : DC_PRED];
+    int lm = intra_mode_context[avail_l ? e->mi_ymode[mi_r * g->mi_cols + mi_c - 1] : DC_PRED];
+    WRITE_SYM(e, md.ymode, e->cdf.kf_y_mode[am][lm], 13);
+  }
+  if (md.ymode >= V_PRED && md.ymode <= D67_PRED) WRITE_SYM(e, md.yangle + 3, e->cdf.angle_delta[md.ymode - V_PRED], 7);
+  {
+    int cfl_allowed = n <= 32;
+    WRITE_SYM(e, md.uvmode, e->cdf.uv_mode[cfl_allowed][md.ymode], cfl_allowed ? 14 : 13);
+  }
+  if (md.uvmode >= V_PRED && md.uvmode <= D67_PRED) WRITE_SYM(e, md.uvangle + 3, e->cdf.angle_delta[md.uvmode - V_PRED], 7);
+  /* (palette: allow_screen_content_tools = 0; filter intra: disabled; tx_size: TX_MODE_LARGEST) */
+
+  /* ---- residual */
+  if (skip) {
+    /* reset_block_context */
+    for (plane = 0; plane < 3; plane++) {
+      int ss = plane > 0, w4 = bw4 >> ss ? bw4 >> ss : 1;
+      int x4 = mi_c >> ss, y4 = (mi_r & 15) >> ss;
+      for (i = 0; i < w4; i++) {
+        e->above_lvl[plane][x4 + i] = 0; e->above_dc[plane][x4 + i] = 0;
+        e->left_lvl[plane][y4 + i] = 0;  e->left_dc[plane][y4 + i] = 0;
+      }
+    }
+  } else {
+    write_coeffs(e, 0, log2n_y, mi_c, sb_r, mi_r, ty, md.ymode, 1);
+    write_coeffs(e, 1, log2n_uv, mi_c >> 1, sb_r >> 1, mi_r >> 1, tu, md.ymode, 1);
+    write_coeffs(e, 2, log2n_uv, mi_c >> 1, sb_r >> 1, mi_r >> 1, tv, md.ymode, 1);
+  }
+  /* ---- bookkeeping */
+  for (i = 0; i < bw4; i++)
+    for (j = 0; j < bw4; j++) {
+      int idx = (mi_r + i) * g->mi_cols + mi_c + j;
+      if (mi_r + i < g->mi_rows && mi_c + j < g->mi_cols) {
+        e->mi_bsl[idx] = (uint8_t)bsl;
+        e->mi_skip[idx] = (uint8_t)skip;
+        e->mi_ymode[idx] = (uint8_t)md.ymode;
+      }
+    }
+  for (plane = 0; plane < 2; plane++) {
+    int ss = plane, w4 = (bw4 >> ss) ? (bw4 >> ss) : 1;
+    int r4 = sb_r >> ss, c4 = sb_c >> ss, pl2;
+    for (pl2 = plane; pl2 < (plane ? 3 : 1); pl2++)
+      for (i = 0; i < w4; i++)
+        for (j = 0; j < w4; j++) e->block_decoded[pl2][r4 + i + 1][c4 + j + 1] = 1;
+  }
+  if (e->stats) {
+    e->stats->n_blocks++;
+    e->stats->n_skip_blocks += (uint64_t)skip;
+    e->stats->mode_hist[md.ymode]++;
+    e->stats->bs_hist[bsl]++;
+  }
+  free(pred);
+  free(ty);
+}
+
+/* ------------------------------------------------------------------ partition §5.11.4 */
+static int icdf_prob(const uint16_t *icdf, int el) { return (el > 0 ? icdf[el - 1] : 32768) - icdf[el]; }
+
+static void encode_partition(Enc *e, int mi_r, int mi_c, int bsl) {
+  const Geom *g = e->g;
+  const Av1oConfig *cfg = e->cfg;
+  int n4 = 1 << (bsl - 2), half = n4 >> 1;
+  int has_rows, has_cols, split, ctx, bsl_idx;
+  uint16_t *pc;
+  if (mi_r >= g->mi_rows || mi_c >= g->mi_cols) return;
+  has_rows = (mi_r + half) < g->mi_rows;
+  has_cols = (mi_c + half) < g->mi_cols;
+  /* encoder decision: a block may be a leaf only if it lies fully inside the frame */
+  if (bsl <= cfg->min_bs_log2 || bsl == 3) split = 0;
+  else if (bsl > cfg->max_bs_log2) split = 1;
+  else split = 0;
+  if (mi_r + n4 > g->mi_rows || mi_c + n4 > g->mi_cols) split = 1;
+  if (bsl == 3) split = 0;
+  /* context (§8.3.2 partition): neighbours' block sizes */
+  {
+    int avail_u = is_inside(e, mi_r - 1, mi_c), avail_l = is_inside(e, mi_r, mi_c - 1);
+    int above = avail_u && e->mi_bsl[(mi_r - 1) * g->mi_cols + mi_c] < bsl;
+    int left = avail_l && e->mi_bsl[mi_r * g->mi_cols + mi_c - 1] < bsl;
+    ctx = left * 2 + above;
+  }
+  bsl_idx = bsl - 3; /* 8x8 -> 0 ... 64x64 -> 3 */
+  pc = e->cdf.partition[bsl_idx * 4 + ctx];
+  if (has_rows && has_cols) {
+    WRITE_SYM(e, split ? PARTITION_SPLIT : PARTITION_NONE, pc, bsl == 3 ? 4 : 10);
+  } else if (has_cols) {
+    /* split_or_horz: P(split) gathered from the vert-alike partitions (no adaptation) */
+    int p = icdf_prob(pc, 2) + icdf_prob(pc, 3);
+    if (bsl != 3) p += icdf_prob(pc, 4) + icdf_prob(pc, 6) + icdf_prob(pc, 7) + icdf_prob(pc, 9);
+    av1o_ec_encode_bool(&e->ec, 1, (unsigned)p); /* must split (block crosses the bottom edge) */
+    split = 1;
+  } else if (has_rows) {
+    int p = icdf_prob(pc, 1) + icdf_prob(pc, 3);
+    if (bsl != 3) p += icdf_prob(pc, 4) + icdf_prob(pc, 5) + icdf_prob(pc, 6) + icdf_prob(pc, 8);
+    av1o_ec_encode_bool(&e->ec, 1, (unsigned)p);
+    split = 1;
+  } else {
+    split = 1;
+  }
+  if (!split) {
+    encode_block(e, mi_r, mi_c, bsl);
+  } else {
+    encode_partition(e, mi_r, mi_c, bsl - 1);
+    encode_partition(e, mi_r, mi_c + half, bsl - 1);
+    encode_partition(e, mi_r + half, mi_c, bsl - 1);
+    encode_partition(e, mi_r + half, mi_c + half, bsl - 1);
+  }
+}
+
+static void clear_block_decoded(Enc *e, int mi_r, int mi_c) {
+  int plane, y, x;
+  for (plane = 0; plane < 3; plane++) {
+    int ss = plane > 0;
+    int sbw4 = (e->mi_col_end - mi_c) >> ss, sbh4 = (e->mi_row_end - mi_r) >> ss, sz = 16 >> ss;
+    for (y = -1; y <= sz; y++)
+      for (x = -1; x <= sz; x++) {
+        int v;
+        if (y < 0 && x < sbw4) v = 1;
+        else if (x < 0 && y < sbh4) v = 1;
+        else v = 0;
+        e->block_decoded[plane][y + 1][x + 1] = (uint8_t)v;
+      }
+    e->block_decoded[plane][sz + 1][0] = 0;
+  }
+}
+
+static size_t encode_tile(Enc *e, int tr, int tc, uint8_t *out, size_t cap) {
+  const Geom *g = e->g;
+  int r, c, p;
+  e->mi_row_start = g->row_start_sb[tr] * 16;
+  e->mi_row_end = g->row_start_sb[tr + 1] * 16 < g->mi_rows ? g->row_start_sb[tr + 1] * 16 : g->mi_rows;
+  e->mi_col_start = g->col_start_sb[tc] * 16;
+  e->mi_col_end = g->col_start_sb[tc + 1] * 16 < g->mi_cols ? g->col_start_sb[tc + 1] * 16 : g->mi_cols;
+  init_cdfs(&e->cdf, e->cfg->base_q_idx);
+  av1o_ec_init(&e->ec, out, cap);
+  for (p = 0; p < 3; p++) {
+    memset(e->above_lvl[p], 0, (size_t)g->mi_cols + 16);
+    memset(e->above_dc[p], 0, (size_t)g->mi_cols + 16);
+  }
+  for (r = e->mi_row_start; r < e->mi_row_end; r += 16) {
+    memset(e->left_lvl, 0, sizeof(e->left_lvl));
+    memset(e->left_dc, 0, sizeof(e->left_dc));
+    for (c = e->mi_col_start; c < e->mi_col_end; c += 16) {
+      clear_block_decoded(e, r, c);
+      encode_partition(e, r, c, 6);
+    }
+  }
+  {
+    size_t n = av1o_ec_finish(&e->ec);
+    if (e->stats) e->stats->n_symbols += e->ec.nsym;
+    return e->ec.error ? (size_t)-1 : n;
+  }
+}
+
+/* ------------------------------------------------------------------ frame */
+long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq_hdr, uint8_t *out, size_t out_cap,
+                       Av1oFrame *recon, Av1oStats *stats) {
+  Geom g;
+  Enc *e;
+  size_t pos = 0, payload_cap, hdr_bits, n_mi;
+  uint8_t *payload, *tilebuf;
+  int tr, tc, p, bd = cfg->bit_depth;
+  long ret = -1;
+  if (cfg->width % 8 || cfg->height % 8 || cfg->width < 8 || cfg->height < 8) return -2;
+  if (bd != 8 && bd != 10) return -2;
+  make_geom(cfg, &g);
+  if (g.tile_cols > 64 || g.tile_rows > 64) return -3;
+  e = (Enc *)calloc(1, sizeof(Enc));
+  e->cfg = cfg;
+  e->g = &g;
+  e->src = src;
+  e->rec = av1o_frame_alloc(cfg->width, cfg->height);
+  n_mi = (size_t)g.mi_rows * g.mi_cols;
+  e->mi_bsl = (uint8_t *)calloc(n_mi, 1);
+  e->mi_skip = (uint8_t *)calloc(n_mi, 1);
+  e->mi_ymode = (uint8_t *)calloc(n_mi, 1);
+  e->cdef_idx_sb = (int8_t *)malloc((size_t)g.sb_rows * g.sb_cols);
+  memset(e->cdef_idx_sb, -1, (size_t)g.sb_rows * g.sb_cols);
+  for (p = 0; p < 3; p++) {
+    e->above_lvl[p] = (uint8_t *)calloc((size_t)g.mi_cols + 16, 1);
+    e->above_dc[p] = (uint8_t *)calloc((size_t)g.mi_cols + 16, 1);
+  }
+  e->dc_q = bd == 8 ? av1_dc_q8[cfg->base_q_idx] : av1_dc_q10[cfg->base_q_idx];
+  e->ac_q = bd == 8 ? av1_ac_q8[cfg->base_q_idx] : av1_ac_q10[cfg->base_q_idx];
+  e->stats = stats;
+  e->rng_state = (uint32_t)(cfg->fuzz_coeffs ? cfg->fuzz_coeffs : (cfg->fuzz_modes ? cfg->fuzz_modes : 1)) * 2654435761u + 1u;
+  if (stats) memset(stats, 0, sizeof(*stats));
+
+  payload_cap = (size_t)cfg->width * cfg->height * 4 + (size_t)g.tile_cols * g.tile_rows * 64 + 4096;
+  payload = (uint8_t *)malloc(payload_cap);
+  tilebuf = (uint8_t *)malloc(payload_cap);
+
+  /* temporal delimiter + optional sequence header */
+  if (out_cap < 64) goto done;
+  out[pos++] = (2 << 3) | 2;
+  out[pos++] = 0;
+  if (with_seq_hdr) {
+    long k = av1o_write_sequence_header(cfg, out + pos, out_cap - pos);
+    if (k < 0) goto done;
+    pos += (size_t)k;
+  }
+  /* OBU_FRAME payload = frame_header_obu + byte_alignment + tile_group_obu */
+  {
+    size_t pp;
+    BitW b;
+    hdr_bits = frame_header_bits(cfg, &g, payload, payload_cap);
+    b.buf = payload; b.cap = payload_cap; b.pos = hdr_bits;
+    bw_align(&b); /* byte_alignment() after the frame header inside OBU_FRAME */
+    if (g.tile_cols * g.tile_rows > 1) {
+      bw_put(&b, 0, 1); /* tile_start_and_end_present_flag */
+      bw_align(&b);
+    }
+    pp = b.pos >> 3;
+    for (tr = 0; tr < g.tile_rows; tr++)
+      for (tc = 0; tc < g.tile_cols; tc++) {
+        int last = tr == g.tile_rows - 1 && tc == g.tile_cols - 1;
+        size_t n = encode_tile(e, tr, tc, tilebuf, payload_cap);
+        if (n == (size_t)-1 || pp + n + 8 > payload_cap) goto done;
+        if (!last) {
+          uint32_t v = (uint32_t)(n - 1);
+          payload[pp++] = (uint8_t)v; payload[pp++] = (uint8_t)(v >> 8);
+          payload[pp++] = (uint8_t)(v >> 16); payload[pp++] = (uint8_t)(v >> 24);
+        }
+        memcpy(payload + pp, tilebuf, n);
+        pp += n;
+      }
+    if (pos + 1 + (size_t)leb128_size(pp) + pp > out_cap) goto done;
+    out[pos++] = (6 << 3) | 2; /* OBU_FRAME */
+    pos += put_leb128(out + pos, pp);
+    memcpy(out + pos, payload, pp);
+    pos += pp;
+  }
+  /* CDEF -> final reconstruction */
+  if (recon || stats) {
+    Av1oFrame *fin = recon ? recon : av1o_frame_alloc(cfg->width, cfg->height);
+    av1o_cdef_frame(cfg, e->rec, fin, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
+    if (stats) {
+      for (p = 0; p < 3; p++) {
+        int pw = p ? cfg->width / 2 : cfg->width, ph = p ? cfg->height / 2 : cfg->height, x, y;
+        uint64_t s = 0;
+        for (y = 0; y < ph; y++)
+          for (x = 0; x < pw; x++) {
+            int d = (int)fin->p[p][y * fin->stride[p] + x] - (int)src->p[p][y * src->stride[p] + x];
+            s += (uint64_t)(d * d);
+          }
+        stats->sse[p] = s;
+      }
+    }
+    if (!recon) av1o_frame_free(fin);
+  }
+  ret = (long)pos;
+done:
+  free(payload);
+  free(tilebuf);
+  for (p = 0; p < 3; p++) { free(e->above_lvl[p]); free(e->above_dc[p]); }
+  free(e->mi_bsl); free(e->mi_skip); free(e->mi_ymode); free(e->cdef_idx_sb);
+  av1o_frame_free(e->rec);
+  free(e);
+  return ret;
+}

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Recover the AV1 *normative constant tables* (default CDFs, quantiser lookups)
+that the AV1 specification defines and this build needs, and emit them as
+`av1-base_amd/csrc/av1_tables.h`.
+
+Why a tool: there is no copy of the AV1 specification in the build container and
+no network (SURVEY.md §7 hard part 2).  The container does hold two independent,
+spec-conformant codecs inside Pillow's libavif (libaom 3.13.2 encoder, dav1d 1.5.3
+decoder).  Both embed the spec's tables in .rodata.  This script
+locates each table by a short anchor (its first few values, which are public spec
+constants), reads it with the known array shape, checks the structural invariants
+of a CDF (strictly monotone, terminated) and - where the table exists in both
+codecs - checks that the two copies agree.  Nothing here is reference (av1-base)
+code; the output is data only.
+
+The generated header is committed, so neither the tests nor the GPU box need
+Pillow.  Every table is additionally pinned end-to-end: a wrong entry desynchronises
+dav1d's arithmetic decoder and the dav1d golden fixtures in tests/golden/ fail.
+
+Usage:  python tools/extract_av1_tables.py [--lib PATH] [--out PATH]
+"""
+import argparse
+import glob
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_OUT = os.path.join(HERE, "..", "av1-base_amd", "csrc", "av1_tables.h")
+
+
+def find_lib():
+    import PIL
+    c = glob.glob(os.path.join(os.path.dirname(PIL.__file__), "..", "pillow.libs", "libavif*.so*"))
+    if not c:
+        raise SystemExit("libavif not found next to Pillow")
+    return c[0]
+
+
+class Blob:
+    def __init__(self, path):
+        self.b = open(path, "rb").read()
+        self.a = np.frombuffer(self.b, dtype=np.uint8)
+
+    def find_all(self, pat):
+        out, i = [], 0
+        while True:
+            i = self.b.find(pat, i)
+            if i < 0:
+                return out
+            out.append(i)
+            i += 1
+
+    def u16(self, off, n):
+        return self.a[off:off + 2 * n].view(np.uint16).astype(np.int64)
+
+    def s16(self, off, n):
+        return self.a[off:off + 2 * n].view(np.int16).astype(np.int64)
+
+
+def icdf_pat(vals, stride_pad=0):
+    return struct.pack("<%dH" % len(vals), *[32768 - v for v in vals])
+
+
+def read_cdf_table(blob, off, count, stride, nsym_of):
+    """Read `count` CDFs laid out every `stride` u16.  Stored inverted
+    (32768 - cumulative).  Returns list of lists of the nsym-1 cumulative values
+    (spec orientation, i.e. 32768*P(X<=i))."""
+    out = []
+    for k in range(count):
+        n = nsym_of(k) if callable(nsym_of) else nsym_of
+        raw = blob.u16(off + 2 * stride * k, stride)
+        if n == 0:  # placeholder row (unused context): must be all zero
+            assert not raw.any(), (hex(off), k, raw)
+            out.append([])
+            continue
+        v = raw[: n - 1]
+        # structural checks: strictly decreasing inverted values in (0,32768), zero padded after
+        assert all(0 < x < 32768 for x in v), (hex(off), k, raw)
+        assert all(v[i] > v[i + 1] for i in range(len(v) - 1)), (hex(off), k, raw)
+        assert not raw[n - 1:].any(), (hex(off), k, n, raw)
+        out.append([int(32768 - x) for x in v])
+    return out
+
+
+def uniq(blob, pat, what, region=None):
+    hits = blob.find_all(pat)
+    if region:
+        hits = [h for h in hits if region[0] <= h < region[1]]
+    if len(hits) < 1:
+        raise SystemExit("anchor not found: " + what)
+    return hits
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--out", default=DEFAULT_OUT)
+    args = ap.parse_args()
+    lib = args.lib or find_lib()
+    blob = Blob(lib)
+    T = {}
+
+    # ---- locate the two codecs' copies of kf_y_mode to tell their regions apart -------
+    kf_anchor = icdf_pat([15588, 17027, 19338, 20218, 20682, 21110, 21825, 23244, 24189, 28165, 29093, 30466])
+    kf_hits = blob.find_all(kf_anchor)
+    assert len(kf_hits) == 2, kf_hits
+    # libaom: CDF_SIZE(13)=14 u16 per row; dav1d pads to 16
+    def row_stride(h):
+        nxt = blob.u16(h + 28, 1)[0]
+        return 14 if nxt != 0 else 16
+    aom_kf = [h for h in kf_hits if row_stride(h) == 14][0]
+    dav_kf = [h for h in kf_hits if row_stride(h) == 16][0]
+
+    def aom(anchor_vals, what):
+        hits = blob.find_all(icdf_pat(anchor_vals))
+        # libaom's tables sit within ~256 KiB below its kf_y_mode table
+        hits = [h for h in hits if aom_kf - 0x40000 <= h <= aom_kf + 0x10000]
+        assert len(hits) == 1, (what, [hex(h) for h in hits])
+        return hits[0]
+
+    def dav(anchor_vals, what, pad=None):
+        pat = icdf_pat(anchor_vals)
+        hits = blob.find_all(pat)
+        hits = [h for h in hits if dav_kf - 0x10000 <= h <= dav_kf + 0x1000]
+        assert len(hits) >= 1, (what, [hex(h) for h in hits])
+        return hits[0]
+
+    # ---- mode CDFs (libaom layout: [..][CDF_SIZE(n)] = n+1 u16, inverted) -------------
+    T["kf_y_mode"] = (read_cdf_table(blob, aom_kf, 25, 14, 13), (5, 5), 13)
+    o = aom([2180, 5032, 7567, 22776, 26989, 30217], "angle_delta")
+    T["angle_delta"] = (read_cdf_table(blob, o, 8, 8, 7), (8,), 7)
+    o = aom([22631, 24152, 25378, 25661], "uv_mode")
+    T["uv_mode_nocfl"] = (read_cdf_table(blob, o, 13, 15, 13), (13,), 13)
+    T["uv_mode_cfl"] = (read_cdf_table(blob, o + 13 * 30, 13, 15, 14), (13,), 14)
+    o = aom([19132, 25510, 30392], "partition")
+    T["partition"] = (read_cdf_table(blob, o, 20, 11, lambda k: 4 if k < 4 else (10 if k < 16 else 8)), (20,), 10)
+    o = aom([1535, 8035, 9461, 12751, 23467, 27825], "intra_ext_tx set1")
+    # default_intra_ext_tx_cdf[3 sets][4 sizes][13 modes][17]; set1 = 7 symbols, set2 = 5 symbols
+    T["intra_tx_set1"] = (read_cdf_table(blob, o, 4 * 13, 17, 7), (4, 13), 7)
+    T["intra_tx_set2"] = (read_cdf_table(blob, o + 4 * 13 * 34, 4 * 13, 17, 5), (4, 13), 5)
+    o = aom([22801, 23489, 24293, 24756], "if_y_mode")
+    T["if_y_mode"] = (read_cdf_table(blob, o, 4, 14, 13), (4,), 13)
+    o = aom([7637, 20719, 31401, 32481], "cfl_alpha")
+    T["cfl_alpha"] = (read_cdf_table(blob, o, 6, 17, 16), (6,), 16)
+
+    # ---- coefficient CDFs (libaom token_cdfs.h layout) --------------------------------
+    # several tables start with a 2-symbol CDF; disambiguate by second row (5892)
+    hits = [h for h in blob.find_all(icdf_pat([31849]) + b"\0\0\0\0" + icdf_pat([5892]))]
+    assert len(hits) == 1
+    T["txb_skip"] = (read_cdf_table(blob, hits[0], 4 * 5 * 13, 3, 2), (4, 5, 13), 2)
+    hits = blob.find_all(icdf_pat([16961]) + b"\0\0\0\0" + icdf_pat([17223]))
+    assert len(hits) == 1, hits
+    T["eob_extra"] = (read_cdf_table(blob, hits[0], 4 * 5 * 2 * 9, 3, 2), (4, 5, 2, 9), 2)
+    hits = blob.find_all(icdf_pat([128 * 125]) + b"\0\0\0\0" + icdf_pat([128 * 102]) + b"\0\0\0\0" + icdf_pat([128 * 147]))
+    assert hits and all(b - a == 36 for a, b in zip(hits, hits[1:])), hits  # same row repeats per q-ctx/plane
+    T["dc_sign"] = (read_cdf_table(blob, hits[0], 4 * 2 * 3, 3, 2), (4, 2, 3), 2)
+    o = aom([4034, 8930, 12727], "coeff_base")
+    T["coeff_base"] = (read_cdf_table(blob, o, 4 * 5 * 2 * 42, 5, 4), (4, 5, 2, 42), 4)
+    o = aom([14298, 20718, 24174], "coeff_br")
+    T["coeff_br"] = (read_cdf_table(blob, o, 4 * 5 * 2 * 21, 5, 4), (4, 5, 2, 21), 4)
+    o = aom([17837, 29055], "coeff_base_eob")
+    T["coeff_base_eob"] = (read_cdf_table(blob, o, 4 * 5 * 2 * 4, 4, 3), (4, 5, 2, 4), 3)
+    eob_anchor = {
+        16: [840, 1039, 1980, 4895], 32: [400, 520, 977, 2102, 6542],
+        64: [329, 498, 1101, 1784, 3265, 7758], 128: [219, 482, 1140, 2091, 3680, 6028, 12586],
+        256: [310, 584, 1887, 3589, 6168, 8611, 11352, 15652],
+        512: [641, 983, 3707, 5430, 10234, 14958, 18788, 23412, 26061],
+        1024: [393, 421, 751, 1623, 3160, 6352, 13345, 18047, 22571, 25830],
+    }
+    for i, (sz, anc) in enumerate(eob_anchor.items()):
+        n = 5 + i
+        o = aom(anc, "eob_multi%d" % sz)
+        T["eob_multi%d" % sz] = (read_cdf_table(blob, o, 4 * 2 * 2, n + 1, n), (4, 2, 2), n)
+
+    # ---- small CDFs: libaom inlines these into code, take dav1d's copy -----------------
+    # dav1d stores a boolean CDF as {32768-p, counter}; n-ary as n-1 values zero padded
+    hits = blob.find_all(struct.pack("<5H", 32768 - 31671, 0, 32768 - 16515, 0, 32768 - 4576))
+    assert len(hits) == 1, hits
+    o = hits[0]
+    raw = blob.u16(o, 6)
+    assert raw[1] == 0 and raw[3] == 0 and raw[5] == 0
+    T["skip"] = ([[int(32768 - raw[0])], [int(32768 - raw[2])], [int(32768 - raw[4])]], (3,), 2)
+    assert T["skip"][0] == [[31671], [16515], [4576]]
+    hits = blob.find_all(struct.pack("<9H", 32768 - 19968, 0, 0, 0, 32768 - 19968, 0, 0, 0, 32768 - 24320))
+    assert hits and all((blob.u16(h, 48) == blob.u16(hits[0], 48)).all() for h in hits), hits
+    o = hits[0]
+    raw = blob.u16(o, 48).reshape(4, 3, 4)
+    txs = []
+    for cat in range(4):
+        for ctx in range(3):
+            n = 2 if cat == 0 else 3
+            r = raw[cat, ctx]
+            assert not r[n - 1:].any() and all(r[: n - 1] > 0)
+            txs.append([int(32768 - x) for x in r[: n - 1]])
+    T["tx_size"] = (txs, (4, 3), 3)
+    o = dav([9413, 22581], "switchable_restore")
+    raw = blob.u16(o, 8)
+    T["switchable_restore"] = ([[int(32768 - raw[0]), int(32768 - raw[1])]], (1,), 3)
+    T["use_wiener"] = ([[int(32768 - raw[4])]], (1,), 2)
+    T["use_sgrproj"] = ([[int(32768 - raw[6])]], (1,), 2)
+    assert T["use_wiener"][0] == [[11570]] and T["use_sgrproj"][0] == [[16855]]
+    o = dav([1418, 2123, 13340, 18405, 26972, 28343, 32294], "cfl_sign")
+    T["cfl_sign"] = ([[int(32768 - x) for x in blob.u16(o, 7)]], (1,), 8)
+
+    # ---- cross-check the libaom mode tables against dav1d's copies ---------------------
+    dk = read_cdf_table(blob, dav_kf, 25, 16, 13)
+    assert dk == T["kf_y_mode"][0], "kf_y_mode: libaom and dav1d disagree"
+    n_checked = 1
+    for name in ("angle_delta", "uv_mode_nocfl", "uv_mode_cfl", "intra_tx_set1", "coeff_base_eob",
+                 "coeff_br", "eob_multi16", "eob_multi1024", "cfl_alpha"):
+        rows = T[name][0]
+        # every non-uniform row of the libaom table must occur (inverted) in dav1d's region
+        found = 0
+        for i, r in enumerate(rows[:8]):
+            if not r:
+                continue
+            hits = [h for h in blob.find_all(icdf_pat(r)) if h > aom_kf + 0x10000]
+            found += bool(hits)
+            # (dav1d drops contexts that cannot occur, e.g. the 1-D class of eob_multi1024)
+            assert hits or i > 0, (name, r)
+        assert found >= 2, name
+        n_checked += 1
+
+    # ---- quantiser lookups (libaom int16 dc/ac_qlookup for 8/10/12 bit) ----------------
+    def qtab(anchor):
+        hits = blob.find_all(struct.pack("<%dh" % len(anchor), *anchor))
+        assert len(hits) == 1, (anchor, hits)
+        v = blob.s16(hits[0], 256)
+        assert all(v[i] <= v[i + 1] for i in range(255))
+        return [int(x) for x in v]
+    Q = {
+        "dc_q8": qtab([4, 8, 8, 9, 10, 11, 12, 12, 13, 14]),
+        "ac_q8": qtab([4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18]),
+        "dc_q10": qtab([4, 9, 10, 13, 15, 17, 20, 22, 25, 28]),
+        "ac_q10": qtab([4, 9, 11, 13, 16, 18, 21, 24, 27, 30]),
+        "dc_q12": qtab([4, 12, 18, 25, 33, 41, 50, 60, 70, 80]),
+        "ac_q12": qtab([4, 13, 19, 27, 35, 44, 54, 64, 75, 87]),
+    }
+    assert Q["dc_q8"][255] == 1336 and Q["ac_q8"][255] == 1828
+    # dav1d keeps dq_tbl[3][256][2] = {dc, ac} interleaved (uint16): cross-check 8-bit
+    inter = []
+    for i in range(8):
+        inter += [Q["dc_q8"][i], Q["ac_q8"][i]]
+    assert blob.find_all(struct.pack("<16H", *inter)), "dav1d dq_tbl does not match libaom qlookup"
+
+    # ---- emit ---------------------------------------------------------------------------
+    out = []
+    w = out.append
+    w("/* GENERATED by tools/extract_av1_tables.py - do not edit.")
+    w(" * AV1 normative constants (default CDFs, quantiser lookups) as defined by the AV1")
+    w(" * Bitstream & Decoding Process Specification (sections 'Default CDF tables' and")
+    w(" * 'Quantizer lookup tables'); recovered from the spec-conformant codecs in the build")
+    w(" * container and cross-checked between them (see the tool's docstring).")
+    w(" * CDF orientation: spec orientation, cdf[i] = 32768 * P(symbol <= i), the final 32768")
+    w(" * entry and the adaptation counter are NOT stored (row length = nsym-1, zero padded")
+    w(" * to the table's widest row).  */")
+    w("#ifndef AV1MI_AV1_TABLES_H")
+    w("#define AV1MI_AV1_TABLES_H")
+    w("#include <stdint.h>")
+    w("")
+    for name, (rows, dims, nsym) in T.items():
+        width = nsym - 1
+        flat = []
+        for r in rows:
+            flat += r + [0] * (width - len(r))
+        total = 1
+        for d_ in dims:
+            total *= d_
+        assert len(rows) == total, (name, len(rows), dims)
+        dimstr = "".join("[%d]" % d_ for d_ in dims) + "[%d]" % width
+        w("static const uint16_t av1_default_%s_cdf%s = {" % (name, dimstr))
+        for i in range(0, len(flat), 16):
+            w("  " + ", ".join("%d" % x for x in flat[i:i + 16]) + ",")
+        w("};")
+        w("")
+    for name, v in Q.items():
+        w("static const int16_t av1_%s[256] = {" % name)
+        for i in range(0, 256, 16):
+            w("  " + ", ".join("%d" % x for x in v[i:i + 16]) + ",")
+        w("};")
+        w("")
+    w("#endif")
+    with open(args.out, "w") as f:
+        f.write("\n".join(out) + "\n")
+    print("wrote %s: %d CDF tables, %d q tables (%d cross-checked against dav1d)" % (
+        os.path.relpath(args.out), len(T), len(Q), n_checked))
+
+
+if __name__ == "__main__":
+    main()

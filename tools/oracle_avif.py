@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Conformance-oracle harness (SURVEY.md §7 step 0, §8c "stand-in oracle").
+
+The build container ships Pillow 12.2 whose libavif 1.4.1 links dav1d 1.5.3
+(decoder) and libaom 3.13.2 (encoder).  This module
+
+  * wraps raw AV1 OBUs (what `av1mi_encode_chunk` produces) in a minimal AVIF
+    still-image container (`wrap_avif`),
+  * decodes an AVIF with dav1d and returns the *exact* Y/U/V planes at native bit
+    depth by calling libavif's public C API through ctypes (`decode_yuv`) -
+    Pillow's own plugin only returns 8-bit RGB, which is not exact for 4:2:0,
+  * encodes planes with libaom at a fixed CQ level for the reported-only CPU
+    baseline (`libaom_encode_yuv`).
+
+It is test/bench infrastructure: it is used to GENERATE the golden fixtures under
+tests/golden/ (tools/make_golden.py) and, when present on the box, by bench.py's
+reported-only cpu_baseline leg.  Tests never require it.
+"""
+import ctypes as C
+import glob
+import os
+import struct
+
+import numpy as np
+
+_lib = None
+
+
+def have_libavif():
+    try:
+        _load()
+        return True
+    except Exception:
+        return False
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    import PIL
+    cands = glob.glob(os.path.join(os.path.dirname(PIL.__file__), "..", "pillow.libs", "libavif*.so*"))
+    if not cands:
+        raise RuntimeError("libavif (bundled with Pillow) not found")
+    lib = C.CDLL(cands[0])
+    lib.avifDecoderCreate.restype = C.c_void_p
+    lib.avifDecoderDestroy.argtypes = [C.c_void_p]
+    lib.avifImageCreateEmpty.restype = C.c_void_p
+    lib.avifImageDestroy.argtypes = [C.c_void_p]
+    lib.avifDecoderReadMemory.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.avifDecoderReadMemory.restype = C.c_int
+    lib.avifResultToString.argtypes = [C.c_int]
+    lib.avifResultToString.restype = C.c_char_p
+    lib.avifVersion.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+class _AvifImageHead(C.Structure):
+    # leading fields of `struct avifImage` (libavif 1.x public header avif.h)
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_uint32),
+        ("yuvFormat", C.c_int), ("yuvRange", C.c_int), ("yuvChromaSamplePosition", C.c_int),
+        ("yuvPlanes", C.c_void_p * 3), ("yuvRowBytes", C.c_uint32 * 3),
+    ]
+
+
+# ------------------------------------------------------------------ ISO-BMFF writer
+def _box(kind, payload):
+    return struct.pack(">I4s", 8 + len(payload), kind) + payload
+
+
+def _fullbox(kind, version, flags, payload):
+    return _box(kind, struct.pack(">I", (version << 24) | flags) + payload)
+
+
+def av1c_bytes(depth=8, mono=False, seq_profile=0, seq_level_idx=31, ss=(1, 1)):
+    b0 = 0x81
+    b1 = (seq_profile << 5) | (seq_level_idx & 31)
+    high = 1 if depth > 8 else 0
+    twelve = 1 if depth == 12 else 0
+    b2 = (0 << 7) | (high << 6) | (twelve << 5) | ((1 if mono else 0) << 4) | (ss[0] << 3) | (ss[1] << 2) | 0
+    return bytes([b0, b1, b2, 0])
+
+
+def wrap_avif(obus, width, height, depth=8, mono=False, seq_level_idx=31):
+    """Minimal still-image AVIF around one temporal unit (layout verified against
+    dav1d in SURVEY.md §B.5): ftyp, meta{hdlr pitm iloc iinf iprp{ipco{ispe pixi av1C} ipma}}, mdat."""
+    ftyp = _box(b"ftyp", b"avif" + struct.pack(">I", 0) + b"avif" + b"mif1" + b"miaf")
+    hdlr = _fullbox(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"pict") + b"\0" * 12 + b"\0")
+    pitm = _fullbox(b"pitm", 0, 0, struct.pack(">H", 1))
+    infe = _fullbox(b"infe", 2, 0, struct.pack(">HH4s", 1, 0, b"av01") + b"\0")
+    iinf = _fullbox(b"iinf", 0, 0, struct.pack(">H", 1) + infe)
+    ispe = _fullbox(b"ispe", 0, 0, struct.pack(">II", width, height))
+    nch = 1 if mono else 3
+    pixi = _fullbox(b"pixi", 0, 0, bytes([nch] + [depth] * nch))
+    av1c = _box(b"av1C", av1c_bytes(depth, mono, 0, seq_level_idx))
+    ipco = _box(b"ipco", ispe + pixi + av1c)
+    ipma = _fullbox(b"ipma", 0, 0, struct.pack(">IHB", 1, 1, 3) + bytes([1, 2, 0x80 | 3]))
+    iprp = _box(b"iprp", ipco + ipma)
+
+    def meta_with(offset):
+        iloc = _fullbox(b"iloc", 0, 0, bytes([0x44, 0x00]) + struct.pack(">HHHHII", 1, 1, 0, 1, offset, len(obus)))
+        return _fullbox(b"meta", 0, 0, hdlr + pitm + iloc + iinf + iprp)
+
+    meta = meta_with(0)
+    offset = len(ftyp) + len(meta) + 8
+    meta = meta_with(offset)
+    return ftyp + meta + _box(b"mdat", bytes(obus))
+
+
+def extract_obus(avif_bytes):
+    """Return the payload of the first mdat box (single-item stills only)."""
+    i = 0
+    while i < len(avif_bytes):
+        size, kind = struct.unpack(">I4s", avif_bytes[i:i + 8])
+        if kind == b"mdat":
+            return avif_bytes[i + 8:i + size]
+        i += size
+    raise ValueError("no mdat")
+
+
+# ------------------------------------------------------------------ dav1d decode
+def decode_yuv(avif_bytes):
+    """Decode with dav1d via libavif; returns (planes, depth) where planes is a list
+    of 1 (mono) or 3 numpy arrays (uint8 or uint16) - the exact decoder output."""
+    lib = _load()
+    dec = lib.avifDecoderCreate()
+    img = lib.avifImageCreateEmpty()
+    try:
+        buf = bytes(avif_bytes)
+        r = lib.avifDecoderReadMemory(dec, img, buf, len(buf))
+        if r != 0:
+            raise RuntimeError("libavif/dav1d decode failed: %s" % lib.avifResultToString(r).decode())
+        h = _AvifImageHead.from_address(img)
+        depth = h.depth
+        planes = []
+        fmt = h.yuvFormat  # 1=444 2=422 3=420 4=400
+        for p in range(3):
+            if not h.yuvPlanes[p]:
+                break
+            pw = h.width if (p == 0 or fmt == 1) else (h.width + 1) // 2
+            ph = h.height if (p == 0 or fmt in (1, 2)) else (h.height + 1) // 2
+            rb = h.yuvRowBytes[p]
+            raw = C.string_at(h.yuvPlanes[p], rb * ph)
+            a = np.frombuffer(raw, dtype=np.uint8).reshape(ph, rb)
+            if depth > 8:
+                a = a.view(np.uint16)[:, :pw].copy()
+            else:
+                a = a[:, :pw].copy()
+            planes.append(a)
+        return planes, depth
+    finally:
+        lib.avifImageDestroy(img)
+        lib.avifDecoderDestroy(dec)
+
+
+def decode_obus(obus, width, height, depth=8, mono=False):
+    return decode_yuv(wrap_avif(obus, width, height, depth, mono))[0]
+
+
+# ------------------------------------------------------------------ libaom baseline
+def libaom_encode_gray(y, cq=30, speed=8, threads=1, extra=None):
+    """Encode one 8-bit luma plane as a monochrome AVIF with libaom (end-usage=q)."""
+    import io
+    from PIL import Image
+    adv = {"end-usage": "q", "cq-level": str(cq)}
+    if extra:
+        adv.update(extra)
+    bio = io.BytesIO()
+    Image.fromarray(y, "L").save(bio, format="AVIF", codec="aom", speed=speed, max_threads=threads,
+                                 subsampling="4:0:0", advanced=adv)
+    return bio.getvalue()
+
+
+def libaom_encode_rgb420(rgb, cq=30, speed=8, threads=1, extra=None):
+    import io
+    from PIL import Image
+    adv = {"end-usage": "q", "cq-level": str(cq)}
+    if extra:
+        adv.update(extra)
+    bio = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(bio, format="AVIF", codec="aom", speed=speed, max_threads=threads,
+                                     subsampling="4:2:0", advanced=adv)
+    return bio.getvalue()
+
+
+if __name__ == "__main__":
+    lib = _load()
+    print("libavif", lib.avifVersion().decode())
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:128, 0:192]
+    y = ((xx * 3 + yy * 2) % 256).astype(np.uint8)
+    av = libaom_encode_gray(y)
+    p, d = decode_yuv(av)
+    print("libaom mono cq30:", len(av), "bytes; planes", [q.shape for q in p], "depth", d)
+    ob = extract_obus(av)
+    p2 = decode_obus(ob, 192, 128, 8, mono=True)
+    print("re-wrapped identical:", all((a == b).all() for a, b in zip(p, p2)))
