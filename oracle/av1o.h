@@ -48,6 +48,7 @@ typedef struct {
   int enable_cdef;
   uint32_t mode_mask;     /* bit m set -> luma intra mode m is a candidate */
   int still_picture;      /* 1: reduced still-picture headers (AVIF style) */
+  int disable_cdf_update; /* 1: static default CDFs (no per-symbol adaptation) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */

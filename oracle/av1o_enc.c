@@ -215,7 +215,7 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, uint8_t *b
     bw_put(&b, 1, 1); /* show_frame */
     /* error_resilient_mode = 1 implied (key frame shown) */
   }
-  bw_put(&b, 0, 1); /* disable_cdf_update */
+  bw_put(&b, (uint32_t)cfg->disable_cdf_update, 1); /* disable_cdf_update */
   /* allow_screen_content_tools = seq_force_screen_content_tools = 0 (still: SELECT -> coded) */
   if (cfg->still_picture) bw_put(&b, 0, 1); /* allow_screen_content_tools */
   if (!cfg->still_picture) bw_put(&b, 0, 1); /* frame_size_override_flag */
@@ -223,7 +223,7 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, uint8_t *b
   /* frame_size(): from sequence; superres_params(): none */
   bw_put(&b, 0, 1); /* render_and_frame_size_different */
   /* allow_intrabc not coded (allow_screen_content_tools = 0) */
-  if (!cfg->still_picture) bw_put(&b, 1, 1); /* disable_frame_end_update_cdf */
+  if (!cfg->still_picture && !cfg->disable_cdf_update) bw_put(&b, 1, 1); /* disable_frame_end_update_cdf */
   /* tile_info() */
   {
     int sb_cols = g->sb_cols, sb_rows = g->sb_rows;
@@ -354,7 +354,7 @@ static void init_cdfs(TileCdfs *c, int qidx) {
     for (l = 0; l < 3; l++) load_cdf(c->dc_sign[j][l], av1_default_dc_sign_cdf[q][j][l], 2);
 }
 
-typedef struct {
+typedef struct Enc_ {
   const Av1oConfig *cfg;
   const Geom *g;
   const Av1oFrame *src;
@@ -405,11 +405,22 @@ static int coeff_base_ctx_offset(int log2n, int row, int col) {
   return off[row][col];
 }
 
+static void write_sym(struct Enc_ *e, int s, uint16_t *icdf, int n);
 static int is_inside(const Enc *e, int r, int c) {
   return c >= e->mi_col_start && c < e->mi_col_end && r >= e->mi_row_start && r < e->mi_row_end;
 }
 
-#define WRITE_SYM(e, s, cdf, n) av1o_ec_encode_symbol(&(e)->ec, (s), (cdf), (n))
+#define WRITE_SYM(e, s, cdf, n) write_sym((e), (s), (cdf), (n))
+
+static void write_sym(Enc *e, int s, uint16_t *icdf, int n) {
+  if (e->cfg->disable_cdf_update) {
+    uint16_t tmp[17];
+    memcpy(tmp, icdf, sizeof(uint16_t) * (size_t)(n + 1));
+    av1o_ec_encode_symbol(&e->ec, s, tmp, n);
+  } else {
+    av1o_ec_encode_symbol(&e->ec, s, icdf, n);
+  }
+}
 
 /* ------------------------------------------------------------------ coefficient coding §5.11.39 */
 typedef struct {
