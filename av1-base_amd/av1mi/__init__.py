@@ -1,0 +1,228 @@
+"""av1mi - Python binding of libav1mi (the MI355X AV1 chunk encoder) and the host-side mirror of
+the reference's encode boundary.
+
+Reference interface mirrored (files under /root/reference/crates/daemon/src):
+  encode/av1an.rs:36-61   struct Av1anEncodeParams{input_path, output_path, temp_chunks_dir,
+                          concurrency} + ::new          -> EncodeParams
+  encode/av1an.rs:17-30   enum EncodeError{Av1anFailed(i32), Av1anTerminated, Io(io::Error)}
+                                                         -> EncodeError / EncodeFailed / EncodeIo
+  encode/av1an.rs:126-139 fn run_av1an(&params) -> Result<(), EncodeError>   -> run_mi355x
+  concurrency.rs:9-18,28-89 ConcurrencyPlan + derive (av1an_workers -> `--workers`)
+                                                         -> ConcurrencyPlan / derive_plan
+
+There is NO CPU fallback: if libav1mi.so is missing this module raises at import, and without a
+HIP device every call fails with AV1MI_E_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "libav1mi.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("libav1mi.so not built (run __graft_entry__.build() or av1-base_amd/build.py): %s" % LIB_PATH)
+_lib = C.CDLL(os.path.abspath(LIB_PATH))
+
+E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_OOM, E_OVERFLOW, E_FORMAT, E_UNSUPPORTED = range(1, 8)
+
+# every symbol include/av1mi.h declares
+ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", "av1mi_last_error", "av1mi_encode_chunk",
+               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers"]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "bit_depth", "cq_level", "keyint", "block_log2", "cdf_update",
+                                          "enable_cdef", "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec",
+                                          "cdef_damping")] + [("reserved", C.c_uint32 * 8)]
+
+
+class Buf(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_size_t)]
+
+
+class Report(C.Structure):
+    _fields_ = [("frames", C.c_uint32), ("bytes", C.c_uint64), ("sse", C.c_double * 3), ("psnr", C.c_double * 3),
+                ("ms_h2d", C.c_float), ("ms_recon", C.c_float), ("ms_cdef", C.c_float), ("ms_entropy", C.c_float),
+                ("ms_pack", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float), ("n_symbols", C.c_uint64)]
+
+
+class Job(C.Structure):
+    _fields_ = [("input_path", C.c_char_p), ("output_path", C.c_char_p), ("temp_dir", C.c_char_p), ("workers", C.c_uint32),
+                ("chunk_frames", C.c_uint32), ("gpu_mask", C.c_int32), ("params", Params)]
+
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64)
+
+_lib.av1mi_default_params.argtypes = [C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32]
+_lib.av1mi_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+_lib.av1mi_ctx_destroy.argtypes = [C.c_void_p]
+_lib.av1mi_last_error.argtypes = [C.c_void_p]
+_lib.av1mi_last_error.restype = C.c_char_p
+_lib.av1mi_encode_chunk.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_int, C.POINTER(Buf),
+                                    C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(Report)]
+_lib.av1mi_free.argtypes = [C.c_void_p]
+_lib.av1mi_encode_file.argtypes = [C.POINTER(Job), PROGRESS_CB, C.c_void_p, C.POINTER(Report)]
+_lib.av1mi_cq_to_qindex.argtypes = [C.c_uint32]
+_lib.av1mi_cq_to_qindex.restype = C.c_uint32
+_lib.av1mi_abi_version.restype = C.c_uint32
+_lib.av1mi_write_headers.argtypes = [C.POINTER(Params), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t)]
+
+
+# ------------------------------------------------------------------ error taxonomy (av1an.rs:17-30)
+class EncodeError(Exception):
+    """Base of the reference's `EncodeError` variants."""
+
+
+class EncodeFailed(EncodeError):
+    """`EncodeError::Av1anFailed(code)`: the encoder returned a non-zero code."""
+
+    def __init__(self, code, detail=""):
+        super().__init__("MI355X encoder failed with code: %d%s" % (code, (" (" + detail + ")") if detail else ""))
+        self.code = code
+
+
+class EncodeIo(EncodeError):
+    """`EncodeError::Io(io::Error)`."""
+
+    def __init__(self, err):
+        super().__init__("IO error: %s" % os.strerror(err))
+        self.errno = err
+
+
+def _raise_for(rc, detail=""):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise EncodeIo(-rc)
+    raise EncodeFailed(rc, detail)
+
+
+def default_params(width, height, bit_depth=8, **kw):
+    p = Params()
+    _lib.av1mi_default_params(C.byref(p), width, height, bit_depth)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def cq_to_qindex(cq):
+    return int(_lib.av1mi_cq_to_qindex(cq))
+
+
+def write_headers(params):
+    seq = C.create_string_buffer(64)
+    fh = C.create_string_buffer(1024)
+    n = C.c_size_t(64)
+    bits = C.c_size_t(0)
+    _raise_for(_lib.av1mi_write_headers(C.byref(params), seq, C.byref(n), fh, C.byref(bits)))
+    return seq.raw[:n.value], fh.raw[:(bits.value + 7) // 8], bits.value
+
+
+class Context:
+    """One GPU + one HIP stream = one chunk in flight (include/av1mi.h: av1mi_ctx)."""
+
+    def __init__(self, device_id=0):
+        h = C.c_void_p()
+        _raise_for(_lib.av1mi_ctx_create(device_id, C.byref(h)), "av1mi_ctx_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            _lib.av1mi_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def last_error(self):
+        return _lib.av1mi_last_error(self._h).decode()
+
+    def encode_chunk(self, params, frames, n_frames, on_device=False, want_recon=False, recon_ptr=None):
+        """frames: bytes-like/numpy (host) or an int device pointer (on_device=True).
+        Returns (bitstream bytes, [frame sizes], Report, recon bytes or None)."""
+        import numpy as np
+        out = Buf()
+        sizes = (C.c_uint32 * n_frames)()
+        rep = Report()
+        bps = 2 if params.bit_depth > 8 else 1
+        nbytes = params.width * params.height * 3 // 2 * bps * n_frames
+        recon = None
+        rptr = None
+        if on_device:
+            fptr = C.c_void_p(int(frames))
+            if recon_ptr is not None:
+                rptr = C.c_void_p(int(recon_ptr))
+        else:
+            arr = np.ascontiguousarray(np.frombuffer(frames, dtype=np.uint8) if not isinstance(frames, np.ndarray) else frames)
+            if arr.nbytes != nbytes:
+                raise ValueError("frames: expected %d bytes, got %d" % (nbytes, arr.nbytes))
+            fptr = arr.ctypes.data_as(C.c_void_p)
+            if want_recon:
+                recon = np.empty(nbytes, dtype=np.uint8)
+                rptr = recon.ctypes.data_as(C.c_void_p)
+        rc = _lib.av1mi_encode_chunk(self._h, C.byref(params), fptr, n_frames, 1 if on_device else 0, C.byref(out), sizes, rptr,
+                                     C.byref(rep))
+        if rc:
+            _raise_for(rc, self.last_error())
+        data = C.string_at(out.data, out.size)
+        _lib.av1mi_free(out.data)
+        return data, list(sizes), rep, recon
+
+
+# ------------------------------------------------------------------ ConcurrencyPlan (concurrency.rs:9-89)
+class ConcurrencyPlan:
+    def __init__(self, total_cores, target_threads, av1an_workers, max_concurrent_jobs):
+        self.total_cores = total_cores
+        self.target_threads = target_threads
+        self.av1an_workers = av1an_workers
+        self.max_concurrent_jobs = max_concurrent_jobs
+
+
+def derive_plan(total_cores, target_cpu_utilization=0.85, workers_override=0, max_jobs_override=0):
+    """Restates ConcurrencyPlan::derive (concurrency.rs:28-61): utilisation clamped to [0.5, 1.0],
+    8 workers if >= 32 cores else 4, 1 job if >= 24 cores else 2; overrides win when non-zero."""
+    util = min(1.0, max(0.5, float(target_cpu_utilization)))
+    target_threads = max(1, int(round(total_cores * util)))
+    workers = workers_override if workers_override else (8 if total_cores >= 32 else 4)
+    jobs = max_jobs_override if max_jobs_override else (1 if total_cores >= 24 else 2)
+    return ConcurrencyPlan(total_cores, target_threads, workers, jobs)
+
+
+# ------------------------------------------------------------------ the boundary (av1an.rs:36-139)
+class EncodeParams:
+    """Field for field `Av1anEncodeParams` (av1an.rs:36-45), plus the operating point that the
+    reference hard-codes as SVT_PARAMS (av1an.rs:14)."""
+
+    def __init__(self, input_path, output_path, temp_chunks_dir, concurrency, cq_level=30, chunk_frames=60, gpu_mask=0, **enc):
+        self.input_path = os.fspath(input_path)
+        self.output_path = os.fspath(output_path)
+        self.temp_chunks_dir = os.fspath(temp_chunks_dir)
+        self.concurrency = concurrency
+        self.cq_level = cq_level
+        self.chunk_frames = chunk_frames
+        self.gpu_mask = gpu_mask
+        self.enc = enc
+
+
+def run_mi355x(params, progress=None):
+    """Drop-in for `run_av1an(&params)`: blocks until the output file is complete; returns the
+    Report on success, raises EncodeFailed / EncodeIo otherwise (never leaves a partial output)."""
+    job = Job()
+    job.input_path = params.input_path.encode()
+    job.output_path = params.output_path.encode()
+    job.temp_dir = params.temp_chunks_dir.encode()
+    job.workers = params.concurrency.av1an_workers if params.concurrency else 0
+    job.chunk_frames = params.chunk_frames
+    job.gpu_mask = params.gpu_mask
+    p = default_params(8, 8, 8, cq_level=params.cq_level, **params.enc)
+    job.params = p
+    rep = Report()
+    cb = PROGRESS_CB(lambda u, d, t, fps, b: progress(d, t, fps, b)) if progress else C.cast(None, PROGRESS_CB)
+    rc = _lib.av1mi_encode_file(C.byref(job), cb, None, C.byref(rep))
+    _raise_for(rc)
+    return rep

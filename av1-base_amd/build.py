@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Build libav1mi.so (HIP kernels + C ABI host) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU; the resulting av1-base_amd/libav1mi.so is git-ignored but
+travels with the tree to the GPU box."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libav1mi.so")
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["recon_kernel.hip", "entropy_kernel.hip", "cdef_pack_kernels.hip", "av1mi_host.cpp", "av1mi_file.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-missing-braces", "-Wno-pass-failed"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(HERE, "..", "include", "av1mi.h")]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJDIR, s.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or not os.path.exists(OUT):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

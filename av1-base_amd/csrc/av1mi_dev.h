@@ -1,0 +1,75 @@
+// av1mi_dev.h - host/device shared definitions of the MI355X AV1 chunk encoder.
+// Product code (never includes anything from oracle/).
+#ifndef AV1MI_DEV_H
+#define AV1MI_DEV_H
+#include <stdint.h>
+#include <stddef.h>
+
+// Uniform kernel parameters of one chunk (all frames of a chunk share them).
+struct Av1miDevParams {
+  int width, height, bit_depth;
+  int mi_rows, mi_cols;     // 4x4 units
+  int sb_rows, sb_cols;     // 64x64 superblocks == tiles (tile = 1 SB)
+  int b8_rows, b8_cols;     // 8x8 units (block-info granularity)
+  int n_frames;
+  int base_q_idx, qctx;
+  int dc_q, ac_q;
+  uint32_t dc_recip, ac_recip;  // ceil(2^32 / q)
+  int min_bs_log2, max_bs_log2;
+  uint32_t mode_mask;
+  int enable_cdef, cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping;
+  int disable_cdf_update;
+  // plane geometry in samples
+  int stride_y, stride_c;
+  long plane_off_u, plane_off_v;  // sample offsets of U and V inside a frame
+  long frame_samples;             // samples per frame
+  // per-tile bitstream slot
+  int tile_slot_bytes;
+  // header blob (identical for every frame): sequence header OBU + frame header payload
+  int seq_hdr_bytes, frame_hdr_bytes;
+  int tile_size_bytes;
+};
+
+// Per 8x8-unit block info written by the recon kernel, read by entropy + CDEF kernels.
+// Only the entry at a block's top-left 8x8 unit carries eobs; mode/skip are replicated over the
+// block so neighbour-context lookups are direct.
+struct Av1miBlkInfo {
+  uint8_t ymode;
+  uint8_t skip;
+  uint8_t bsl;      // log2 block size in pixels (3..6)
+  uint8_t pad;
+  uint16_t eob[3];
+  uint16_t pad2;
+};
+
+#define AV1MI_SB_LEVELS 6144  // int16 levels per superblock: 64*64 + 2*32*32
+
+// Default-CDF blob layout (uint16 inverted CDFs, each row n+1 entries: n-1 values, 0, counter)
+// for one q context; offsets in uint16 units.  Mirrors the per-tile adaptive state.
+struct Av1miCdfLayout {
+  enum {
+    PARTITION = 0,                         // [20][11]
+    KF_Y_MODE = PARTITION + 20 * 11,       // [5][5][14]
+    UV_MODE = KF_Y_MODE + 25 * 14,         // [2][13][15]
+    ANGLE_DELTA = UV_MODE + 26 * 15,       // [8][8]
+    SKIP = ANGLE_DELTA + 64,               // [3][3]
+    TX_SET1 = SKIP + 9,                    // [2][13][8]
+    TX_SET2 = TX_SET1 + 26 * 8,            // [3][13][6]
+    TXB_SKIP = TX_SET2 + 39 * 6,           // [5][13][3]
+    EOB16 = TXB_SKIP + 65 * 3,             // [2][2][6]
+    EOB32 = EOB16 + 4 * 6,                 // [2][2][7]
+    EOB64 = EOB32 + 4 * 7,
+    EOB128 = EOB64 + 4 * 8,
+    EOB256 = EOB128 + 4 * 9,
+    EOB512 = EOB256 + 4 * 10,
+    EOB1024 = EOB512 + 4 * 11,
+    EOB_EXTRA = EOB1024 + 4 * 12,          // [5][2][9][3]
+    DC_SIGN = EOB_EXTRA + 90 * 3,          // [2][3][3]
+    COEFF_BASE_EOB = DC_SIGN + 6 * 3,      // [5][2][4][4]
+    COEFF_BASE = COEFF_BASE_EOB + 40 * 4,  // [5][2][42][5]
+    COEFF_BR = COEFF_BASE + 420 * 5,       // [5][2][21][5]
+    TOTAL = COEFF_BR + 210 * 5
+  };
+};
+
+#endif

@@ -1,0 +1,234 @@
+// av1mi_file.cpp - av1mi_encode_file(): the in-process replacement of
+//   pub fn run_av1an(params: &Av1anEncodeParams) -> Result<(), EncodeError>
+// (/root/reference/crates/daemon/src/encode/av1an.rs:126-139), including the parts av1an does
+// around the codec: splitting the clip into independent chunks (each starts with a key frame +
+// sequence header; `--workers`/`--temp`, av1an.rs:100-104), running `workers` chunks in flight
+// (here: one context per visible GPU, round-robin) and concatenating chunk streams in order
+// (§8e).  Input is Y4M, output is IVF (container demux/mux via ffmpeg
+// is out of scope).  Output is written to a temporary name and renamed, so the
+// caller's `exists && len > 0` validation (job_executor.rs:296-317) never sees a partial file.
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include "../../include/av1mi.h"
+
+namespace {
+
+struct Y4m {
+  FILE *f = nullptr;
+  uint32_t w = 0, h = 0, bd = 8, fps_n = 30, fps_d = 1;
+  size_t frame_bytes = 0;
+};
+
+int y4m_open(const char *path, Y4m *y) {
+  y->f = fopen(path, "rb");
+  if (!y->f) return -errno;
+  char line[512];
+  size_t n = 0;
+  int ch;
+  while ((ch = fgetc(y->f)) != EOF && ch != '\n' && n < sizeof(line) - 1) line[n++] = (char)ch;
+  line[n] = 0;
+  if (strncmp(line, "YUV4MPEG2", 9) != 0) return AV1MI_E_FORMAT;
+  bool ok420 = true;
+  for (char *tok = strtok(line + 9, " "); tok; tok = strtok(nullptr, " ")) {
+    switch (tok[0]) {
+      case 'W': y->w = (uint32_t)atoi(tok + 1); break;
+      case 'H': y->h = (uint32_t)atoi(tok + 1); break;
+      case 'F': sscanf(tok + 1, "%u:%u", &y->fps_n, &y->fps_d); break;
+      case 'C':
+        if (strncmp(tok + 1, "420p10", 6) == 0) y->bd = 10;
+        else if (strncmp(tok + 1, "420", 3) == 0 && (tok[4] == 0 || tok[4] == 'j' || tok[4] == 'm' || (tok[4] == 'p' && tok[5] == 'a'))) y->bd = 8;
+        else ok420 = false;
+        break;
+      default: break;
+    }
+  }
+  if (!ok420 || !y->w || !y->h) return AV1MI_E_FORMAT;
+  y->frame_bytes = (size_t)y->w * y->h * 3 / 2 * (y->bd > 8 ? 2 : 1);
+  return 0;
+}
+
+// returns 1 frame read, 0 clean EOF, <0 error
+int y4m_read_frame(Y4m *y, uint8_t *dst) {
+  char hdr[128];
+  size_t n = 0;
+  int ch;
+  while ((ch = fgetc(y->f)) != EOF && ch != '\n' && n < sizeof(hdr) - 1) hdr[n++] = (char)ch;
+  if (ch == EOF && n == 0) return 0;
+  hdr[n] = 0;
+  if (strncmp(hdr, "FRAME", 5) != 0) return AV1MI_E_FORMAT;
+  if (fread(dst, 1, y->frame_bytes, y->f) != y->frame_bytes) return AV1MI_E_FORMAT;
+  return 1;
+}
+
+void put_le(uint8_t *p, uint64_t v, int n) { for (int i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * i)); }
+
+struct Chunk {
+  uint32_t index = 0, n_frames = 0;
+  std::vector<uint8_t> frames;
+  av1mi_buf out = { nullptr, 0 };
+  std::vector<uint32_t> sizes;
+  av1mi_report rep = {};
+  int rc = 0;
+};
+
+}  // namespace
+
+extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total) {
+  if (!job || !job->input_path || !job->output_path) return AV1MI_E_INVALID_ARG;
+  Y4m y;
+  int rc = y4m_open(job->input_path, &y);
+  if (rc) { if (y.f) fclose(y.f); return rc; }
+  av1mi_params prm = job->params;
+  prm.width = y.w; prm.height = y.h; prm.bit_depth = y.bd;
+  const uint32_t chunk_frames = job->chunk_frames ? job->chunk_frames : 60;
+  // contexts: `workers` chunks in flight, spread round-robin over the allowed GPUs
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fclose(y.f); return AV1MI_E_NO_DEVICE; }
+  std::vector<int> devs;
+  for (int d = 0; d < ndev; d++) if (job->gpu_mask <= 0 || ((job->gpu_mask >> d) & 1)) devs.push_back(d);
+  if (devs.empty()) { fclose(y.f); return AV1MI_E_NO_DEVICE; }
+  uint32_t workers = job->workers ? job->workers : (uint32_t)devs.size();
+  if (workers > 64) workers = 64;
+  std::vector<av1mi_ctx *> ctxs(workers, nullptr);
+  for (uint32_t i = 0; i < workers; i++) {
+    rc = av1mi_ctx_create(devs[i % devs.size()], &ctxs[i]);
+    if (rc) { for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
+  }
+  std::string tmp = std::string(job->output_path) + ".tmp." + std::to_string((long)getpid());
+  FILE *fo = fopen(tmp.c_str(), "wb");
+  if (!fo) { int e = -errno; for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return e; }
+  uint8_t ivf[32] = { 'D', 'K', 'I', 'F', 0, 0, 32, 0, 'A', 'V', '0', '1' };
+  put_le(ivf + 12, y.w, 2); put_le(ivf + 14, y.h, 2); put_le(ivf + 16, y.fps_n, 4); put_le(ivf + 20, y.fps_d, 4);
+  fwrite(ivf, 1, 32, fo);
+
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<Chunk *> queue;
+  std::map<uint32_t, Chunk *> done;
+  bool eof = false;
+  int first_err = 0;
+  auto worker = [&](av1mi_ctx *ctx) {
+    for (;;) {
+      Chunk *ck = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return !queue.empty() || eof; });
+        if (queue.empty()) return;
+        ck = queue.front();
+        queue.pop_front();
+      }
+      ck->sizes.resize(ck->n_frames);
+      ck->rc = av1mi_encode_chunk(ctx, &prm, ck->frames.data(), ck->n_frames, 0, &ck->out, ck->sizes.data(), nullptr, &ck->rep);
+      std::vector<uint8_t>().swap(ck->frames);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        done[ck->index] = ck;
+      }
+      cv_done.notify_all();
+    }
+  };
+  std::vector<std::thread> threads;
+  for (auto c : ctxs) threads.emplace_back(worker, c);
+
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t n_chunks = 0, next_write = 0, frames_done = 0, frames_read = 0;
+  uint64_t bytes_out = 32, pts = 0;
+  av1mi_report tot = {};
+  auto drain = [&](bool all) {
+    for (;;) {
+      Chunk *ck = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (all) cv_done.wait(lk, [&] { return next_write >= n_chunks || done.count(next_write); });
+        if (next_write >= n_chunks || !done.count(next_write)) return;
+        ck = done[next_write];
+        done.erase(next_write);
+      }
+      if (ck->rc && !first_err) first_err = ck->rc;
+      if (!ck->rc && !first_err) {
+        size_t off = 0;
+        for (uint32_t f = 0; f < ck->n_frames; f++) {
+          uint8_t fh[12];
+          put_le(fh, ck->sizes[f], 4); put_le(fh + 4, pts++, 8);
+          fwrite(fh, 1, 12, fo);
+          fwrite(ck->out.data + off, 1, ck->sizes[f], fo);
+          off += ck->sizes[f];
+          bytes_out += 12 + ck->sizes[f];
+        }
+        frames_done += ck->n_frames;
+        tot.frames += ck->n_frames; tot.bytes += ck->rep.bytes; tot.n_symbols += ck->rep.n_symbols;
+        for (int p = 0; p < 3; p++) tot.sse[p] += ck->rep.sse[p];
+        tot.ms_recon += ck->rep.ms_recon; tot.ms_cdef += ck->rep.ms_cdef; tot.ms_entropy += ck->rep.ms_entropy;
+        tot.ms_pack += ck->rep.ms_pack; tot.ms_h2d += ck->rep.ms_h2d; tot.ms_d2h += ck->rep.ms_d2h; tot.ms_total += ck->rep.ms_total;
+        if (cb) {
+          double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          cb(user, frames_done, frames_read, sec > 0 ? frames_done / sec : 0.0, bytes_out);
+        }
+      }
+      av1mi_free(ck->out.data);
+      delete ck;
+      next_write++;
+    }
+  };
+  // reader: split into chunks (fixed length; every chunk starts with a key frame)
+  for (;;) {
+    Chunk *ck = new Chunk();
+    ck->index = n_chunks;
+    ck->frames.resize((size_t)chunk_frames * y.frame_bytes);
+    int r = 1;
+    while (ck->n_frames < chunk_frames && (r = y4m_read_frame(&y, ck->frames.data() + (size_t)ck->n_frames * y.frame_bytes)) == 1) ck->n_frames++;
+    if (r < 0 && !first_err) first_err = r;
+    if (ck->n_frames == 0) { delete ck; break; }
+    frames_read += ck->n_frames;
+    n_chunks++;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      // bound the number of chunks held in memory
+      cv_done.wait(lk, [&] { return queue.size() + done.size() < (size_t)workers * 2; });
+      queue.push_back(ck);
+    }
+    cv_work.notify_one();
+    drain(false);
+    if (r != 1 || first_err) break;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    eof = true;
+  }
+  cv_work.notify_all();
+  drain(true);
+  for (auto &t : threads) t.join();
+  for (auto c : ctxs) av1mi_ctx_destroy(c);
+  fclose(y.f);
+  // patch frame count, finish atomically
+  int io_err = 0;
+  if (fseek(fo, 24, SEEK_SET) == 0) { uint8_t cnt[4]; put_le(cnt, frames_done, 4); fwrite(cnt, 1, 4, fo); }
+  if (fflush(fo) != 0 || ferror(fo)) io_err = -EIO;
+  fclose(fo);
+  if (!first_err && !io_err && frames_done == 0) first_err = AV1MI_E_FORMAT;
+  if (first_err || io_err) { unlink(tmp.c_str()); return first_err ? first_err : io_err; }
+  if (rename(tmp.c_str(), job->output_path) != 0) { int e = -errno; unlink(tmp.c_str()); return e; }
+  if (total) {
+    const double mx = (double)((1 << y.bd) - 1);
+    for (int p = 0; p < 3; p++) {
+      const double npx = (double)tot.frames * y.w * y.h / (p ? 4 : 1);
+      tot.psnr[p] = tot.sse[p] > 0 ? 10.0 * log10(mx * mx * npx / tot.sse[p]) : 99.0;
+    }
+    *total = tot;
+  }
+  return AV1MI_OK;
+}

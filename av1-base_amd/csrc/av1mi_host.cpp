@@ -1,0 +1,529 @@
+// av1mi_host.cpp - host side of libav1mi behind the C ABI of include/av1mi.h.
+//
+// Mirrors the reference's encode boundary: `run_av1an(&Av1anEncodeParams) -> Result<(), EncodeError>`
+// (/root/reference/crates/daemon/src/encode/av1an.rs:126-139) becomes av1mi_encode_file(); the
+// per-chunk work av1an farms out to SVT-AV1 workers (`--workers`, av1an.rs:100-101) becomes
+// av1mi_encode_chunk() on one context (= one GPU + one HIP stream).  No CPU encode path exists
+// here: without a HIP device every entry point fails with AV1MI_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <errno.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/av1mi.h"
+#include "av1_tables.h"
+#include "av1mi_dev.h"
+
+extern "C" {
+hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, hipStream_t s);
+hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
+                                uint8_t *slots, uint32_t *tile_bytes, uint32_t *sym_count, hipStream_t s);
+hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t s);
+hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
+hipError_t av1mi_launch_pack(const Av1miDevParams *P, const uint8_t *slots, const uint32_t *tile_bytes, uint32_t *tile_off,
+                             uint32_t *frame_size, uint32_t *payload_size, unsigned long long *frame_off, const uint8_t *hdr_blob,
+                             uint8_t *out, int *overflow, int stage, hipStream_t s);
+}
+
+namespace {
+
+// ------------------------------------------------------------------ header bit writer
+struct BitWriter {
+  std::vector<uint8_t> buf;
+  size_t bits = 0;
+  void put(uint32_t v, int n) {
+    for (int i = n - 1; i >= 0; i--) {
+      if ((bits & 7) == 0) buf.push_back(0);
+      buf.back() |= (uint8_t)(((v >> i) & 1) << (7 - (bits & 7)));
+      bits++;
+    }
+  }
+  void align() { while (bits & 7) put(0, 1); }
+  void trailing() { put(1, 1); align(); }
+  // ns(n), AV1 spec §4.10.7
+  void put_ns(int n, int v) {
+    int w = 0;
+    while ((1 << w) <= n) w++;  // w = floor(log2 n) + 1
+    int m = (1 << w) - n;
+    if (v < m) put((uint32_t)v, w - 1);
+    else { int x = v + m; put((uint32_t)(x >> 1), w - 1); put((uint32_t)(x & 1), 1); }
+  }
+};
+
+int tile_log2(int blk, int target) { int k = 0; while ((blk << k) < target) k++; return k; }
+int bits_for(unsigned v) { int n = 0; while (v) { n++; v >>= 1; } return n ? n : 1; }
+
+struct Resolved {
+  av1mi_params p;
+  int qidx;
+  int sb_cols, sb_rows;
+};
+
+// aom's quantizer_to_qindex[] (CQ level -> base_q_idx); 30 -> 120
+const uint8_t kQuantizerToQindex[64] = {
+  0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 108, 112, 116, 120, 124,
+  128, 132, 136, 140, 144, 148, 152, 156, 160, 164, 168, 172, 176, 180, 184, 188, 192, 196, 200, 204, 208, 212, 216, 220, 224, 228, 232, 236, 240, 244, 249, 255 };
+
+int resolve(const av1mi_params *in, Resolved *r) {
+  if (!in) return AV1MI_E_INVALID_ARG;
+  r->p = *in;
+  av1mi_params &p = r->p;
+  if (p.width < 8 || p.height < 8 || (p.width & 7) || (p.height & 7) || p.width > 65536 || p.height > 65536) return AV1MI_E_INVALID_ARG;
+  if (p.bit_depth != 8 && p.bit_depth != 10) return AV1MI_E_INVALID_ARG;
+  if (p.cq_level > 63) return AV1MI_E_INVALID_ARG;
+  if (p.keyint == 0) p.keyint = 1;
+  if (p.keyint != 1) return AV1MI_E_UNSUPPORTED;
+  if (p.block_log2 == 0) p.block_log2 = 5;
+  if (p.block_log2 < 3 || p.block_log2 > 5) return AV1MI_E_INVALID_ARG;
+  if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 1; p.cdef_uv_pri = 1; p.cdef_uv_sec = 1; p.cdef_damping = 5; }
+  if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
+  r->qidx = kQuantizerToQindex[p.cq_level];
+  r->sb_cols = (p.width + 63) / 64;
+  r->sb_rows = (p.height + 63) / 64;
+  if (r->sb_cols > 64 || r->sb_rows > 64) return AV1MI_E_UNSUPPORTED;  // needs tiles larger than one superblock
+  return AV1MI_OK;
+}
+
+// sequence_header_obu (AV1 spec §5.5), complete OBU incl. header and size
+std::vector<uint8_t> make_sequence_header(const Resolved &r) {
+  const av1mi_params &p = r.p;
+  BitWriter b;
+  const int wbits = bits_for(p.width - 1), hbits = bits_for(p.height - 1);
+  b.put(0, 3);   // seq_profile
+  b.put(0, 1);   // still_picture
+  b.put(0, 1);   // reduced_still_picture_header
+  b.put(0, 1);   // timing_info_present_flag
+  b.put(0, 1);   // initial_display_delay_present_flag
+  b.put(0, 5);   // operating_points_cnt_minus_1
+  b.put(0, 12);  // operating_point_idc[0]
+  b.put(31, 5);  // seq_level_idx[0]: maximum parameters
+  b.put(0, 1);   // seq_tier[0]
+  b.put((uint32_t)(wbits - 1), 4);
+  b.put((uint32_t)(hbits - 1), 4);
+  b.put(p.width - 1, wbits);
+  b.put(p.height - 1, hbits);
+  b.put(0, 1);  // frame_id_numbers_present_flag
+  b.put(0, 1);  // use_128x128_superblock
+  b.put(0, 1);  // enable_filter_intra
+  b.put(0, 1);  // enable_intra_edge_filter
+  b.put(0, 1);  // enable_interintra_compound
+  b.put(0, 1);  // enable_masked_compound
+  b.put(0, 1);  // enable_warped_motion
+  b.put(0, 1);  // enable_dual_filter
+  b.put(0, 1);  // enable_order_hint
+  b.put(0, 1);  // seq_choose_screen_content_tools
+  b.put(0, 1);  // seq_force_screen_content_tools
+  b.put(0, 1);  // enable_superres
+  b.put(p.enable_cdef ? 1 : 0, 1);
+  b.put(0, 1);  // enable_restoration
+  // color_config
+  b.put(p.bit_depth > 8, 1);  // high_bitdepth
+  b.put(0, 1);                // mono_chrome
+  b.put(0, 1);                // color_description_present_flag
+  b.put(1, 1);                // color_range
+  b.put(0, 2);                // chroma_sample_position
+  b.put(0, 1);                // separate_uv_delta_q
+  b.put(0, 1);                // film_grain_params_present
+  b.trailing();
+  std::vector<uint8_t> out;
+  out.push_back((1 << 3) | 2);
+  out.push_back((uint8_t)b.buf.size());  // < 128
+  out.insert(out.end(), b.buf.begin(), b.buf.end());
+  return out;
+}
+
+// OBU_FRAME payload up to the first tile: frame_header_obu (§5.9) + byte_alignment +
+// tile_group_obu's tile_start_and_end_present_flag + byte_alignment (§5.11.1)
+std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits) {
+  const av1mi_params &p = r.p;
+  BitWriter b;
+  b.put(0, 1);  // show_existing_frame
+  b.put(0, 2);  // frame_type KEY_FRAME
+  b.put(1, 1);  // show_frame
+  b.put(p.cdf_update ? 0 : 1, 1);  // disable_cdf_update
+  b.put(0, 1);  // frame_size_override_flag
+  b.put(0, 1);  // render_and_frame_size_different
+  if (p.cdf_update) b.put(1, 1);  // disable_frame_end_update_cdf
+  // tile_info: explicit spacing, every tile one superblock
+  {
+    const int sb_cols = r.sb_cols, sb_rows = r.sb_rows;
+    const int max_tile_width_sb = 4096 >> 6, max_tile_area_sb = (4096 * 2304) >> 12;
+    int min_log2_tile_cols = tile_log2(max_tile_width_sb, sb_cols);
+    int min_log2_tiles = tile_log2(max_tile_area_sb, sb_rows * sb_cols);
+    if (min_log2_tiles < min_log2_tile_cols) min_log2_tiles = min_log2_tile_cols;
+    b.put(0, 1);  // uniform_tile_spacing_flag
+    for (int start = 0; start < sb_cols; start++) {
+      int max_w = sb_cols - start < max_tile_width_sb ? sb_cols - start : max_tile_width_sb;
+      b.put_ns(max_w, 0);
+    }
+    int area = sb_rows * sb_cols;
+    if (min_log2_tiles > 0) area >>= (min_log2_tiles + 1);
+    int max_tile_height_sb = area / 1;
+    if (max_tile_height_sb < 1) max_tile_height_sb = 1;
+    for (int start = 0; start < sb_rows; start++) {
+      int max_h = sb_rows - start < max_tile_height_sb ? sb_rows - start : max_tile_height_sb;
+      b.put_ns(max_h, 0);
+    }
+    const int cl = tile_log2(1, sb_cols), rl = tile_log2(1, sb_rows);
+    if (cl > 0 || rl > 0) {
+      b.put(0, cl + rl);  // context_update_tile_id
+      b.put(3, 2);        // tile_size_bytes_minus_1
+    }
+  }
+  b.put((uint32_t)r.qidx, 8);
+  b.put(0, 1);  // DeltaQYDc
+  b.put(0, 1);  // DeltaQUDc
+  b.put(0, 1);  // DeltaQUAc
+  b.put(0, 1);  // using_qmatrix
+  b.put(0, 1);  // segmentation_enabled
+  if (r.qidx > 0) b.put(0, 1);  // delta_q_present
+  b.put(0, 6); b.put(0, 6);  // loop_filter_level[0..1] = 0: deblocking off
+  b.put(0, 3);  // loop_filter_sharpness
+  b.put(0, 1);  // loop_filter_delta_enabled
+  if (p.enable_cdef) {
+    b.put(p.cdef_damping - 3, 2);
+    b.put(0, 2);  // cdef_bits
+    b.put(p.cdef_y_pri, 4); b.put(p.cdef_y_sec, 2);
+    b.put(p.cdef_uv_pri, 4); b.put(p.cdef_uv_sec, 2);
+  }
+  b.put(0, 1);  // tx_mode_select = 0: TX_MODE_LARGEST
+  b.put(0, 1);  // reduced_tx_set
+  if (hdr_bits) *hdr_bits = b.bits;
+  b.align();
+  if (r.sb_cols * r.sb_rows > 1) { b.put(0, 1); b.align(); }  // tile_start_and_end_present_flag
+  return b.buf;
+}
+
+// default CDF blob for one q context in the layout of Av1miCdfLayout (inverted, 0, counter)
+template <size_t W>
+void emit_rows(std::vector<uint16_t> &v, size_t off, const uint16_t (*rows)[W], int nrows, int row_stride, const int *nsym, int nsym_const) {
+  for (int i = 0; i < nrows; i++) {
+    int n = nsym ? nsym[i] : nsym_const;
+    for (int k = 0; k < n - 1; k++) v[off + (size_t)i * row_stride + k] = (uint16_t)(32768 - rows[i][k]);
+  }
+}
+std::vector<uint16_t> make_cdf_blob(int qidx) {
+  typedef Av1miCdfLayout CL;
+  const int q = qidx <= 20 ? 0 : (qidx <= 60 ? 1 : (qidx <= 120 ? 2 : 3));
+  std::vector<uint16_t> v(CL::TOTAL, 0);
+  int pn[20];
+  for (int i = 0; i < 20; i++) pn[i] = i < 4 ? 4 : (i < 16 ? 10 : 8);
+  emit_rows(v, CL::PARTITION, av1_default_partition_cdf, 20, 11, pn, 0);
+  emit_rows(v, CL::KF_Y_MODE, &av1_default_kf_y_mode_cdf[0][0], 25, 14, nullptr, 13);
+  emit_rows(v, CL::UV_MODE, av1_default_uv_mode_nocfl_cdf, 13, 15, nullptr, 13);
+  emit_rows(v, CL::UV_MODE + 13 * 15, av1_default_uv_mode_cfl_cdf, 13, 15, nullptr, 14);
+  emit_rows(v, CL::ANGLE_DELTA, av1_default_angle_delta_cdf, 8, 8, nullptr, 7);
+  emit_rows(v, CL::SKIP, av1_default_skip_cdf, 3, 3, nullptr, 2);
+  emit_rows(v, CL::TX_SET1, &av1_default_intra_tx_set1_cdf[0][0], 26, 8, nullptr, 7);
+  emit_rows(v, CL::TX_SET2, &av1_default_intra_tx_set2_cdf[0][0], 39, 6, nullptr, 5);
+  emit_rows(v, CL::TXB_SKIP, &av1_default_txb_skip_cdf[q][0][0], 65, 3, nullptr, 2);
+  emit_rows(v, CL::EOB16, &av1_default_eob_multi16_cdf[q][0][0], 4, 6, nullptr, 5);
+  emit_rows(v, CL::EOB32, &av1_default_eob_multi32_cdf[q][0][0], 4, 7, nullptr, 6);
+  emit_rows(v, CL::EOB64, &av1_default_eob_multi64_cdf[q][0][0], 4, 8, nullptr, 7);
+  emit_rows(v, CL::EOB128, &av1_default_eob_multi128_cdf[q][0][0], 4, 9, nullptr, 8);
+  emit_rows(v, CL::EOB256, &av1_default_eob_multi256_cdf[q][0][0], 4, 10, nullptr, 9);
+  emit_rows(v, CL::EOB512, &av1_default_eob_multi512_cdf[q][0][0], 4, 11, nullptr, 10);
+  emit_rows(v, CL::EOB1024, &av1_default_eob_multi1024_cdf[q][0][0], 4, 12, nullptr, 11);
+  emit_rows(v, CL::EOB_EXTRA, &av1_default_eob_extra_cdf[q][0][0][0], 90, 3, nullptr, 2);
+  emit_rows(v, CL::DC_SIGN, &av1_default_dc_sign_cdf[q][0][0], 6, 3, nullptr, 2);
+  emit_rows(v, CL::COEFF_BASE_EOB, &av1_default_coeff_base_eob_cdf[q][0][0][0], 40, 4, nullptr, 3);
+  emit_rows(v, CL::COEFF_BASE, &av1_default_coeff_base_cdf[q][0][0][0], 420, 5, nullptr, 4);
+  emit_rows(v, CL::COEFF_BR, &av1_default_coeff_br_cdf[q][0][0][0], 210, 5, nullptr, 4);
+  return v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ context
+struct av1mi_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  std::string err;
+  // workspace (device)
+  size_t cap_frames = 0;
+  Resolved res = {};
+  void *d_src = nullptr, *d_rec = nullptr, *d_fin = nullptr;
+  int16_t *d_levels = nullptr;
+  Av1miBlkInfo *d_blk = nullptr;
+  uint8_t *d_slots = nullptr, *d_out = nullptr, *d_hdr = nullptr;
+  uint16_t *d_cdf = nullptr;
+  uint32_t *d_tile_bytes = nullptr, *d_tile_off = nullptr, *d_frame_size = nullptr, *d_payload = nullptr, *d_sym = nullptr;
+  unsigned long long *d_frame_off = nullptr, *d_sse = nullptr;
+  int *d_overflow = nullptr;
+  size_t out_cap = 0;
+  // host staging (pinned)
+  uint8_t *h_out = nullptr;
+  size_t h_out_cap = 0;
+  Av1miDevParams P = {};
+};
+
+namespace {
+
+void set_err(av1mi_ctx *c, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+}
+
+#define HIPCHK(c, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      set_err((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__);   \
+      return e__ == hipErrorOutOfMemory ? AV1MI_E_OOM : AV1MI_E_HIP;                             \
+    }                                                                                            \
+  } while (0)
+
+void free_workspace(av1mi_ctx *c) {
+  void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow };
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
+  c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr;
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  c->h_out = nullptr; c->h_out_cap = 0;
+  c->cap_frames = 0;
+}
+
+int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
+  const av1mi_params &p = r.p;
+  bool same = c->cap_frames >= n_frames && c->res.p.width == p.width && c->res.p.height == p.height && c->res.p.bit_depth == p.bit_depth;
+  const int bps = p.bit_depth > 8 ? 2 : 1;
+  const size_t frame_samples = (size_t)p.width * p.height * 3 / 2;
+  const size_t nsb = (size_t)r.sb_cols * r.sb_rows;
+  const int slot = bps == 1 ? 8192 : 16384;
+  if (!same) {
+    free_workspace(c);
+    const size_t nf = n_frames;
+    HIPCHK(c, hipMalloc(&c->d_src, nf * frame_samples * bps));
+    HIPCHK(c, hipMalloc(&c->d_rec, nf * frame_samples * bps));
+    HIPCHK(c, hipMalloc(&c->d_fin, nf * frame_samples * bps));
+    HIPCHK(c, hipMalloc((void **)&c->d_levels, nf * nsb * AV1MI_SB_LEVELS * sizeof(int16_t)));
+    const size_t nb8 = (size_t)(p.width / 8) * (p.height / 8);
+    HIPCHK(c, hipMalloc((void **)&c->d_blk, nf * nb8 * sizeof(Av1miBlkInfo)));
+    HIPCHK(c, hipMemset(c->d_blk, 0, nf * nb8 * sizeof(Av1miBlkInfo)));
+    HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * nsb * slot));
+    c->out_cap = nf * (nsb * (size_t)(slot + 4) + 256);
+    HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));
+    HIPCHK(c, hipMalloc((void **)&c->d_hdr, 4096));
+    HIPCHK(c, hipMalloc((void **)&c->d_cdf, Av1miCdfLayout::TOTAL * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_tile_bytes, nf * nsb * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_tile_off, nf * nsb * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_sym, nf * nsb * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_frame_size, nf * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_payload, nf * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_frame_off, (nf + 1) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_sse, nf * 3 * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_overflow, 4));
+    c->cap_frames = n_frames;
+  }
+  c->res = r;
+  Av1miDevParams &P = c->P;
+  memset(&P, 0, sizeof(P));
+  P.width = p.width; P.height = p.height; P.bit_depth = p.bit_depth;
+  P.mi_rows = p.height / 4; P.mi_cols = p.width / 4;
+  P.sb_rows = r.sb_rows; P.sb_cols = r.sb_cols;
+  P.b8_rows = p.height / 8; P.b8_cols = p.width / 8;
+  P.n_frames = (int)n_frames;
+  P.base_q_idx = r.qidx;
+  P.qctx = r.qidx <= 20 ? 0 : (r.qidx <= 60 ? 1 : (r.qidx <= 120 ? 2 : 3));
+  P.dc_q = p.bit_depth == 8 ? av1_dc_q8[r.qidx] : av1_dc_q10[r.qidx];
+  P.ac_q = p.bit_depth == 8 ? av1_ac_q8[r.qidx] : av1_ac_q10[r.qidx];
+  P.dc_recip = (uint32_t)((((uint64_t)1 << 32) + P.dc_q - 1) / P.dc_q);
+  P.ac_recip = (uint32_t)((((uint64_t)1 << 32) + P.ac_q - 1) / P.ac_q);
+  P.min_bs_log2 = P.max_bs_log2 = (int)p.block_log2;
+  P.mode_mask = 0x1FFF;
+  P.enable_cdef = p.enable_cdef ? 1 : 0;
+  P.cdef_y_pri = p.cdef_y_pri; P.cdef_y_sec = p.cdef_y_sec; P.cdef_uv_pri = p.cdef_uv_pri; P.cdef_uv_sec = p.cdef_uv_sec;
+  P.cdef_damping = p.cdef_damping;
+  P.disable_cdf_update = p.cdf_update ? 0 : 1;
+  P.stride_y = p.width; P.stride_c = p.width / 2;
+  P.plane_off_u = (long)p.width * p.height;
+  P.plane_off_v = P.plane_off_u + (long)(p.width / 2) * (p.height / 2);
+  P.frame_samples = (long)frame_samples;
+  P.tile_slot_bytes = slot;
+  P.tile_size_bytes = 4;
+  return AV1MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t av1mi_abi_version(void) { return AV1MI_ABI_VERSION; }
+uint32_t av1mi_cq_to_qindex(uint32_t cq) { return kQuantizerToQindex[cq > 63 ? 63 : cq]; }
+
+void av1mi_default_params(av1mi_params *p, uint32_t w, uint32_t h, uint32_t bd) {
+  memset(p, 0, sizeof(*p));
+  p->width = w; p->height = h; p->bit_depth = bd;
+  p->cq_level = 30; p->keyint = 1; p->block_log2 = 5; p->cdf_update = 1; p->enable_cdef = 1;
+  p->cdef_y_pri = 2; p->cdef_y_sec = 1; p->cdef_uv_pri = 1; p->cdef_uv_sec = 1; p->cdef_damping = 5;
+}
+
+int av1mi_write_headers(const av1mi_params *p, uint8_t *seq_hdr, size_t *seq_len, uint8_t *frame_hdr, size_t *frame_hdr_bits) {
+  Resolved r;
+  int rc = resolve(p, &r);
+  if (rc) return rc;
+  std::vector<uint8_t> s = make_sequence_header(r);
+  size_t bits = 0;
+  std::vector<uint8_t> f = make_frame_header(r, &bits);
+  if (seq_hdr && seq_len) { if (*seq_len < s.size()) return AV1MI_E_INVALID_ARG; memcpy(seq_hdr, s.data(), s.size()); }
+  if (seq_len) *seq_len = s.size();
+  if (frame_hdr) memcpy(frame_hdr, f.data(), f.size());
+  if (frame_hdr_bits) *frame_hdr_bits = bits;
+  return AV1MI_OK;
+}
+
+int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
+  if (!out) return AV1MI_E_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return AV1MI_E_NO_DEVICE;
+  av1mi_ctx *c = new (std::nothrow) av1mi_ctx();
+  if (!c) return AV1MI_E_OOM;
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return AV1MI_E_NO_DEVICE;
+  }
+  for (auto &e : c->ev) (void)hipEventCreate(&e);
+  *out = c;
+  return AV1MI_OK;
+}
+
+void av1mi_ctx_destroy(av1mi_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_workspace(c);
+  for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *av1mi_last_error(const av1mi_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+void av1mi_free(void *p) { free(p); }
+
+int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *frames, uint32_t n_frames, int frames_on_device,
+                       av1mi_buf *out, uint32_t *frame_sizes, void *recon, av1mi_report *report) {
+  if (!c || !frames || !out || n_frames == 0) return AV1MI_E_INVALID_ARG;
+  out->data = nullptr; out->size = 0;
+  Resolved r;
+  int rc = resolve(params, &r);
+  if (rc) { set_err(c, "invalid parameters"); return rc; }
+  HIPCHK(c, hipSetDevice(c->device));
+  rc = ensure_workspace(c, r, n_frames);
+  if (rc) return rc;
+  Av1miDevParams &P = c->P;
+  const int bps = P.bit_depth > 8 ? 2 : 1;
+  const size_t chunk_bytes = (size_t)n_frames * P.frame_samples * bps;
+  hipStream_t s = c->stream;
+  // headers + CDFs
+  std::vector<uint8_t> seq = make_sequence_header(r), fh = make_frame_header(r, nullptr);
+  P.seq_hdr_bytes = (int)seq.size();
+  P.frame_hdr_bytes = (int)fh.size();
+  std::vector<uint8_t> blob(seq);
+  blob.insert(blob.end(), fh.begin(), fh.end());
+  std::vector<uint16_t> cdf = make_cdf_blob(r.qidx);
+  HIPCHK(c, hipMemcpyAsync(c->d_hdr, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->d_cdf, cdf.data(), cdf.size() * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, s));
+  HIPCHK(c, hipMemsetAsync(c->d_sse, 0, (size_t)n_frames * 24, s));
+  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  const void *d_src = frames;
+  if (!frames_on_device) {
+    HIPCHK(c, hipMemcpyAsync(c->d_src, frames, chunk_bytes, hipMemcpyHostToDevice, s));
+    d_src = c->d_src;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  HIPCHK(c, av1mi_launch_recon(&P, d_src, c->d_rec, c->d_levels, c->d_blk, s));
+  HIPCHK(c, hipEventRecord(c->ev[2], s));
+  HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s));
+  HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s));
+  HIPCHK(c, hipEventRecord(c->ev[3], s));
+  HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_slots, c->d_tile_bytes, c->d_sym, s));
+  HIPCHK(c, hipEventRecord(c->ev[4], s));
+  HIPCHK(c, av1mi_launch_pack(&P, c->d_slots, c->d_tile_bytes, c->d_tile_off, c->d_frame_size, c->d_payload, c->d_frame_off, c->d_hdr,
+                              c->d_out, c->d_overflow, 0, s));
+  HIPCHK(c, av1mi_launch_pack(&P, c->d_slots, c->d_tile_bytes, c->d_tile_off, c->d_frame_size, c->d_payload, c->d_frame_off, c->d_hdr,
+                              c->d_out, c->d_overflow, 1, s));
+  HIPCHK(c, hipEventRecord(c->ev[5], s));
+  // sizes first, then exactly the bytes produced
+  std::vector<unsigned long long> foff(n_frames + 1);
+  int overflow = 0;
+  HIPCHK(c, hipMemcpyAsync(foff.data(), c->d_frame_off, (n_frames + 1) * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(&overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (overflow) { set_err(c, "a tile outgrew its %d-byte bitstream slot", P.tile_slot_bytes); return AV1MI_E_OVERFLOW; }
+  const size_t total = (size_t)foff[n_frames];
+  if (total > c->out_cap) { set_err(c, "internal: packed size exceeds buffer"); return AV1MI_E_OVERFLOW; }
+  uint8_t *host = (uint8_t *)malloc(total ? total : 1);
+  if (!host) return AV1MI_E_OOM;
+  if (c->h_out_cap < total) {
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    c->h_out = nullptr; c->h_out_cap = 0;
+    if (hipHostMalloc((void **)&c->h_out, total + (total >> 2) + 4096, hipHostMallocDefault) == hipSuccess) c->h_out_cap = total + (total >> 2) + 4096;
+  }
+  uint8_t *dst = c->h_out ? c->h_out : host;
+  hipError_t e1 = hipMemcpyAsync(dst, c->d_out, total, hipMemcpyDeviceToHost, s);
+  hipError_t e2 = hipEventRecord(c->ev[6], s);
+  if (e1 == hipSuccess && e2 == hipSuccess && recon) {
+    e1 = hipMemcpyAsync(recon, c->d_fin, chunk_bytes, frames_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s);
+  }
+  std::vector<unsigned long long> sse(n_frames * 3);
+  std::vector<uint32_t> syms;
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(sse.data(), c->d_sse, (size_t)n_frames * 24, hipMemcpyDeviceToHost, s);
+  if (e1 == hipSuccess && report) {
+    syms.resize((size_t)n_frames * P.sb_rows * P.sb_cols);
+    e1 = hipMemcpyAsync(syms.data(), c->d_sym, syms.size() * 4, hipMemcpyDeviceToHost, s);
+  }
+  if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    free(host);
+    set_err(c, "device-to-host copy failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return AV1MI_E_HIP;
+  }
+  if (dst != host) memcpy(host, dst, total);
+  out->data = host; out->size = total;
+  if (frame_sizes) for (uint32_t f = 0; f < n_frames; f++) frame_sizes[f] = (uint32_t)(foff[f + 1] - foff[f]);
+  if (report) {
+    memset(report, 0, sizeof(*report));
+    report->frames = n_frames;
+    report->bytes = total;
+    const double mx = (double)((1 << P.bit_depth) - 1);
+    for (int pl = 0; pl < 3; pl++) {
+      double t = 0;
+      for (uint32_t f = 0; f < n_frames; f++) t += (double)sse[f * 3 + pl];
+      report->sse[pl] = t;
+      const double npx = (double)n_frames * P.width * P.height / (pl ? 4 : 1);
+      report->psnr[pl] = t > 0 ? 10.0 * log10(mx * mx * npx / t) : 99.0;
+    }
+    for (uint32_t v : syms) report->n_symbols += v;
+    (void)hipEventElapsedTime(&report->ms_h2d, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&report->ms_recon, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&report->ms_cdef, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&report->ms_entropy, c->ev[3], c->ev[4]);
+    (void)hipEventElapsedTime(&report->ms_pack, c->ev[4], c->ev[5]);
+    (void)hipEventElapsedTime(&report->ms_d2h, c->ev[5], c->ev[6]);
+    (void)hipEventElapsedTime(&report->ms_total, c->ev[0], c->ev[6]);
+  }
+  return AV1MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,337 @@
+// cdef_pack_kernels.hip - (1) CDEF of the reconstructed frames, (2) bitstream packing.
+//
+// (1) replaces the CDEF stage of the external SVT-AV1 worker behind `run_av1an`
+//     (/root/reference/crates/daemon/src/encode/av1an.rs:126-139):
+//     AV1 spec §7.15 - 8x8 direction search (§7.15.2) and the constrained primary/secondary
+//     filter (§7.15.3), 4:2:0, one strength set per frame (cdef_bits = 0).
+//     MI355X mapping: one wave per 64x64 superblock; luma (68x68) and chroma (36x36 x2) tiles incl.
+//     the 2-pixel halo are staged once into LDS with coalesced row loads, unavailable (outside
+//     frame) samples carry a sentinel; each lane owns one 8x8 block (direction + filter).
+// (2) replaces av1an's chunk concatenation (`-o`, av1an.rs:87) at tile
+//     granularity: prefix sums over tile sizes, then every tile copies itself into the final
+//     Section-5 OBU stream (temporal delimiter, sequence header, OBU_FRAME with tile sizes).
+#include <hip/hip_runtime.h>
+#include "av1mi_dev.h"
+
+namespace {
+
+__constant__ int8_t c_cdef_dir[8][2][2] = {
+  { { -1, 1 }, { -2, 2 } }, { { 0, 1 }, { -1, 2 } }, { { 0, 1 }, { 0, 2 } }, { { 0, 1 }, { 1, 2 } },
+  { { 1, 1 }, { 2, 2 } },   { { 1, 0 }, { 2, 1 } },  { { 1, 0 }, { 2, 0 } }, { { 1, 0 }, { 2, -1 } } };
+__constant__ int c_div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
+
+#define CDEF_NA 0xFFFFu
+
+struct CdefLds {
+  uint16_t y[68 * 68];
+  uint16_t c[2][36 * 36];
+};
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int constrain(int diff, int threshold, int damping) {
+  if (!threshold) return 0;
+  int adj = damping - (31 - __builtin_clz((unsigned)threshold));
+  if (adj < 0) adj = 0;
+  const int mag = iabs(diff);
+  int lim = threshold - (mag >> adj);
+  lim = lim < 0 ? 0 : (lim > mag ? mag : lim);
+  return diff < 0 ? -lim : lim;
+}
+
+template <int W, int LDS_STRIDE>
+__device__ __forceinline__ void filter_block(const uint16_t *t /* block origin in LDS tile */, int pri, int sec, int damping,
+                                             int dir, int coeff_shift, uint16_t (&out)[W * W]) {
+  const int pt0 = ((pri >> coeff_shift) & 1) ? 3 : 4, pt1 = ((pri >> coeff_shift) & 1) ? 3 : 2;
+#pragma unroll
+  for (int i = 0; i < W; i++)
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      const int x = t[i * LDS_STRIDE + j];
+      int sum = 0, mx = x, mn = x;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int ptap = k ? pt1 : pt0, stap = k ? 1 : 2;
+#pragma unroll
+        for (int sg = -1; sg <= 1; sg += 2) {
+          {
+            const int p = t[(i + sg * c_cdef_dir[dir][k][0]) * LDS_STRIDE + j + sg * c_cdef_dir[dir][k][1]];
+            if (p != CDEF_NA) {
+              sum += ptap * constrain(p - x, pri, damping);
+              mx = p > mx ? p : mx;
+              mn = p < mn ? p : mn;
+            }
+          }
+#pragma unroll
+          for (int d = -2; d <= 2; d += 4) {
+            const int dd = (dir + d) & 7;
+            const int s = t[(i + sg * c_cdef_dir[dd][k][0]) * LDS_STRIDE + j + sg * c_cdef_dir[dd][k][1]];
+            if (s != CDEF_NA) {
+              sum += stap * constrain(s - x, sec, damping);
+              mx = s > mx ? s : mx;
+              mn = s < mn ? s : mn;
+            }
+          }
+        }
+      }
+      int v = x + ((8 + sum - (sum < 0)) >> 4);
+      v = v < mn ? mn : (v > mx ? mx : v);
+      out[i * W + j] = (uint16_t)v;
+    }
+}
+
+template <typename PIX>
+__global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
+                                                    const Av1miBlkInfo *__restrict__ blk) {
+  __shared__ CdefLds S;
+  const int sbs_per_frame = P.sb_rows * P.sb_cols;
+  const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
+  const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
+  const int lane = threadIdx.x;
+  const PIX *fr = rec + (size_t)f * P.frame_samples;
+  PIX *fo = fin + (size_t)f * P.frame_samples;
+  const int x0 = sbc * 64, y0 = sbr * 64;
+  // stage luma 68x68 and chroma 36x36 (x2) with halo; outside-frame -> sentinel
+  for (int t = lane; t < 68 * 68; t += 64) {
+    const int r = t / 68, c = t % 68;
+    const int gy = y0 + r - 2, gx = x0 + c - 2;
+    S.y[t] = (gy >= 0 && gx >= 0 && gy < P.height && gx < P.width) ? (uint16_t)fr[(size_t)gy * P.stride_y + gx] : (uint16_t)CDEF_NA;
+  }
+  for (int pl = 0; pl < 2; pl++) {
+    const PIX *cp = fr + (pl ? P.plane_off_v : P.plane_off_u);
+    for (int t = lane; t < 36 * 36; t += 64) {
+      const int r = t / 36, c = t % 36;
+      const int gy = (y0 >> 1) + r - 2, gx = (x0 >> 1) + c - 2;
+      S.c[pl][t] = (gy >= 0 && gx >= 0 && gy < (P.height >> 1) && gx < (P.width >> 1)) ? (uint16_t)cp[(size_t)gy * P.stride_c + gx] : (uint16_t)CDEF_NA;
+    }
+  }
+  __syncthreads();
+  const int b8r = lane >> 3, b8c = lane & 7;
+  const bool inside = (sbr * 8 + b8r) < P.b8_rows && (sbc * 8 + b8c) < P.b8_cols;
+  int skip = 1;
+  if (inside) skip = blk[(size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8 + b8r) * P.b8_cols + sbc * 8 + b8c].skip;
+  // cdef_idx of the superblock is coded (== 0) iff some block in it is not skipped
+  const bool sb_on = __ballot(inside && !skip) != 0ull;
+  if (!inside) return;
+  const int bd = P.bit_depth, coeff_shift = bd - 8;
+  const uint16_t *ty = S.y + (b8r * 8 + 2) * 68 + b8c * 8 + 2;
+  uint16_t outy[64];
+  const bool do_filter = P.enable_cdef && sb_on && !skip;
+  int ydir = 0, var = 0;
+  if (do_filter) {
+    // direction search §7.15.2
+    int cost[8], partial[8][15];
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+      cost[a] = 0;
+#pragma unroll
+      for (int b = 0; b < 15; b++) partial[a][b] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int x = (ty[i * 68 + j] >> coeff_shift) - 128;
+        partial[0][i + j] += x;
+        partial[1][i + j / 2] += x;
+        partial[2][i] += x;
+        partial[3][3 + i - j / 2] += x;
+        partial[4][7 + i - j] += x;
+        partial[5][3 - i / 2 + j] += x;
+        partial[6][j] += x;
+        partial[7][i / 2 + j] += x;
+      }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      cost[2] += partial[2][i] * partial[2][i];
+      cost[6] += partial[6][i] * partial[6][i];
+    }
+    cost[2] *= 105;
+    cost[6] *= 105;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * c_div_table[i + 1];
+      cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * c_div_table[i + 1];
+    }
+    cost[0] += partial[0][7] * partial[0][7] * 105;
+    cost[4] += partial[4][7] * partial[4][7] * 105;
+#pragma unroll
+    for (int i = 1; i < 8; i += 2) {
+#pragma unroll
+      for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
+      cost[i] *= 105;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * c_div_table[2 * j + 2];
+    }
+    int best = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++)
+      if (cost[d] > best) { best = cost[d]; ydir = d; }
+    int opp = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++)
+      if (d == ((ydir + 4) & 7)) opp = cost[d];
+    var = (best - opp) >> 10;
+  }
+  PIX *oy = fo + (size_t)(y0 + b8r * 8) * P.stride_y + x0 + b8c * 8;
+  if (do_filter) {
+    int pri = P.cdef_y_pri << coeff_shift;
+    const int sec = (P.cdef_y_sec == 3 ? 4 : P.cdef_y_sec) << coeff_shift;
+    const int dir = pri == 0 ? 0 : ydir;
+    const int v6 = var >> 6;
+    const int var_str = v6 ? ((31 - __builtin_clz((unsigned)v6)) < 12 ? (31 - __builtin_clz((unsigned)v6)) : 12) : 0;
+    pri = var ? (pri * (4 + var_str) + 8) >> 4 : 0;
+    filter_block<8, 68>(ty, pri, sec, P.cdef_damping + coeff_shift, dir, coeff_shift, outy);
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < 8; j++) oy[(size_t)i * P.stride_y + j] = (PIX)outy[i * 8 + j];
+  } else {
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < 8; j++) oy[(size_t)i * P.stride_y + j] = (PIX)ty[i * 68 + j];
+  }
+  for (int pl = 0; pl < 2; pl++) {
+    const uint16_t *tc = S.c[pl] + (b8r * 4 + 2) * 36 + b8c * 4 + 2;
+    PIX *oc = fo + (pl ? P.plane_off_v : P.plane_off_u) + (size_t)((y0 >> 1) + b8r * 4) * P.stride_c + (x0 >> 1) + b8c * 4;
+    if (do_filter) {
+      const int pri = P.cdef_uv_pri << coeff_shift;
+      const int sec = (P.cdef_uv_sec == 3 ? 4 : P.cdef_uv_sec) << coeff_shift;
+      const int dir = pri == 0 ? 0 : ydir;
+      uint16_t outc[16];
+      filter_block<4, 36>(tc, pri, sec, P.cdef_damping + coeff_shift - 1, dir, coeff_shift, outc);
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) oc[(size_t)i * P.stride_c + j] = (PIX)outc[i * 4 + j];
+    } else {
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) oc[(size_t)i * P.stride_c + j] = (PIX)tc[i * 36 + j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ SSE (PSNR)
+template <typename PIX>
+__global__ void __launch_bounds__(256) sse_kernel(Av1miDevParams P, const PIX *__restrict__ a, const PIX *__restrict__ b,
+                                                 unsigned long long *__restrict__ sse /* [n_frames][3] */) {
+  const int f = blockIdx.y;
+  const PIX *pa = a + (size_t)f * P.frame_samples, *pb = b + (size_t)f * P.frame_samples;
+  const long ny = (long)P.width * P.height, nc = ny >> 2;
+  unsigned long long acc[3] = { 0, 0, 0 };
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P.frame_samples; i += (long)gridDim.x * 256) {
+    const int d = (int)pa[i] - (int)pb[i];
+    const int pl = i < ny ? 0 : (i < ny + nc ? 1 : 2);
+    acc[pl] += (unsigned long long)(d * d);
+  }
+  for (int pl = 0; pl < 3; pl++) {
+    unsigned long long v = acc[pl];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sse[f * 3 + pl], v);
+  }
+}
+
+// ------------------------------------------------------------------------------ packing
+__device__ __forceinline__ int leb128_len(uint32_t v) {
+  int n = 1;
+  while (v >>= 7) n++;
+  return n;
+}
+
+// one workgroup per frame: tile offsets inside the OBU_FRAME payload, frame (temporal unit) size
+__global__ void __launch_bounds__(256) frame_layout_kernel(Av1miDevParams P, const uint32_t *__restrict__ tile_bytes,
+                                                          uint32_t *__restrict__ tile_off, uint32_t *__restrict__ frame_size,
+                                                          uint32_t *__restrict__ payload_size, int *__restrict__ overflow) {
+  __shared__ uint32_t part[256];
+  const int f = blockIdx.x, nt = P.sb_rows * P.sb_cols, t = threadIdx.x;
+  const uint32_t *tb = tile_bytes + (size_t)f * nt;
+  const int per = (nt + 255) / 256;
+  uint32_t s = 0;
+  for (int i = t * per; i < (t + 1) * per && i < nt; i++) {
+    if (tb[i] > (uint32_t)P.tile_slot_bytes) atomicExch(overflow, 1);
+    s += tb[i] + (i < nt - 1 ? (uint32_t)P.tile_size_bytes : 0u);
+  }
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = (uint32_t)P.frame_hdr_bytes;
+    for (int i = 0; i < 256; i++) { uint32_t v = part[i]; part[i] = run; run += v; }
+    payload_size[f] = run;
+    frame_size[f] = 2u + (uint32_t)P.seq_hdr_bytes + 1u + (uint32_t)leb128_len(run) + run;
+  }
+  __syncthreads();
+  uint32_t run = part[t];
+  for (int i = t * per; i < (t + 1) * per && i < nt; i++) {
+    tile_off[(size_t)f * nt + i] = run;
+    run += tb[i] + (i < nt - 1 ? (uint32_t)P.tile_size_bytes : 0u);
+  }
+}
+
+__global__ void chunk_layout_kernel(int n_frames, const uint32_t *__restrict__ frame_size, unsigned long long *__restrict__ frame_off) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int f = 0; f < n_frames; f++) { frame_off[f] = run; run += frame_size[f]; }
+    frame_off[n_frames] = run;
+  }
+}
+
+// one wave per tile: copy the tile (and, for tile 0, the frame's headers) to its final position
+__global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const uint8_t *__restrict__ slots,
+                                                       const uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ tile_off,
+                                                       const uint32_t *__restrict__ payload_size,
+                                                       const unsigned long long *__restrict__ frame_off,
+                                                       const uint8_t *__restrict__ hdr_blob, uint8_t *__restrict__ out) {
+  const int nt = P.sb_rows * P.sb_cols;
+  const int f = blockIdx.x / nt, t = blockIdx.x % nt, lane = threadIdx.x;
+  const uint32_t pay = payload_size[f];
+  const int ll = leb128_len(pay);
+  uint8_t *fo = out + frame_off[f];
+  const int prefix = 2 + P.seq_hdr_bytes + 1 + ll;  // TD + sequence header + OBU_FRAME header + size
+  if (t == 0) {
+    if (lane == 0) {
+      fo[0] = 0x12; fo[1] = 0x00;
+      uint8_t *q = fo + 2 + P.seq_hdr_bytes;
+      q[0] = 0x32;
+      uint32_t v = pay;
+      for (int i = 0; i < ll; i++) { uint8_t b = v & 0x7F; v >>= 7; if (v) b |= 0x80; q[1 + i] = b; }
+    }
+    for (int i = lane; i < P.seq_hdr_bytes; i += 64) fo[2 + i] = hdr_blob[i];
+    for (int i = lane; i < P.frame_hdr_bytes; i += 64) fo[prefix + i] = hdr_blob[P.seq_hdr_bytes + i];
+  }
+  const uint32_t n = tile_bytes[blockIdx.x];
+  uint8_t *dst = fo + prefix + tile_off[blockIdx.x];
+  if (t < nt - 1) {
+    if (lane < P.tile_size_bytes) dst[lane] = (uint8_t)((n - 1) >> (8 * lane));
+    dst += P.tile_size_bytes;
+  }
+  const uint8_t *src = slots + (size_t)blockIdx.x * P.tile_slot_bytes;
+  for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+}
+
+}  // namespace
+
+extern "C" hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t stream) {
+  const int grid = P->n_frames * P->sb_rows * P->sb_cols;
+  if (P->bit_depth == 8)
+    hipLaunchKernelGGL(cdef_sb_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)rec, (uint8_t *)fin, blk);
+  else
+    hipLaunchKernelGGL(cdef_sb_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)rec, (uint16_t *)fin, blk);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t stream) {
+  dim3 grid(64, P->n_frames);
+  if (P->bit_depth == 8)
+    hipLaunchKernelGGL(sse_kernel<uint8_t>, grid, dim3(256), 0, stream, *P, (const uint8_t *)a, (const uint8_t *)b, sse);
+  else
+    hipLaunchKernelGGL(sse_kernel<uint16_t>, grid, dim3(256), 0, stream, *P, (const uint16_t *)a, (const uint16_t *)b, sse);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t av1mi_launch_pack(const Av1miDevParams *P, const uint8_t *slots, const uint32_t *tile_bytes, uint32_t *tile_off,
+                                        uint32_t *frame_size, uint32_t *payload_size, unsigned long long *frame_off,
+                                        const uint8_t *hdr_blob, uint8_t *out, int *overflow, int stage, hipStream_t stream) {
+  const int nt = P->sb_rows * P->sb_cols;
+  if (stage == 0) {
+    hipLaunchKernelGGL(frame_layout_kernel, dim3(P->n_frames), dim3(256), 0, stream, *P, tile_bytes, tile_off, frame_size, payload_size, overflow);
+    hipLaunchKernelGGL(chunk_layout_kernel, dim3(1), dim3(64), 0, stream, P->n_frames, frame_size, frame_off);
+  } else {
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(P->n_frames * nt), dim3(64), 0, stream, *P, slots, tile_bytes, tile_off, payload_size, frame_off, hdr_blob, out);
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,524 @@
+// recon_kernel.hip - closed-loop intra reconstruction of one 64x64 superblock (= one tile) per
+// wavefront, for every superblock of every frame of a chunk in one launch.
+//
+// Replaces the per-superblock inner loop that the reference runs inside an external SVT-AV1
+// worker (av1an -> SVT-AV1, reached through `run_av1an`,
+// /root/reference/crates/daemon/src/encode/av1an.rs:126-139):
+// directional/smooth/Paeth/DC intra prediction (AV1 spec §7.11.2), forward DCT/ADST, dead-zone
+// quantiser, normative dequantiser (§7.12.3) and inverse DCT/ADST (§7.13.3).
+//
+// MI355X mapping: one 64-lane wave owns one superblock; the superblock's
+// reconstruction lives in LDS (u16 planes) for the whole walk, so neighbour edges never touch
+// HBM; source pixels are read once (coalesced rows) into registers; transforms run one row or
+// column per lane on VGPR-resident straight-line butterflies (txfm_gen.h) with the 2-D
+// transposition staged through a padded LDS tile (stride n+1: conflict-free for both row and
+// column access); quantised levels are staged in LDS and leave as 16-byte-per-lane stores.
+// Algorithmic HBM traffic per superblock: source read once, reconstruction written once, levels
+// written once (SURVEY.md §8d "stage A").
+#include <hip/hip_runtime.h>
+#include "av1mi_dev.h"
+#define AV1_TXFM_FN static __device__ __forceinline__
+#include "txfm_gen.h"
+
+namespace {
+
+enum { DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED, D67_PRED,
+       SMOOTH_PRED, SMOOTH_V_PRED, SMOOTH_H_PRED, PAETH_PRED };
+
+__constant__ uint8_t c_sm_weights[4 + 8 + 16 + 32 + 64] = {
+  255, 149, 85, 64,
+  255, 197, 146, 105, 73, 50, 37, 32,
+  255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16,
+  255, 240, 225, 210, 196, 182, 169, 157, 145, 133, 122, 111, 101, 92, 83, 74, 66, 59, 52, 45, 39, 34, 29, 25, 21, 17, 14, 12, 10, 9, 8, 8,
+  255, 248, 240, 233, 225, 218, 210, 203, 196, 189, 182, 176, 169, 163, 156, 150, 144, 138, 133, 127, 121, 116, 111, 106, 101, 96, 91, 86, 82, 77, 73, 69,
+  65, 61, 57, 54, 50, 47, 44, 41, 38, 35, 32, 29, 27, 25, 22, 20, 18, 16, 15, 13, 12, 10, 9, 8, 7, 6, 6, 5, 5, 4, 4, 4 };
+// Dr_Intra_Derivative indexed by angle/3 rounded down is not injective, so index by angle
+__constant__ int16_t c_dr_deriv[91] = {
+  0, 0, 0, 1023, 0, 0, 547, 0, 0, 372, 0, 0, 0, 0, 273, 0, 0, 215, 0, 0, 178, 0, 0, 151, 0, 0, 132, 0, 0, 116, 0, 0,
+  102, 0, 0, 0, 90, 0, 0, 80, 0, 0, 71, 0, 0, 64, 0, 0, 57, 0, 0, 51, 0, 0, 45, 0, 0, 0, 40, 0, 0, 35, 0, 0,
+  31, 0, 0, 27, 0, 0, 23, 0, 0, 19, 0, 0, 15, 0, 0, 0, 0, 11, 0, 0, 7, 0, 0, 3, 0, 0, 0 };
+__constant__ int16_t c_mode_angle[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
+// Mode_To_Txfm (spec §6.10.x): 0 DCT_DCT 1 ADST_DCT 2 DCT_ADST 3 ADST_ADST
+__constant__ uint8_t c_mode_txfm[13] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3 };
+
+struct SbLds {
+  uint16_t rec_y[64 * 64];   // superblock reconstruction, u16 for 8 and 10 bit
+  uint16_t rec_c[2][32 * 32];
+  int32_t scratch[32 * 33];
+  uint16_t edge_a[2 * 64 + 8];  // [0] = element -1
+  uint16_t edge_l[2 * 64 + 8];
+  int16_t lvl[32 * 32];
+  uint8_t blkdec[2][19][19];    // luma, chroma (U and V decode together)
+};
+
+__device__ __forceinline__ int wave_sum(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int rshift_round(int v, int s) { return s ? (v + (1 << (s - 1))) >> s : v; }
+__device__ __forceinline__ int clamp_bits(int v, int bits) {
+  int lo = -(1 << (bits - 1)), hi = (1 << (bits - 1)) - 1;
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// ---- 1-D transform dispatch (type: 0 DCT, 1 ADST) -------------------------------------------
+template <int LOG2N> struct Tx1d;
+template <> struct Tx1d<2> {
+  static __device__ __forceinline__ void iadst(int32_t *x) {
+    // spec §7.13.2.6 inverse ADST4 (sinpi 1321 2482 3344 3803)
+    int x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    int s0 = 1321 * x0, s1 = 2482 * x0, s2 = 3344 * x1, s3 = 3803 * x2, s4 = 1321 * x2, s5 = 2482 * x3, s6 = 3803 * x3;
+    int s7 = x0 - x2 + x3;
+    s0 = s0 + s3; s1 = s1 - s4; s3 = s2; s2 = 3344 * s7;
+    s0 = s0 + s5; s1 = s1 - s6;
+    x[0] = (s0 + s3 + 2048) >> 12; x[1] = (s1 + s3 + 2048) >> 12; x[2] = (s2 + 2048) >> 12; x[3] = (s0 + s1 - s3 + 2048) >> 12;
+  }
+  static __device__ __forceinline__ void fadst(int32_t *x) {
+    int x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    int s0 = 1321 * x0, s1 = 3803 * x0, s2 = 2482 * x1, s3 = 1321 * x1, s4 = 3344 * x2, s5 = 3803 * x3, s6 = 2482 * x3;
+    int s7 = x0 + x1 - x3;
+    int y0 = s0 + s2 + s5, y1 = 3344 * s7, y2 = s1 - s3 + s6, y3 = s4;
+    x[0] = (y0 + y3 + 2048) >> 12; x[1] = (y1 + 2048) >> 12; x[2] = (y2 - y3 + 2048) >> 12; x[3] = (y2 - y0 + y3 + 2048) >> 12;
+  }
+  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t) fadst(x); else av1_fdct4(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t) iadst(x); else av1_idct4(x); }
+};
+template <> struct Tx1d<3> {
+  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t) av1_fadst8(x); else av1_fdct8(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t) av1_iadst8(x); else av1_idct8(x); }
+};
+template <> struct Tx1d<4> {
+  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t) av1_fadst16(x); else av1_fdct16(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t) av1_iadst16(x); else av1_idct16(x); }
+};
+template <> struct Tx1d<5> {
+  static __device__ __forceinline__ void fwd(int32_t *x, int) { av1_fdct32(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int) { av1_idct32(x); }
+};
+
+// position of (row, col) in the default zig-zag scan of an n x n block:
+// odd anti-diagonals run with increasing row, even ones with increasing column.
+__device__ __forceinline__ int scan_index(int row, int col, int n) {
+  int d = row + col;
+  int before = d < n ? (d * (d + 1)) >> 1 : n * n - (((2 * n - 1 - d) * (2 * n - d)) >> 1);
+  int lo = d - (n - 1) > 0 ? d - (n - 1) : 0;
+  return before + ((d & 1) ? row - lo : col - lo);
+}
+
+// ---- intra prediction of one pixel (spec §7.11.2, no edge filter / upsampling) -------------------
+// A = &edge_a[1], L = &edge_l[1] (index -1 valid).
+template <int LOG2N>
+__device__ __forceinline__ int pred_pixel(int mode, int r, int c, const uint16_t *A, const uint16_t *L, int dcval) {
+  constexpr int N = 1 << LOG2N;
+  constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
+  switch (mode) {
+    case DC_PRED: return dcval;
+    case V_PRED: return A[c];
+    case H_PRED: return L[r];
+    case PAETH_PRED: {
+      int tl = A[-1], t = A[c], l = L[r];
+      int base = t + l - tl;
+      int pl = iabs(base - l), pt = iabs(base - t), ptl = iabs(base - tl);
+      return (pl <= pt && pl <= ptl) ? l : (pt <= ptl ? t : tl);
+    }
+    case SMOOTH_PRED: {
+      int wr = c_sm_weights[WOFF + r], wc = c_sm_weights[WOFF + c];
+      return (wr * A[c] + (256 - wr) * L[N - 1] + wc * L[r] + (256 - wc) * A[N - 1] + 256) >> 9;
+    }
+    case SMOOTH_V_PRED: {
+      int wr = c_sm_weights[WOFF + r];
+      return (wr * A[c] + (256 - wr) * L[N - 1] + 128) >> 8;
+    }
+    case SMOOTH_H_PRED: {
+      int wc = c_sm_weights[WOFF + c];
+      return (wc * L[r] + (256 - wc) * A[N - 1] + 128) >> 8;
+    }
+    default: {
+      int ang = c_mode_angle[mode];  // angle delta is always 0 in this build's decisions
+      if (ang < 90) {
+        int dx = c_dr_deriv[ang];
+        int idx = (r + 1) * dx;
+        int base = (idx >> 6) + c, sh = (idx >> 1) & 31;
+        if (base < 2 * N - 1) return (A[base] * (32 - sh) + A[base + 1] * sh + 16) >> 5;
+        return A[2 * N - 1];
+      } else if (ang < 180) {
+        int dx = c_dr_deriv[180 - ang], dy = c_dr_deriv[ang - 90];
+        int idx = (c << 6) - (r + 1) * dx;
+        int base = idx >> 6;
+        if (base >= -1) {
+          int sh = (idx >> 1) & 31;
+          return (A[base] * (32 - sh) + A[base + 1] * sh + 16) >> 5;
+        }
+        idx = (r << 6) - (c + 1) * dy;
+        base = idx >> 6;
+        int sh = (idx >> 1) & 31;
+        return (L[base] * (32 - sh) + L[base + 1] * sh + 16) >> 5;
+      } else {
+        int dy = c_dr_deriv[270 - ang];
+        int idx = (c + 1) * dy;
+        int base = (idx >> 6) + r, sh = (idx >> 1) & 31;
+        return (L[base] * (32 - sh) + L[base + 1] * sh + 16) >> 5;
+      }
+    }
+  }
+}
+
+struct SbCtx {
+  const Av1miDevParams *P;
+  SbLds *S;
+  int lane;
+  int sb_x, sb_y;          // superblock origin in luma pixels
+};
+
+// Fill edge_a / edge_l for an n x n block at (x0, y0) of `plane` (plane-local pixel coordinates
+// inside the superblock).  Tile == superblock, so nothing outside the superblock is available.
+template <int LOG2N>
+__device__ __forceinline__ void prepare_edges(const SbCtx &cx, int plane, int x0, int y0, int have_ar, int have_bl) {
+  constexpr int N = 1 << LOG2N;
+  SbLds *S = cx.S;
+  const int stride = plane ? 32 : 64;
+  const uint16_t *rec = plane ? S->rec_c[plane - 1] : S->rec_y;
+  const int bd = cx.P->bit_depth;
+  const int have_above = y0 > 0, have_left = x0 > 0;
+  // frame limits in superblock-local coordinates of this plane
+  const int max_x = ((plane ? cx.P->width >> 1 : cx.P->width) - 1) - (plane ? cx.sb_x >> 1 : cx.sb_x);
+  const int max_y = ((plane ? cx.P->height >> 1 : cx.P->height) - 1) - (plane ? cx.sb_y >> 1 : cx.sb_y);
+  uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
+  for (int i = cx.lane; i < 2 * N; i += 64) {
+    int a, l;
+    if (!have_above && have_left) a = rec[y0 * stride + x0 - 1];
+    else if (!have_above) a = (1 << (bd - 1)) - 1;
+    else {
+      int lim = x0 + (have_ar ? 2 * N : N) - 1;
+      if (lim > max_x) lim = max_x;
+      int xx = x0 + i < lim ? x0 + i : lim;
+      a = rec[(y0 - 1) * stride + xx];
+    }
+    if (!have_left && have_above) l = rec[(y0 - 1) * stride + x0];
+    else if (!have_left) l = (1 << (bd - 1)) + 1;
+    else {
+      int lim = y0 + (have_bl ? 2 * N : N) - 1;
+      if (lim > max_y) lim = max_y;
+      int yy = y0 + i < lim ? y0 + i : lim;
+      l = rec[yy * stride + x0 - 1];
+    }
+    A[i] = (uint16_t)a;
+    L[i] = (uint16_t)l;
+  }
+  if (cx.lane == 0) {
+    int tl;
+    if (have_above && have_left) tl = rec[(y0 - 1) * stride + x0 - 1];
+    else if (have_above) tl = rec[(y0 - 1) * stride + x0];
+    else if (have_left) tl = rec[y0 * stride + x0 - 1];
+    else tl = 1 << (bd - 1);
+    A[-1] = (uint16_t)tl;
+    L[-1] = (uint16_t)tl;
+  }
+  __syncthreads();
+}
+
+template <int LOG2N>
+__device__ __forceinline__ int dc_value(const SbCtx &cx, int have_above, int have_left) {
+  constexpr int N = 1 << LOG2N;
+  const uint16_t *A = cx.S->edge_a + 1, *L = cx.S->edge_l + 1;
+  int s = 0;
+  if (cx.lane < N) s = (have_above ? A[cx.lane] : 0) + (have_left ? L[cx.lane] : 0);
+  s = wave_sum(s);
+  if (have_above && have_left) return (s + N) >> (LOG2N + 1);
+  if (have_above || have_left) return (s + (N >> 1)) >> LOG2N;
+  return 1 << (cx.P->bit_depth - 1);
+}
+
+// Predict + transform + quantise + reconstruct one n x n transform block.
+// src: this lane's source pixels (pixel p = lane + 64*k -> row p / N, col p % N).
+// Returns eob; levels (row-major n x n int16) go to `lv_out` (global) when eob > 0.
+template <int LOG2N, int PPL>
+__device__ __forceinline__ int code_tx_block(const SbCtx &cx, int plane, int x0, int y0, int mode, int dcval,
+                                             const int (&src)[PPL], int16_t *lv_out) {
+  constexpr int N = 1 << LOG2N;
+  constexpr int ST = N + 1;
+  SbLds *S = cx.S;
+  const Av1miDevParams *P = cx.P;
+  const int stride = plane ? 32 : 64;
+  uint16_t *rec = plane ? S->rec_c[plane - 1] : S->rec_y;
+  const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
+  const int bd = P->bit_depth;
+  const int txt = LOG2N <= 4 ? c_mode_txfm[mode] : 0;
+  const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
+  constexpr int SH0 = 2, SH1 = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : (LOG2N == 4 ? 2 : 4));
+  constexpr int RS = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : 2);
+  // 1. prediction -> rec, residual -> scratch
+#pragma unroll
+  for (int k = 0; k < PPL; k++) {
+    int p = cx.lane + 64 * k;
+    if (p < N * N) {
+      int r = p >> LOG2N, c = p & (N - 1);
+      int pv = pred_pixel<LOG2N>(mode, r, c, A, L, dcval);
+      rec[(y0 + r) * stride + x0 + c] = (uint16_t)pv;
+      S->scratch[r * ST + c] = src[k] - pv;
+    }
+  }
+  __syncthreads();
+  // 2. forward columns
+  int32_t x[N];
+  if (cx.lane < N) {
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = S->scratch[i * ST + cx.lane] << SH0;
+    Tx1d<LOG2N>::fwd(x, vt);
+#pragma unroll
+    for (int i = 0; i < N; i++) S->scratch[i * ST + cx.lane] = rshift_round(x[i], SH1);
+  }
+  __syncthreads();
+  // 3. forward rows, quantise, dequantise, inverse rows
+  int my_eob = 0;
+  if (cx.lane < N) {
+    const int row = cx.lane;
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = S->scratch[row * ST + j];
+    Tx1d<LOG2N>::fwd(x, ht);
+    constexpr int TSH = LOG2N == 5 ? 1 : 0;  // dequant shift of the size class (§7.12.3)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      int v = x[j];
+      bool dc = (row | j) == 0;
+      uint32_t q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
+      uint32_t recip = dc ? P->dc_recip : P->ac_recip;
+      uint32_t a = ((uint32_t)iabs(v) << TSH) + ((3 * q) >> 3);
+      uint32_t lv = __umulhi(a, recip);
+      if (lv > 0x7FFF) lv = 0x7FFF;
+      int slv = v < 0 ? -(int)lv : (int)lv;
+      S->lvl[row * N + j] = (int16_t)slv;
+      if (lv) {
+        int si = scan_index(row, j, N) + 1;
+        my_eob = si > my_eob ? si : my_eob;
+        int d = (int)(((uint32_t)lv * q) & 0xFFFFFF) >> TSH;
+        int lim = 1 << (7 + bd);
+        d = v < 0 ? -d : d;
+        d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
+        x[j] = clamp_bits(d, bd + 8);
+      } else {
+        x[j] = 0;
+      }
+    }
+  }
+  const int eob = wave_max(my_eob);
+  if (eob == 0) return 0;  // reconstruction = prediction
+  if (cx.lane < N) {
+    const int row = cx.lane;
+    Tx1d<LOG2N>::inv(x, ht);
+#pragma unroll
+    for (int j = 0; j < N; j++) S->scratch[row * ST + j] = clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
+  }
+  __syncthreads();
+  // 4. inverse columns + reconstruction
+  if (cx.lane < N) {
+    const int col = cx.lane;
+    const int maxv = (1 << bd) - 1;
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = S->scratch[i * ST + col];
+    Tx1d<LOG2N>::inv(x, vt);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int v = rec[(y0 + i) * stride + x0 + col] + ((x[i] + 8) >> 4);
+      rec[(y0 + i) * stride + x0 + col] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+    }
+  }
+  // 5. levels out (staged in LDS, coalesced)
+  {
+    constexpr int WORDS = N * N / 2;  // 32-bit words
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(S->lvl);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(lv_out);
+    for (int i = cx.lane; i < WORDS; i += 64) d32[i] = s32[i];
+  }
+  __syncthreads();
+  return eob;
+}
+
+template <typename PIX, int LOG2N, int PPL>
+__device__ __forceinline__ void load_src(const PIX *plane, int stride, int gx, int gy, int lane, int (&src)[PPL]) {
+  constexpr int N = 1 << LOG2N;
+#pragma unroll
+  for (int k = 0; k < PPL; k++) {
+    int p = lane + 64 * k;
+    src[k] = 0;
+    if (p < N * N) {
+      int r = p >> LOG2N, c = p & (N - 1);
+      src[k] = plane[(size_t)(gy + r) * stride + gx + c];
+    }
+  }
+}
+
+// One leaf block: luma mode decision (closed-loop SAD over the candidate modes, first minimum in
+// mode order wins), luma + both chroma transform blocks.
+template <typename PIX, int LOG2N>
+__device__ __forceinline__ void encode_block(const SbCtx &cx, const PIX *frame, int bx, int by,
+                                             int16_t *sb_levels, Av1miBlkInfo *info, int b8_stride) {
+  constexpr int N = 1 << LOG2N;
+  constexpr int PPL = (N * N + 63) / 64;
+  constexpr int LOG2C = LOG2N - 1;
+  constexpr int NC = N >> 1;
+  constexpr int PPLC = (NC * NC + 63) / 64;
+  SbLds *S = cx.S;
+  const Av1miDevParams *P = cx.P;
+  // availability of above-right / below-left from the decoded-block map (spec §5.11.35)
+  const int r4 = by >> 2, c4 = bx >> 2, step = N >> 2;
+  const int have_ar = S->blkdec[0][r4 - 1 + 1][c4 + step + 1];
+  const int have_bl = S->blkdec[0][r4 + step + 1][c4 - 1 + 1];
+  constexpr int stepc = (NC >> 2) > 0 ? (NC >> 2) : 1;
+  const int have_ar_c = S->blkdec[1][(r4 >> 1) - 1 + 1][(c4 >> 1) + stepc + 1];
+  const int have_bl_c = S->blkdec[1][(r4 >> 1) + stepc + 1][(c4 >> 1) - 1 + 1];
+  int src[PPL];
+  load_src<PIX, LOG2N, PPL>(frame, P->stride_y, cx.sb_x + bx, cx.sb_y + by, cx.lane, src);
+  prepare_edges<LOG2N>(cx, 0, bx, by, have_ar, have_bl);
+  const int have_above = by > 0, have_left = bx > 0;
+  const int dcv = dc_value<LOG2N>(cx, have_above, have_left);
+  // ---- mode decision
+  int best_mode = 0, best_sad = 0x7FFFFFFF;
+  {
+    const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
+    for (int m = 0; m < 13; m++) {
+      if (!((P->mode_mask >> m) & 1)) continue;
+      int sad = 0;
+#pragma unroll
+      for (int k = 0; k < PPL; k++) {
+        int p = cx.lane + 64 * k;
+        if (p < N * N) sad += iabs(src[k] - pred_pixel<LOG2N>(m, p >> LOG2N, p & (N - 1), A, L, dcv));
+      }
+      sad = wave_sum(sad);
+      if (sad < best_sad) { best_sad = sad; best_mode = m; }
+    }
+  }
+  const int mode = best_mode;
+  int16_t *lv_y = sb_levels + by * 64 + bx * N;
+  const int eob_y = code_tx_block<LOG2N, PPL>(cx, 0, bx, by, mode, dcv, src, lv_y);
+  // ---- chroma (uv_mode = y mode)
+  int eob_c[2];
+#pragma unroll
+  for (int pl = 1; pl < 3; pl++) {
+    const PIX *cplane = frame + (pl == 1 ? P->plane_off_u : P->plane_off_v);
+    int csrc[PPLC];
+    load_src<PIX, LOG2C, PPLC>(cplane, P->stride_c, (cx.sb_x + bx) >> 1, (cx.sb_y + by) >> 1, cx.lane, csrc);
+    prepare_edges<LOG2C>(cx, pl, bx >> 1, by >> 1, have_ar_c, have_bl_c);
+    const int dcc = dc_value<LOG2C>(cx, have_above, have_left);
+    int16_t *lv_c = sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * NC;
+    eob_c[pl - 1] = code_tx_block<LOG2C, PPLC>(cx, pl, bx >> 1, by >> 1, mode, dcc, csrc, lv_c);
+  }
+  // ---- bookkeeping
+  const int skip = (eob_y | eob_c[0] | eob_c[1]) == 0;
+  if (cx.lane == 0) {
+    const int n8 = N >> 3 ? N >> 3 : 1;
+    for (int i = 0; i < n8; i++)
+      for (int j = 0; j < n8; j++) {
+        Av1miBlkInfo bi;
+        bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)skip; bi.bsl = (uint8_t)LOG2N; bi.pad = 0;
+        bi.eob[0] = (uint16_t)eob_y; bi.eob[1] = (uint16_t)eob_c[0]; bi.eob[2] = (uint16_t)eob_c[1]; bi.pad2 = 0;
+        info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
+      }
+  }
+  for (int t = cx.lane; t < step * step; t += 64) S->blkdec[0][r4 + t / step + 1][c4 + t % step + 1] = 1;
+  for (int t = cx.lane; t < stepc * stepc; t += 64) S->blkdec[1][(r4 >> 1) + t / stepc + 1][(c4 >> 1) + t % stepc + 1] = 1;
+  __syncthreads();
+}
+
+// Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
+// not the origin of a leaf.  The tree is a pure function of geometry: a block is
+// a leaf iff it lies inside the frame and its size is <= max_bs (never below 8x8).
+__device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, int sb_y, int bx, int by) {
+  for (int bsl = 6; bsl >= 3; bsl--) {
+    const int n = 1 << bsl;
+    const int ox = bx & ~(n - 1), oy = by & ~(n - 1);
+    bool split;
+    if (bsl <= P.min_bs_log2 || bsl == 3) split = false;
+    else if (bsl > P.max_bs_log2) split = true;
+    else split = false;
+    if (sb_y + oy + n > P.height || sb_x + ox + n > P.width) split = true;
+    if (bsl == 3) split = false;
+    if (!split) return (ox == bx && oy == by) ? bsl : 0;
+  }
+  return 0;
+}
+
+template <typename PIX>
+__device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, int16_t *sb_levels,
+                                                  Av1miBlkInfo *info, int b8_stride) {
+  const Av1miDevParams &P = *cx.P;
+  for (int z = 0; z < 64; z++) {  // 8x8 units in Z (partition) order
+    const int bx = (((z >> 0) & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) << 3;
+    const int by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) << 3;
+    if (cx.sb_y + by >= P.height || cx.sb_x + bx >= P.width) continue;
+    const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
+    switch (bsl) {
+      case 3: encode_block<PIX, 3>(cx, frame, bx, by, sb_levels, info, b8_stride); break;
+      case 4: encode_block<PIX, 4>(cx, frame, bx, by, sb_levels, info, b8_stride); break;
+      case 5: encode_block<PIX, 5>(cx, frame, bx, by, sb_levels, info, b8_stride); break;
+      default: break;
+    }
+  }
+}
+
+template <typename PIX>
+__global__ void __launch_bounds__(64) recon_sb_kernel(Av1miDevParams P, const PIX *__restrict__ src, PIX *__restrict__ rec,
+                                                     int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk) {
+  __shared__ SbLds S;
+  const int sbs_per_frame = P.sb_rows * P.sb_cols;
+  const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
+  const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
+  SbCtx cx;
+  cx.P = &P; cx.S = &S; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
+  const PIX *frame = src + (size_t)f * P.frame_samples;
+  // decoded-block map (clear_block_decoded_flags, spec §5.11.3) with tile == superblock
+  {
+    const int w4 = (P.mi_cols - sbc * 16), h4 = (P.mi_rows - sbr * 16);
+    for (int t = cx.lane; t < 2 * 19 * 19; t += 64) {
+      int pl = t / 361, y = (t % 361) / 19 - 1, x = t % 19 - 1;
+      int sz = 16 >> pl;
+      int sw = (w4 < 16 ? w4 : 16) >> pl, sh = (h4 < 16 ? h4 : 16) >> pl;
+      int v = 0;
+      if (y <= sz && x <= sz) {
+        if (y < 0 && x < sw) v = 1;
+        else if (x < 0 && y < sh) v = 1;
+        if (y == sz && x == -1) v = 0;
+      }
+      S.blkdec[pl][y + 1][x + 1] = (uint8_t)v;
+    }
+  }
+  __syncthreads();
+  int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
+  Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
+  encode_superblock<PIX>(cx, frame, sb_levels, info, P.b8_cols);
+  __syncthreads();
+  // superblock reconstruction -> HBM (in-frame part only)
+  PIX *out = rec + (size_t)f * P.frame_samples;
+  {
+    const int w = P.width - cx.sb_x < 64 ? P.width - cx.sb_x : 64, h = P.height - cx.sb_y < 64 ? P.height - cx.sb_y : 64;
+    for (int t = cx.lane; t < 64 * h; t += 64) {
+      int r = t >> 6, c = t & 63;
+      if (c < w) out[(size_t)(cx.sb_y + r) * P.stride_y + cx.sb_x + c] = (PIX)S.rec_y[r * 64 + c];
+    }
+    const int wc = w >> 1, hc = h >> 1;
+    for (int pl = 1; pl < 3; pl++) {
+      PIX *op = out + (pl == 1 ? P.plane_off_u : P.plane_off_v);
+      for (int t = cx.lane; t < 32 * hc; t += 64) {
+        int r = t >> 5, c = t & 31;
+        if (c < wc) op[(size_t)((cx.sb_y >> 1) + r) * P.stride_c + (cx.sb_x >> 1) + c] = (PIX)S.rec_c[pl - 1][r * 32 + c];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels,
+                                         Av1miBlkInfo *blk, hipStream_t stream) {
+  const int grid = P->n_frames * P->sb_rows * P->sb_cols;
+  if (P->bit_depth == 8)
+    hipLaunchKernelGGL(recon_sb_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk);
+  else
+    hipLaunchKernelGGL(recon_sb_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk);
+  return hipGetLastError();
+}

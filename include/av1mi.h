@@ -1,0 +1,124 @@
+/* av1mi.h - C ABI of libav1mi: the MI355X-native AV1 chunk encoder that replaces the
+ * `av1an` -> SVT-AV1 subprocess behind the av1-base daemon's encode boundary.
+ *
+ * Every entry point names the reference interface (file:line under /root/reference) it
+ * replaces.  Plain C types only: no C++/torch types cross this boundary; nothing throws.
+ *
+ * Error convention (maps 1:1 onto the reference's `EncodeError`,
+ * crates/daemon/src/encode/av1an.rs:17-30):
+ *     0            -> Ok(())
+ *     > 0          -> EncodeError::Av1anFailed(code)      (encoder / GPU failure; see AV1MI_E_*)
+ *     < 0 (-errno) -> EncodeError::Io(io::Error::from_raw_os_error(errno))
+ * `Av1anTerminated` (killed by signal) has no in-process equivalent.
+ */
+#ifndef AV1MI_H
+#define AV1MI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AV1MI_ABI_VERSION 1
+
+/* positive failure codes (-> Av1anFailed(code)) */
+enum {
+  AV1MI_OK = 0,
+  AV1MI_E_INVALID_ARG = 1,   /* bad dimensions / parameters */
+  AV1MI_E_NO_DEVICE = 2,     /* no MI355X visible, or HIP runtime failure at init */
+  AV1MI_E_HIP = 3,           /* a HIP call or kernel failed; see av1mi_last_error() */
+  AV1MI_E_OOM = 4,           /* host or device allocation failed */
+  AV1MI_E_OVERFLOW = 5,      /* a tile outgrew its bitstream slot */
+  AV1MI_E_FORMAT = 6,        /* input file is not a supported Y4M (420, 8/10 bit) */
+  AV1MI_E_UNSUPPORTED = 7    /* valid request this build cannot serve yet (e.g. keyint > 1) */
+};
+
+typedef struct av1mi_ctx av1mi_ctx;
+
+/* Operating point.  Replaces the reference's single constant
+ *   SVT_PARAMS = "--crf 8 --preset 3 --film-grain 20 ... --keyint 240 --lookahead 40"
+ * (crates/daemon/src/encode/av1an.rs:14) and `--pix-format yuv420p10le` (av1an.rs:90). */
+typedef struct {
+  uint32_t width, height;   /* luma size, multiples of 8, yuv 4:2:0 */
+  uint32_t bit_depth;       /* 8 or 10 (samples: uint8_t / little-endian uint16_t) */
+  uint32_t cq_level;        /* "--crf N": 0..63, mapped to base_q_idx like aom (30 -> 120) */
+  uint32_t keyint;          /* "--keyint": 1 = every frame a key frame (only value served today) */
+  uint32_t block_log2;      /* leaf block size log2: 3 (8x8) .. 5 (32x32); 0 = default (5) */
+  uint32_t cdf_update;      /* 1 = adaptive CDFs (default), 0 = static CDFs (disable_cdf_update) */
+  uint32_t enable_cdef;     /* 1 = CDEF on (default) */
+  uint32_t cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping; /* 0s = defaults */
+  uint32_t reserved[8];
+} av1mi_params;
+
+typedef struct {
+  uint8_t *data;            /* malloc'ed by the library; release with av1mi_free() */
+  size_t size;
+} av1mi_buf;
+
+/* per-chunk report: fills the reference's hollow JobMetrics fields `fps, frames_encoded, psnr`
+ * (crates/daemon/src/metrics.rs:12-30; zeros today at job_executor.rs:117-137) */
+typedef struct {
+  uint32_t frames;
+  uint64_t bytes;
+  double sse[3];            /* sum of squared error of the reconstruction, per plane */
+  double psnr[3];
+  /* device time per stage, milliseconds (HIP events on the encoder's stream) */
+  float ms_h2d, ms_recon, ms_cdef, ms_entropy, ms_pack, ms_d2h, ms_total;
+  uint64_t n_symbols;       /* arithmetic-coded symbols */
+} av1mi_report;
+
+void av1mi_default_params(av1mi_params *p, uint32_t width, uint32_t height, uint32_t bit_depth);
+
+/* One context = one GPU + one HIP stream = one chunk in flight.  `workers` of the reference's
+ * ConcurrencyPlan (crates/daemon/src/concurrency.rs:9-18 -> `--workers`, av1an.rs:100-101)
+ * becomes "number of contexts".  Thread-safe across contexts; one thread per context. */
+int av1mi_ctx_create(int device_id, av1mi_ctx **out);
+void av1mi_ctx_destroy(av1mi_ctx *ctx);
+const char *av1mi_last_error(const av1mi_ctx *ctx);
+
+/* Encode one scene-chunk: `n_frames` planar I420 frames, frame k at
+ * `frames + k * frame_bytes` with frame_bytes = w*h*3/2*bytes_per_sample (Y then U then V) -
+ * the unit av1an hands to one SVT-AV1 worker.  `frames_on_device` != 0: `frames` is a device
+ * pointer (HBM-resident input).  Output: a Section-5 OBU stream (temporal delimiter + sequence
+ * header + OBU_FRAME per frame); `frame_sizes` (optional, n_frames entries) receives each
+ * temporal unit's size.  `recon` (optional, same layout/pointer kind as `frames`) receives the
+ * decoder-identical reconstruction.  Blocking; returns the error codes above. */
+int av1mi_encode_chunk(av1mi_ctx *ctx, const av1mi_params *params, const void *frames, uint32_t n_frames,
+                       int frames_on_device, av1mi_buf *out, uint32_t *frame_sizes, void *recon,
+                       av1mi_report *report);
+
+void av1mi_free(void *p);
+
+/* ---- the drop-in for `run_av1an` ---------------------------------------------------------
+ * Replaces  pub fn run_av1an(params: &Av1anEncodeParams) -> Result<(), EncodeError>
+ * (crates/daemon/src/encode/av1an.rs:126-139), called from JobExecutor::execute through
+ * tokio::task::spawn_blocking (crates/daemon/src/job_executor.rs:279-287).
+ * Field for field `Av1anEncodeParams` (av1an.rs:36-45): input_path, output_path,
+ * temp_chunks_dir, concurrency.av1an_workers. */
+typedef struct {
+  const char *input_path;   /* Y4M (420jpeg/420p10) - container demux/decode is out of scope */
+  const char *output_path;  /* IVF written atomically (tmp + rename); never left zero-length */
+  const char *temp_dir;     /* caller-owned scratch (job_executor.rs:275-276); only tmp files go here */
+  uint32_t workers;         /* chunks in flight = contexts (one per visible GPU, round-robin) */
+  uint32_t chunk_frames;    /* frames per chunk (0 = 60) */
+  int32_t gpu_mask;         /* bit i = may use GPU i; <= 0 = all visible */
+  av1mi_params params;      /* width/height/bit_depth are taken from the Y4M header */
+} av1mi_job;
+
+typedef void (*av1mi_progress_cb)(void *user, uint32_t frames_done, uint32_t frames_total, double fps,
+                                  uint64_t bytes_out);
+
+int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total);
+
+/* helpers shared with the host mirror / tests */
+uint32_t av1mi_cq_to_qindex(uint32_t cq_level);
+uint32_t av1mi_abi_version(void);
+/* writes the sequence header OBU + frame header bytes the encoder will emit (for KATs) */
+int av1mi_write_headers(const av1mi_params *p, uint8_t *seq_hdr, size_t *seq_len, uint8_t *frame_hdr,
+                        size_t *frame_hdr_bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
