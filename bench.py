@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X AV1 chunk-encode path.
+
+Metric (BASELINE.json): encoded frames/s at CQ=30.  Workload at N=1 = BASELINE.json configs[1]:
+1080p, 60-frame all-key-frame (intra-only) `synthclip v1` chunk, 10-bit
+(the reference's pixel format, av1an.rs:90) unless --bit-depth 8.  One "step" = one complete
+encode of one chunk per GPU: source frames already resident in HBM -> reconstruction, CDEF,
+entropy coding, bitstream packing on the GPU -> complete OBU bitstream on the host.
+
+Multi-GPU (torchrun, one rank per GPU): scene-chunks are independent, every
+rank encodes its own chunk (seed 1080 + rank), no data-path collective; weak scaling.  The only
+collectives are the timing barrier and the MAX over ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "av1-base_amd"))
+
+
+def make_clip(w, h, bd, n, seed):
+    """synthclip v1 frames as one I420 byte string (generated with the oracle's generator: test
+    infrastructure used only to SYNTHESISE INPUT, never in the measured path)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import av1o
+    dt = np.uint8 if bd == 8 else np.dtype("<u2")
+    out = []
+    for t in range(n):
+        fr = av1o.synthclip_frame(w, h, bd, seed=seed, t=t)
+        out.append(b"".join(p.astype(dt).tobytes() for p in fr))
+    return b"".join(out)
+
+
+def _cpu_worker(args):
+    w, h, bd, bs, seed, t0, cnt = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import av1o
+    cfg = av1o.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs)
+    frames = [av1o.synthclip_frame(w, h, bd, seed=seed, t=t0 + i) for i in range(cnt)]
+    t = time.perf_counter()
+    nbytes = 0
+    for fr in frames:
+        tu, _, _ = av1o.encode_frame(cfg, fr)
+        nbytes += len(tu)
+    return time.perf_counter() - t, nbytes
+
+
+def cpu_baseline(w, h, bd, bs, budget_s=20.0):
+    """The CPU oracle (kind 'port': same algorithm, plain C, one process per host core) on a
+    bounded sample of the same workload."""
+    import multiprocessing as mp
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    # one calibration frame on one core
+    t1, _ = _cpu_worker((w, h, bd, bs, 1080, 0, 1))
+    per_core = max(1, min(4, int(budget_s / max(t1, 1e-3))))
+    jobs = [(w, h, bd, bs, 1080, c * per_core, per_core) for c in range(cores)]
+    t = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t
+    frames = cores * per_core
+    return {"value": round(frames / wall, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same 1080p synthclip chunk, %d per core, oracle (plain C restatement), single-frame %.2f s" % (
+                frames, per_core, t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=60)
+    ap.add_argument("--bit-depth", type=int, default=10)
+    ap.add_argument("--block-log2", type=int, default=5)
+    ap.add_argument("--static-cdf", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    import av1mi
+    dev = torch.device("cuda", local_rank)
+    w, h, bd, n = args.width, args.height, args.bit_depth, args.frames
+    clip = make_clip(w, h, bd, n, 1080 + rank)
+    d_frames = torch.frombuffer(bytearray(clip), dtype=torch.uint8).to(dev)  # HBM-resident input
+    torch.cuda.synchronize(dev)
+    params = av1mi.default_params(w, h, bd, block_log2=args.block_log2, cdf_update=0 if args.static_cdf else 1)
+    ctx = av1mi.Context(local_rank)
+
+    def step():
+        return ctx.encode_chunk(params, d_frames.data_ptr(), n, on_device=True)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    stage = {"recon": 0.0, "cdef": 0.0, "entropy": 0.0, "pack": 0.0, "d2h": 0.0}
+    last = None
+    for _ in range(args.steps):
+        data, sizes, rep, _ = step()
+        last = (data, rep)
+        stage["recon"] += rep.ms_recon; stage["cdef"] += rep.ms_cdef; stage["entropy"] += rep.ms_entropy
+        stage["pack"] += rep.ms_pack; stage["d2h"] += rep.ms_d2h
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        data, rep = last
+        k = args.steps
+        bps = 2 if bd > 8 else 1
+        N = w * h * 3 // 2  # samples per frame
+        for s in stage:
+            stage[s] /= k
+        # algorithmic HBM bytes per launch of each kernel
+        alg = {"recon": n * N * (2 * bps + 2),           # source read + reconstruction write + int16 levels write
+               "cdef": n * N * 2 * bps,                  # reconstruction read + filtered write
+               "entropy": n * N * 2 + len(data)}         # levels read + bitstream write
+        dom = max(("recon", "cdef", "entropy"), key=lambda s: stage[s])
+        achieved = alg[dom] / (stage[dom] * 1e-3) / 1e9
+        peak = 8000.0
+        out = {
+            "metric": "encoded frames/sec at CQ=30 (1080p intra-only)", "value": round(world * n * k / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(elapsed / k * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "config": {"workload": "%dx%d %d-frame all-key-frame synthclip v1 chunk per GPU, %d-bit 4:2:0, CQ=30 (base_q_idx 120), "
+                                   "%dx%d blocks, 64x64 tiles, %s CDFs, CDEF on" % (w, h, n, bd, 1 << args.block_log2, 1 << args.block_log2,
+                                                                                    "static" if args.static_cdf else "adaptive"),
+                       "frames_per_chunk": n, "chunks_per_gpu": 1, "parallelism": "chunk-per-gpu x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+                         "frac": round(achieved / peak, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage[dom], 3)},
+            "stage_ms": {s: round(v, 3) for s, v in stage.items()},
+            "bytes_per_frame": round(len(data) / n, 1),
+            "psnr_db": [round(rep.psnr[i], 2) for i in range(3)],
+            "symbols_per_frame": int(rep.n_symbols // n),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, h, bd, args.block_log2)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
