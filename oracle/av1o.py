@@ -62,6 +62,12 @@ def lib():
         L.av1o_default_scan.argtypes = [C.c_int]
         L.av1o_predict_intra.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int]
+        L.av1o_cdef_frame.argtypes = [C.POINTER(Config), C.POINTER(Frame), C.POINTER(Frame), C.c_void_p, C.c_int, C.c_void_p]
+        L.av1o_ec_init.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.av1o_ec_encode_symbol.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.av1o_ec_encode_literal.argtypes = [C.c_void_p, C.c_uint, C.c_int]
+        L.av1o_ec_finish.argtypes = [C.c_void_p]
+        L.av1o_ec_finish.restype = C.c_size_t
         _lib = L
     return _lib
 

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("av1-base_amd", "oracle", "tools"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import av1o
+    av1o.build()
+    return av1o
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    import json
+    gdir = os.path.join(ROOT, "tests", "golden")
+    out = []
+    for name in json.load(open(os.path.join(gdir, "index.json"))):
+        meta = json.load(open(os.path.join(gdir, name + ".json")))
+        meta["obu"] = open(os.path.join(gdir, name + ".obu"), "rb").read()
+        out.append(meta)
+    return out

@@ -1,0 +1,172 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the dav1d-pinned
+golden fixtures.  Bit-exact is the bar: identical bitstreams and identical reconstructions."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def av1mi():
+    import av1mi as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(av1mi):
+    c = av1mi.Context(0)
+    yield c
+    c.close()
+
+
+def raw_of(planes, bd):
+    dt = np.uint8 if bd == 8 else np.dtype("<u2")
+    return b"".join(p.astype(dt).tobytes() for p in planes)
+
+
+def sha(planes):
+    h = hashlib.sha256()
+    for p in planes:
+        h.update(np.ascontiguousarray(p.astype("<u2")).tobytes())
+    return h.hexdigest()
+
+
+def split_planes(raw, w, h, bd):
+    dt = np.uint8 if bd == 8 else np.dtype("<u2")
+    a = np.frombuffer(raw, dtype=dt)
+    y = a[:w * h].reshape(h, w)
+    u = a[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)
+    v = a[w * h + w * h // 4:].reshape(h // 2, w // 2)
+    return [y, u, v]
+
+
+def test_extension_is_the_hip_library(av1mi):
+    assert os.path.basename(av1mi.LIB_PATH) == "libav1mi.so"
+    import torch
+    assert torch.cuda.is_available()
+
+
+def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
+    """Every fixture the GPU path can express (one-superblock tiles, 8..32 blocks, decision-driven
+    modes): same bytes as the committed stream, reconstruction hash == dav1d's."""
+    n = 0
+    for m in golden_cases:
+        cfgk = dict(m["config"])
+        bs = cfgk.pop("min_bs_log2", 4)
+        cfgk.pop("max_bs_log2", None)
+        if bs > 5 or any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("base_q_idx", 120) != 120:
+            continue
+        p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs,
+                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_cdef=cfgk.get("enable_cdef", 1))
+        for k in ("cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping"):
+            if k in cfgk:
+                setattr(p, k, cfgk[k])
+        src = oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=m["t"])
+        data, sizes, rep, recon = ctx.encode_chunk(p, raw_of(src, m["bit_depth"]), 1, want_recon=True)
+        assert data == m["obu"], m["name"]
+        assert sha(split_planes(recon.tobytes(), m["width"], m["height"], m["bit_depth"])) == m["dav1d_sha256"], m["name"]
+        n += 1
+    assert n >= 10
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,cdf", [
+    (64, 64, 8, 1, 5, 1), (64, 64, 10, 3, 4, 1), (8, 8, 8, 2, 5, 1), (72, 56, 8, 2, 3, 1), (200, 120, 8, 4, 5, 0),
+    (328, 248, 10, 2, 5, 1), (136, 136, 8, 3, 4, 1), (640, 360, 8, 2, 5, 1)])
+def test_chunk_bitstream_and_recon_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, cdf):
+    frames = [oracle.synthclip_frame(w, h, bd, seed=1000 + w, t=t, scene_len=2) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, cdf_update=cdf)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, disable_cdf_update=0 if cdf else 1)
+    ref, refrec, sse, nsym = b"", b"", [0, 0, 0], 0
+    for i, f in enumerate(frames):
+        tu, rec, st = oracle.encode_frame(cfg, f)
+        assert sizes[i] == len(tu)
+        ref += tu
+        refrec += raw_of(rec, bd)
+        nsym += st.n_symbols
+        for k in range(3):
+            sse[k] += st.sse[k]
+    assert data == ref
+    assert recon.tobytes() == refrec
+    assert [int(x) for x in rep.sse] == sse          # SSE kernel vs oracle, exact integers
+    assert rep.n_symbols == nsym and rep.frames == n and rep.bytes == len(ref)
+
+
+def test_edge_cases_flat_and_extreme_inputs(av1mi, ctx, oracle):
+    """all-skip (flat mid-grey), saturated black/white, and a checkerboard at full amplitude"""
+    w, h = 136, 72
+    cases = []
+    for val in (128, 0, 255):
+        cases.append([np.full((h, w), val, np.uint16), np.full((h // 2, w // 2), val, np.uint16), np.full((h // 2, w // 2), val, np.uint16)])
+    yy, xx = np.mgrid[0:h, 0:w]
+    cb = (((yy // 4 + xx // 4) & 1) * 255).astype(np.uint16)
+    cases.append([cb, cb[::2, ::2].copy(), 255 - cb[::2, ::2]])
+    p = av1mi.default_params(w, h, 8, block_log2=4)
+    cfg = oracle.default_config(w, h, 8, min_bs_log2=4, max_bs_log2=4)
+    for planes in cases:
+        data, sizes, rep, recon = ctx.encode_chunk(p, raw_of(planes, 8), 1, want_recon=True)
+        tu, rec, st = oracle.encode_frame(cfg, planes)
+        assert data == tu and recon.tobytes() == raw_of(rec, 8)
+
+
+def test_full_size_properties_1080p(av1mi, ctx, oracle):
+    """At BASELINE's full frame size the oracle is still used for one frame (seconds), plus
+    size-independent properties on a 6-frame chunk: per-frame independence (chunk == concatenation of
+    single-frame encodes), determinism, and the checksum of the frame sizes."""
+    w, h, bd = 1920, 1080, 10
+    frames = [oracle.synthclip_frame(w, h, bd, seed=1080, t=t) for t in range(6)]
+    raws = [raw_of(f, bd) for f in frames]
+    p = av1mi.default_params(w, h, bd)
+    data, sizes, rep, _ = ctx.encode_chunk(p, b"".join(raws), 6)
+    data2, sizes2, _, _ = ctx.encode_chunk(p, b"".join(raws), 6)
+    assert data == data2 and sizes == sizes2 and sum(sizes) == len(data)
+    off = 0
+    for i in (0, 5):
+        one, s1, _, _ = ctx.encode_chunk(p, raws[i], 1)
+        start = sum(sizes[:i])
+        assert data[start:start + sizes[i]] == one
+    tu, rec, st = oracle.encode_frame(oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5), frames[0])
+    assert data[:sizes[0]] == tu
+    assert 33.0 < rep.psnr[0] < 37.0
+
+
+def test_device_resident_input_matches_host_input(av1mi, ctx, oracle):
+    import torch
+    w, h, bd, n = 200, 120, 8, 3
+    raw = b"".join(raw_of(oracle.synthclip_frame(w, h, bd, seed=5, t=t), bd) for t in range(n))
+    p = av1mi.default_params(w, h, bd)
+    a = ctx.encode_chunk(p, raw, n)[0]
+    d = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    b = ctx.encode_chunk(p, d.data_ptr(), n, on_device=True)[0]
+    assert a == b
+
+
+def test_encode_file_y4m_to_ivf(av1mi, oracle, tmp_path):
+    """The run_av1an drop-in: Y4M in, IVF out (atomic), frames in order across chunk boundaries."""
+    w, h, n = 136, 72, 7
+    frames = [oracle.synthclip_frame(w, h, 8, seed=77, t=t) for t in range(n)]
+    y4m = tmp_path / "clip.y4m"
+    with open(y4m, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h))
+        for fr in frames:
+            f.write(b"FRAME\n" + raw_of(fr, 8))
+    out = tmp_path / "clip.ivf"
+    seen = []
+    rep = av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, tmp_path, av1mi.derive_plan(8), chunk_frames=3),
+                           progress=lambda d, t, fps, b: seen.append(d))
+    blob = out.read_bytes()
+    assert blob[:4] == b"DKIF" and blob[8:12] == b"AV01" and int.from_bytes(blob[24:28], "little") == n
+    cfg = oracle.default_config(w, h, 8, min_bs_log2=5, max_bs_log2=5)
+    pos = 32
+    for i, fr in enumerate(frames):
+        sz = int.from_bytes(blob[pos:pos + 4], "little")
+        assert int.from_bytes(blob[pos + 4:pos + 12], "little") == i
+        tu, _, _ = oracle.encode_frame(cfg, fr)
+        assert blob[pos + 12:pos + 12 + sz] == tu
+        pos += 12 + sz
+    assert pos == len(blob) and rep.frames == n and seen and seen[-1] == n
+    assert not list(tmp_path.glob("*.tmp*"))

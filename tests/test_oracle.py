@@ -1,0 +1,292 @@
+"""CPU tests of the oracle (the checker) itself: golden fixtures pinned by dav1d, known-answer
+tests of the building blocks, size-independent properties.  None of this needs a GPU."""
+import ctypes as C
+import hashlib
+import math
+
+import numpy as np
+import pytest
+
+
+def sha(planes):
+    h = hashlib.sha256()
+    for p in planes:
+        h.update(np.ascontiguousarray(p.astype("<u2")).tobytes())
+    return h.hexdigest()
+
+
+def test_golden_streams_and_dav1d_reconstruction(oracle, golden_cases):
+    """The oracle must reproduce every committed stream byte for byte, and its reconstruction
+    must equal what dav1d 1.5.3 decoded from that stream (hash recorded by tools/make_golden.py)."""
+    assert len(golden_cases) >= 20
+    for m in golden_cases:
+        src = oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=m["t"])
+        assert sha(src) == m["src_sha256"], m["name"]
+        cfg = oracle.default_config(m["width"], m["height"], m["bit_depth"], **m["config"])
+        tu, rec, st = oracle.encode_frame(cfg, src)
+        assert tu == m["obu"], "stream differs for " + m["name"]
+        assert sha(rec) == m["dav1d_sha256"], "reconstruction differs from dav1d for " + m["name"]
+
+
+def test_header_kat(oracle):
+    """Sequence header of a 64x64 8-bit stream, hand-checked against the field order the survey
+    verified on a libaom stream: OBU type 1, profile 0, level 31, 6/6 size bits."""
+    cfg = oracle.default_config(64, 64, 8)
+    src = oracle.synthclip_frame(64, 64, 8, seed=1, t=0)
+    tu, _, _ = oracle.encode_frame(cfg, src)
+    assert tu[:2] == bytes([0x12, 0x00])                 # temporal delimiter
+    assert tu[2] == 0x0A and tu[3] == 10                  # sequence header OBU, 10 payload bytes
+    payload = tu[4:14]
+    bits = "".join("{:08b}".format(b) for b in payload)
+    assert bits[0:3] == "000" and bits[3] == "0" and bits[4] == "0"      # profile, still, reduced
+    assert bits[24:29] == "11111" and bits[29] == "0"                   # seq_level_idx 31, tier 0
+    assert int(bits[30:34], 2) == 5 and int(bits[34:38], 2) == 5         # width/height bits - 1
+    assert int(bits[38:44], 2) == 63 and int(bits[44:50], 2) == 63       # 64x64
+    assert tu[14] == 0x32                                               # OBU_FRAME
+
+
+def test_range_coder_roundtrip_against_spec_decoder(oracle):
+    """Encode a random symbol sequence with adaptive CDFs, decode it with a straight restatement of
+    the spec's symbol decoder (§8.2.2 init_symbol, §8.2.6 read_symbol) and compare."""
+    L = oracle.lib()
+
+    class RE(C.Structure):
+        _fields_ = [("low", C.c_uint32), ("rng", C.c_uint32), ("cnt", C.c_int), ("buf", C.c_void_p), ("cap", C.c_size_t),
+                    ("offs", C.c_size_t), ("error", C.c_int), ("nsym", C.c_uint64)]
+    rng = np.random.default_rng(5)
+    nsyms_list = [2, 3, 4, 5, 7, 13, 16]
+    cdfs_enc, cdfs_dec = [], []
+    for n in nsyms_list:
+        cuts = np.sort(rng.choice(np.arange(1, 32767), n - 1, replace=False))
+        icdf = [int(32768 - c) for c in cuts] + [0, 0]
+        cdfs_enc.append((C.c_uint16 * (n + 1))(*icdf))
+        cdfs_dec.append([int(c) for c in cuts] + [32768, 0])
+    buf = C.create_string_buffer(1 << 16)
+    e = RE()
+    L.av1o_ec_init(C.byref(e), buf, len(buf))
+    seq = []
+    for _ in range(4000):
+        k = int(rng.integers(len(nsyms_list)))
+        n = nsyms_list[k]
+        s = int(rng.integers(n)) if rng.random() < 0.5 else int(min(n - 1, rng.geometric(0.6) - 1))
+        seq.append((k, s))
+        L.av1o_ec_encode_symbol(C.byref(e), s, cdfs_enc[k], n)
+        if rng.random() < 0.1:
+            b = int(rng.integers(2))
+            seq.append((-1, b))
+            L.av1o_ec_encode_literal(C.byref(e), b, 1)
+    L.av1o_ec_finish.restype = C.c_size_t
+    nbytes = L.av1o_ec_finish(C.byref(e))
+    data = buf.raw[:nbytes]
+
+    # ---- spec decoder
+    class Dec:
+        def __init__(self, data):
+            self.bits = "".join("{:08b}".format(b) for b in data)
+            self.pos = 0
+            sz = len(data)
+            nb = min(sz * 8, 15)
+            v = self.f(nb)
+            self.value = ((1 << 15) - 1) ^ (v << (15 - nb))
+            self.range = 1 << 15
+            self.maxbits = 8 * sz - 15
+
+        def f(self, n):
+            v = int(self.bits[self.pos:self.pos + n], 2) if n else 0
+            self.pos += n
+            return v
+
+        def read(self, cdf, adapt=True):
+            N = len(cdf) - 1
+            cur = self.range
+            sym = -1
+            while True:
+                sym += 1
+                prev = cur
+                f = (1 << 15) - cdf[sym]
+                cur = ((self.range >> 8) * (f >> 6) >> 1) + 4 * (N - sym - 1)
+                if not self.value < cur:
+                    break
+            self.range = prev - cur
+            self.value -= cur
+            bits = 15 - (self.range.bit_length() - 1)
+            self.range <<= bits
+            nb = min(bits, max(0, self.maxbits))
+            new = self.f(nb)
+            self.value = (new << (bits - nb)) ^ (((self.value + 1) << bits) - 1)
+            self.maxbits -= bits
+            if adapt:
+                rate = 3 + (cdf[N] > 15) + (cdf[N] > 31) + min(int(math.log2(N)), 2)
+                tmp = 0
+                for i in range(N - 1):
+                    tmp = (1 << 15) if i == sym else tmp
+                    if tmp < cdf[i]:
+                        cdf[i] -= (cdf[i] - tmp) >> rate
+                    else:
+                        cdf[i] += (tmp - cdf[i]) >> rate
+                cdf[N] += cdf[N] < 32
+            return sym
+
+    d = Dec(data)
+    for k, s in seq:
+        if k < 0:
+            assert d.read([1 << 14, 1 << 15, 0], adapt=False) == s
+        else:
+            assert d.read(cdfs_dec[k]) == s
+
+
+@pytest.mark.parametrize("log2n", [2, 3, 4, 5, 6])
+def test_transforms_vs_real_dct(oracle, log2n):
+    """Forward transform = scale * orthonormal 2-D DCT-II within a small integer error; inverse
+    (normative network) inverts it.  scipy is the independent reference."""
+    from scipy.fft import dctn
+    L = oracle.lib()
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n)
+    scale = {2: 8, 3: 8, 4: 8, 5: 4, 6: 2}[log2n]
+    for _ in range(5):
+        x = rng.integers(-255, 256, (n, n)).astype(np.int32)
+        co = np.zeros((n, n), np.int32)
+        L.av1o_fwd_txfm2d(x.ctypes.data, n, co.ctypes.data, log2n, 0, 8)
+        ref = dctn(x.astype(float), norm="ortho") * scale
+        m = min(n, 32)
+        assert np.abs(co[:m, :m] - ref[:m, :m]).max() < 6.0  # integer butterflies: documented bound
+        if n == 64:
+            assert not co[32:, :].any() and not co[:, 32:].any()
+        # inverse of the (unquantised) coefficients returns the residual up to rounding
+        if n <= 32:
+            back = np.zeros((n, n), np.int32)
+            L.av1o_inv_txfm2d(co.ctypes.data, back.ctypes.data, log2n, 0, 8)
+            assert np.abs(back - x).max() <= 2
+
+
+@pytest.mark.parametrize("log2n,tx_type", [(2, 1), (2, 2), (2, 3), (3, 1), (3, 3), (4, 2), (4, 3)])
+def test_adst_roundtrip(oracle, log2n, tx_type):
+    L = oracle.lib()
+    n = 1 << log2n
+    rng = np.random.default_rng(10 * log2n + tx_type)
+    x = rng.integers(-255, 256, (n, n)).astype(np.int32)
+    co = np.zeros((n, n), np.int32)
+    back = np.zeros((n, n), np.int32)
+    L.av1o_fwd_txfm2d(x.ctypes.data, n, co.ctypes.data, log2n, tx_type, 8)
+    L.av1o_inv_txfm2d(co.ctypes.data, back.ctypes.data, log2n, tx_type, 8)
+    assert np.abs(back - x).max() <= 2
+
+
+def test_dc_only_coefficient_gives_flat_block(oracle):
+    L = oracle.lib()
+    for log2n in (2, 3, 4, 5, 6):
+        n = 1 << log2n
+        dq = np.zeros((n, n), np.int32)
+        dq[0, 0] = 800
+        out = np.zeros((n, n), np.int32)
+        L.av1o_inv_txfm2d(dq.ctypes.data, out.ctypes.data, log2n, 0, 8)
+        assert out.min() == out.max() != 0
+
+
+def test_scan_is_a_zigzag_permutation(oracle):
+    L = oracle.lib()
+    for log2n in (2, 3, 4, 5):
+        n = 1 << log2n
+        s = np.ctypeslib.as_array(L.av1o_default_scan(log2n), shape=(n * n,)).astype(int)
+        assert sorted(s.tolist()) == list(range(n * n))
+        d = s // n + s % n
+        assert (np.diff(d) >= 0).all()          # anti-diagonal by anti-diagonal
+        assert s[0] == 0 and s[1] == 1 and s[2] == n   # first step along the row (pinned by dav1d)
+
+
+def test_intra_predictors_known_answers(oracle):
+    L = oracle.lib()
+    n, log2n = 8, 3
+    above = (np.arange(2 * n + 1) * 3 + 10).astype(np.uint16)   # element 0 = above[-1]
+    left = (np.arange(2 * n + 1) * 5 + 20).astype(np.uint16)
+    left[0] = above[0]
+    out = np.zeros((n, n), np.uint16)
+
+    def pred(mode, delta=0, ha=1, hl=1):
+        L.av1o_predict_intra(out.ctypes.data, n, log2n, mode, delta, above.ctypes.data, left.ctypes.data, ha, hl, 8)
+        return out.copy()
+    v = pred(1)
+    assert (v == above[1:n + 1][None, :]).all()
+    h = pred(2)
+    assert (h == left[1:n + 1][:, None]).all()
+    dc = pred(0)
+    assert (dc == (int(above[1:n + 1].sum()) + int(left[1:n + 1].sum()) + n) // (2 * n)).all()
+    assert (pred(0, ha=0, hl=0) == 128).all()
+    # constant edges: every mode predicts that constant
+    above[:] = 77
+    left[:] = 77
+    for mode in range(13):
+        assert (pred(mode) == 77).all(), mode
+    # D45 reads only the above row; D203 only the left column
+    above[:] = (np.arange(2 * n + 1) * 3 + 10).astype(np.uint16)
+    left[:] = 0
+    left[0] = above[0]
+    d45 = pred(3)
+    assert d45[0, 0] == (int(above[2]) * 32 + int(above[3]) * 0 + 16) >> 5 or d45[0, 0] > 0
+    left[:] = (np.arange(2 * n + 1) * 5 + 20).astype(np.uint16)
+    a2 = above.copy()
+    above[1:] = 0
+    assert (pred(7) > 0).all()   # D203 ignores the (zeroed) above row
+    above[:] = a2
+
+
+def test_cdef_leaves_flat_frames_and_skipped_blocks_alone(oracle):
+    """An all-skip frame is returned untouched; flat input is a fixed point of the CDEF filter even
+    at maximum strength (constrain(0) = 0)."""
+    w = h = 64
+    flat = [np.full((h, w), 128, np.uint16), np.full((h // 2, w // 2), 128, np.uint16), np.full((h // 2, w // 2), 128, np.uint16)]
+    cfg = oracle.default_config(w, h, 8, min_bs_log2=4, max_bs_log2=4, cdef_y_pri=15, cdef_y_sec=3, cdef_uv_pri=15, cdef_uv_sec=3)
+    tu, rec, st = oracle.encode_frame(cfg, flat)
+    assert st.n_skip_blocks == st.n_blocks == 16
+    for p in range(3):
+        assert (rec[p] == 128).all()
+    # direct filter call on a flat, non-skipped frame
+    L = oracle.lib()
+    fin = oracle._planes_to_frame([np.full((h, w), 90, np.uint16), np.full((h // 2, w // 2), 100, np.uint16), np.full((h // 2, w // 2), 110, np.uint16)])
+    fout = L.av1o_frame_alloc(w, h)
+    skip = np.zeros((h // 4, w // 4), np.uint8)
+    idx = np.zeros(1, np.int8)
+    L.av1o_cdef_frame(C.byref(cfg), fin, fout, skip.ctypes.data, w // 4, idx.ctypes.data)
+    out = oracle._frame_to_planes(fout)
+    assert (out[0] == 90).all() and (out[1] == 100).all() and (out[2] == 110).all()
+    # a vertical edge keeps its direction: filtering must not move the edge position
+    y = np.full((h, w), 60, np.uint16)
+    y[:, 32:] = 200
+    fin2 = oracle._planes_to_frame([y, np.full((h // 2, w // 2), 128, np.uint16), np.full((h // 2, w // 2), 128, np.uint16)])
+    L.av1o_cdef_frame(C.byref(cfg), fin2, fout, skip.ctypes.data, w // 4, idx.ctypes.data)
+    out = oracle._frame_to_planes(fout)
+    assert (out[0][:, :31] == 60).all() and (out[0][:, 33:] == 200).all()
+
+
+def test_properties_linearity_of_sse_and_determinism(oracle):
+    src = oracle.synthclip_frame(136, 72, 8, seed=3, t=1)
+    cfg = oracle.default_config(136, 72, 8, min_bs_log2=5, max_bs_log2=5)
+    a = oracle.encode_frame(cfg, src)
+    b = oracle.encode_frame(cfg, src)
+    assert a[0] == b[0]
+    for p in range(3):
+        assert (a[1][p] == b[1][p]).all()
+        d = a[1][p].astype(np.int64) - src[p].astype(np.int64)
+        assert int((d * d).sum()) == a[2].sse[p]
+    # coarser quantiser -> fewer bytes, lower PSNR
+    lo = oracle.encode_frame(oracle.default_config(136, 72, 8, min_bs_log2=5, max_bs_log2=5, base_q_idx=60), src)
+    hi = oracle.encode_frame(oracle.default_config(136, 72, 8, min_bs_log2=5, max_bs_log2=5, base_q_idx=200), src)
+    assert len(lo[0]) > len(a[0]) > len(hi[0])
+    assert lo[2].sse[0] < a[2].sse[0] < hi[2].sse[0]
+
+
+def test_rejects_bad_geometry(oracle):
+    with pytest.raises(RuntimeError):
+        oracle.encode_frame(oracle.default_config(60, 64, 8), [np.zeros((64, 60), np.uint16), np.zeros((32, 30), np.uint16), np.zeros((32, 30), np.uint16)])
+
+
+def test_synthclip_scene_cut_and_motion(oracle):
+    a = oracle.synthclip_frame(128, 64, 8, seed=9, t=0, scene_len=4)
+    b = oracle.synthclip_frame(128, 64, 8, seed=9, t=3, scene_len=4)
+    c = oracle.synthclip_frame(128, 64, 8, seed=9, t=4, scene_len=4)   # new scene
+    d = oracle.synthclip_frame(128, 64, 8, seed=10, t=0, scene_len=4)  # == scene 1 of seed 9
+    assert not (a[0] == b[0]).all()
+    assert (c[0] == d[0]).all()
+    ten = oracle.synthclip_frame(128, 64, 10, seed=9, t=0)
+    assert ten[0].max() > 255 and ten[0].max() <= 1023

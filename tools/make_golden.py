@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the build container; needs Pillow's
+libavif = dav1d 1.5.3).
+
+For every case: the oracle encodes a seeded synthclip frame, dav1d decodes the resulting OBU
+stream, and the script REQUIRES dav1d's planes to equal the oracle's reconstruction bit for bit
+before writing
+    <case>.obu        the temporal unit (what both the oracle and the HIP path must reproduce)
+    <case>.json       parameters + SHA-256 of dav1d's decoded Y/U/V planes + stats
+This is the pin of the oracle's normative half (headers, symbol coder, default CDFs, contexts,
+dequantiser, inverse DCT/ADST 4..64, intra predictors, CDEF): see oracle/av1o.h "PARITY PIN".
+The reference (av1-base) holds no fixtures for this path, so these are the
+golden vectors; inputs are regenerated from the seed, outputs are data, no reference source.
+"""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import av1o
+import oracle_avif
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# name, width, height, bit_depth, seed, t, config overrides
+CASES = [
+    ("k64_bs5", 64, 64, 8, 7, 0, dict(min_bs_log2=5, max_bs_log2=5)),
+    ("k64_bs4", 64, 64, 8, 7, 0, dict(min_bs_log2=4, max_bs_log2=4)),
+    ("k64_bs3", 64, 64, 8, 7, 0, dict(min_bs_log2=3, max_bs_log2=3)),
+    ("k64_bs6", 64, 64, 8, 7, 0, dict(min_bs_log2=6, max_bs_log2=6)),
+    ("k200x120_bs5", 200, 120, 8, 1080, 0, dict(min_bs_log2=5, max_bs_log2=5)),
+    ("k200x120_bs4", 200, 120, 8, 1080, 1, dict(min_bs_log2=4, max_bs_log2=4)),
+    ("k200x120_bs3", 200, 120, 8, 1080, 2, dict(min_bs_log2=3, max_bs_log2=3)),
+    ("k200x120_bs5_10b", 200, 120, 10, 1080, 0, dict(min_bs_log2=5, max_bs_log2=5)),
+    ("k200x120_bs4_10b", 200, 120, 10, 1080, 1, dict(min_bs_log2=4, max_bs_log2=4)),
+    ("k200x120_static", 200, 120, 8, 1080, 0, dict(min_bs_log2=5, max_bs_log2=5, disable_cdf_update=1)),
+    ("k200x120_nocdef", 200, 120, 8, 1080, 0, dict(min_bs_log2=5, max_bs_log2=5, enable_cdef=0)),
+    ("k200x120_cdef_strong", 200, 120, 8, 1080, 0, dict(min_bs_log2=4, max_bs_log2=4, cdef_y_pri=7, cdef_y_sec=3, cdef_uv_pri=4, cdef_uv_sec=2, cdef_damping=3)),
+    ("k328x248_tiles2x1", 328, 248, 8, 3, 2, dict(min_bs_log2=4, max_bs_log2=4, tile_w_sb=2, tile_h_sb=1)),
+    ("k136_onetile", 136, 136, 8, 3, 2, dict(min_bs_log2=5, max_bs_log2=5, tile_w_sb=64, tile_h_sb=64)),
+    ("k72x56_q60", 72, 56, 8, 11, 0, dict(min_bs_log2=4, max_bs_log2=4, base_q_idx=60)),
+    ("k72x56_q200", 72, 56, 10, 11, 0, dict(min_bs_log2=5, max_bs_log2=5, base_q_idx=200)),
+    ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
+    ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
+    ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
+    ("fuzz_both_bs6", 136, 136, 8, 24, 0, dict(min_bs_log2=6, max_bs_log2=6, fuzz_coeffs=24, fuzz_modes=124, fuzz_density=8, fuzz_maxlevel=40)),
+]
+
+
+def sha(planes):
+    h = hashlib.sha256()
+    for p in planes:
+        h.update(np.ascontiguousarray(p.astype("<u2")).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    index = []
+    for name, w, h, bd, seed, t, kw in CASES:
+        src = av1o.synthclip_frame(w, h, bd, seed=seed, t=t)
+        cfg = av1o.default_config(w, h, bd, **kw)
+        tu, rec, st = av1o.encode_frame(cfg, src)
+        dec = oracle_avif.decode_obus(tu, w, h, bd)
+        for p in range(3):
+            if not (dec[p].astype(np.uint16) == rec[p]).all():
+                raise SystemExit("%s: dav1d output differs from the oracle reconstruction in plane %d" % (name, p))
+        open(os.path.join(OUT, name + ".obu"), "wb").write(tu)
+        meta = dict(name=name, width=w, height=h, bit_depth=bd, seed=seed, t=t, config=kw, bytes=len(tu),
+                    dav1d_sha256=sha(dec), src_sha256=sha(src), n_symbols=int(st.n_symbols),
+                    psnr=[round(x, 3) for x in av1o.psnr(st, cfg)], decoder="dav1d 1.5.3 via libavif 1.4.1 (Pillow 12.2.0)")
+        json.dump(meta, open(os.path.join(OUT, name + ".json"), "w"), indent=1, sort_keys=True)
+        index.append(name)
+        print("%-24s %6d B  psnr %s  dav1d == oracle recon" % (name, len(tu), meta["psnr"]))
+    json.dump(index, open(os.path.join(OUT, "index.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
