@@ -19,6 +19,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "libav1mi.so")
 
+# PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in
+# one process do not coexist, so when torch is installed it is imported FIRST: libav1mi.so's
+# DT_NEEDED libamdhip64.so.7 then binds to the runtime already in the process.  A non-Python host
+# (the daemon through its FFI) has only /opt/rocm's runtime and needs none of this.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 if not os.path.exists(LIB_PATH):
     raise ImportError("libav1mi.so not built (run __graft_entry__.build() or av1-base_amd/build.py): %s" % LIB_PATH)
 _lib = C.CDLL(os.path.abspath(LIB_PATH))
