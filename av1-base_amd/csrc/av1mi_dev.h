@@ -25,6 +25,7 @@ struct Av1miDevParams {
   long frame_samples;             // samples per frame
   // per-tile bitstream slot
   int tile_slot_bytes;
+  int stream_cap;                 // 32-bit symbol-stream entries per tile (multiple of 4)
   // header blob (identical for every frame): sequence header OBU + frame header payload
   int seq_hdr_bytes, frame_hdr_bytes;
   int tile_size_bytes;

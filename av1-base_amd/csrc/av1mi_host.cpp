@@ -27,7 +27,8 @@
 extern "C" {
 hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
-                                uint8_t *slots, uint32_t *tile_bytes, uint32_t *sym_count, hipStream_t s);
+                                uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
+                                hipStream_t s, hipEvent_t mid);
 hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t s);
 hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
 hipError_t av1mi_launch_pack(const Av1miDevParams *P, const uint8_t *slots, const uint32_t *tile_bytes, uint32_t *tile_off,
@@ -248,7 +249,7 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
 struct av1mi_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[9] = {};
   std::string err;
   // workspace (device)
   size_t cap_frames = 0;
@@ -259,6 +260,7 @@ struct av1mi_ctx {
   uint8_t *d_slots = nullptr, *d_out = nullptr, *d_hdr = nullptr;
   uint16_t *d_cdf = nullptr;
   uint32_t *d_tile_bytes = nullptr, *d_tile_off = nullptr, *d_frame_size = nullptr, *d_payload = nullptr, *d_sym = nullptr;
+  uint32_t *d_streams = nullptr, *d_combos = nullptr;
   unsigned long long *d_frame_off = nullptr, *d_sse = nullptr;
   int *d_overflow = nullptr;
   size_t out_cap = 0;
@@ -290,11 +292,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -307,6 +309,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   const size_t frame_samples = (size_t)p.width * p.height * 3 / 2;
   const size_t nsb = (size_t)r.sb_cols * r.sb_rows;
   const int slot = bps == 1 ? 8192 : 16384;
+  const int stream_cap = 16384;
   if (!same) {
     free_workspace(c);
     const size_t nf = n_frames;
@@ -325,6 +328,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_tile_bytes, nf * nsb * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_tile_off, nf * nsb * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_sym, nf * nsb * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_combos, nf * nsb * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_streams, nf * nsb * (size_t)stream_cap * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_frame_size, nf * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_payload, nf * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_frame_off, (nf + 1) * 8));
@@ -357,6 +362,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.plane_off_v = P.plane_off_u + (long)(p.width / 2) * (p.height / 2);
   P.frame_samples = (long)frame_samples;
   P.tile_slot_bytes = slot;
+  P.stream_cap = stream_cap;
   P.tile_size_bytes = 4;
   return AV1MI_OK;
 }
@@ -457,7 +463,7 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
   HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s));
   HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s));
   HIPCHK(c, hipEventRecord(c->ev[3], s));
-  HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_slots, c->d_tile_bytes, c->d_sym, s));
+  HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, s, c->ev[7]));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, av1mi_launch_pack(&P, c->d_slots, c->d_tile_bytes, c->d_tile_off, c->d_frame_size, c->d_payload, c->d_frame_off, c->d_hdr,
                               c->d_out, c->d_overflow, 0, s));
@@ -519,6 +525,7 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
     (void)hipEventElapsedTime(&report->ms_recon, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&report->ms_cdef, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&report->ms_entropy, c->ev[3], c->ev[4]);
+    (void)hipEventElapsedTime(&report->ms_symbolize, c->ev[3], c->ev[7]);
     (void)hipEventElapsedTime(&report->ms_pack, c->ev[4], c->ev[5]);
     (void)hipEventElapsedTime(&report->ms_d2h, c->ev[5], c->ev[6]);
     (void)hipEventElapsedTime(&report->ms_total, c->ev[0], c->ev[6]);

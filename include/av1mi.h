@@ -65,6 +65,7 @@ typedef struct {
   double psnr[3];
   /* device time per stage, milliseconds (HIP events on the encoder's stream) */
   float ms_h2d, ms_recon, ms_cdef, ms_entropy, ms_pack, ms_d2h, ms_total;
+  float ms_symbolize;       /* part of ms_entropy spent in the symbolize kernel */
   uint64_t n_symbols;       /* arithmetic-coded symbols */
 } av1mi_report;
 
