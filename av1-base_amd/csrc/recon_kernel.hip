@@ -41,15 +41,25 @@ __constant__ int16_t c_mode_angle[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 
 // Mode_To_Txfm (spec §6.10.x): 0 DCT_DCT 1 ADST_DCT 2 DCT_ADST 3 ADST_ADST
 __constant__ uint8_t c_mode_txfm[13] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3 };
 
+// LDS per superblock-wave (~9 KB, so ~4 waves fit a SIMD): decoder-style line buffers instead of the
+// whole reconstructed superblock.  above[p][x] = bottom row of the last block reconstructed over column
+// x, left[p][y] = right column of the last block reconstructed over row y, corner[p][y4][x4] = pixel
+// (4*y4-1, 4*x4-1).  Z-order + quadtree alignment guarantee that whenever the decoded-block map says an
+// edge is available these hold exactly the pixels spec §7.11.2 asks for.
 struct SbLds {
-  uint16_t rec_y[64 * 64];   // superblock reconstruction, u16 for 8 and 10 bit
-  uint16_t rec_c[2][32 * 32];
-  int32_t scratch[32 * 33];
+  uint16_t above[3][64];
+  uint16_t left[3][64];
+  uint16_t corner[3][17][17];
+  uint16_t blkpix[32 * 32];     // prediction, then reconstruction, of the current transform block
+  uint16_t srcblk[32 * 32];     // source pixels of the block; reused for the quantised levels
+  int16_t scratch[32 * 33];     // 2-D transform staging (every intermediate fits 16 bits)
   uint16_t edge_a[2 * 64 + 8];  // [0] = element -1
   uint16_t edge_l[2 * 64 + 8];
-  int16_t lvl[32 * 32];
   uint8_t blkdec[2][19][19];    // luma, chroma (U and V decode together)
+  uint8_t smw[64];              // smooth weights of the current block size
 };
+__shared__ SbLds g_sb;
+#define S (&g_sb)
 
 __device__ __forceinline__ int wave_sum(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -66,7 +76,7 @@ __device__ __forceinline__ int clamp_bits(int v, int bits) {
   return v < lo ? lo : (v > hi ? hi : v);
 }
 
-// ---- 1-D transform dispatch (type: 0 DCT, 1 ADST) -------------------------------------------
+// ---- 1-D transforms (type: 0 DCT, 1 ADST) ---------------------------------------------------
 template <int LOG2N> struct Tx1d;
 template <> struct Tx1d<2> {
   static __device__ __forceinline__ void iadst(int32_t *x) {
@@ -111,11 +121,11 @@ __device__ __forceinline__ int scan_index(int row, int col, int n) {
 }
 
 // ---- intra prediction of one pixel (spec §7.11.2, no edge filter / upsampling) -------------------
-// A = &edge_a[1], L = &edge_l[1] (index -1 valid).
+// A = edge_a + 1, L = edge_l + 1 (index -1 valid); dx/dy = Dr_Intra_Derivative values of the mode.
 template <int LOG2N>
-__device__ __forceinline__ int pred_pixel(int mode, int r, int c, const uint16_t *A, const uint16_t *L, int dcval) {
+__device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int ang, int dx, int dy) {
   constexpr int N = 1 << LOG2N;
-  constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
+  const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
   switch (mode) {
     case DC_PRED: return dcval;
     case V_PRED: return A[c];
@@ -127,27 +137,24 @@ __device__ __forceinline__ int pred_pixel(int mode, int r, int c, const uint16_t
       return (pl <= pt && pl <= ptl) ? l : (pt <= ptl ? t : tl);
     }
     case SMOOTH_PRED: {
-      int wr = c_sm_weights[WOFF + r], wc = c_sm_weights[WOFF + c];
+      int wr = S->smw[r], wc = S->smw[c];
       return (wr * A[c] + (256 - wr) * L[N - 1] + wc * L[r] + (256 - wc) * A[N - 1] + 256) >> 9;
     }
     case SMOOTH_V_PRED: {
-      int wr = c_sm_weights[WOFF + r];
+      int wr = S->smw[r];
       return (wr * A[c] + (256 - wr) * L[N - 1] + 128) >> 8;
     }
     case SMOOTH_H_PRED: {
-      int wc = c_sm_weights[WOFF + c];
+      int wc = S->smw[c];
       return (wc * L[r] + (256 - wc) * A[N - 1] + 128) >> 8;
     }
     default: {
-      int ang = c_mode_angle[mode];  // angle delta is always 0 in this build's decisions
       if (ang < 90) {
-        int dx = c_dr_deriv[ang];
         int idx = (r + 1) * dx;
         int base = (idx >> 6) + c, sh = (idx >> 1) & 31;
         if (base < 2 * N - 1) return (A[base] * (32 - sh) + A[base + 1] * sh + 16) >> 5;
         return A[2 * N - 1];
       } else if (ang < 180) {
-        int dx = c_dr_deriv[180 - ang], dy = c_dr_deriv[ang - 90];
         int idx = (c << 6) - (r + 1) * dx;
         int base = idx >> 6;
         if (base >= -1) {
@@ -159,7 +166,6 @@ __device__ __forceinline__ int pred_pixel(int mode, int r, int c, const uint16_t
         int sh = (idx >> 1) & 31;
         return (L[base] * (32 - sh) + L[base + 1] * sh + 16) >> 5;
       } else {
-        int dy = c_dr_deriv[270 - ang];
         int idx = (c + 1) * dy;
         int base = (idx >> 6) + r, sh = (idx >> 1) & 31;
         return (L[base] * (32 - sh) + L[base + 1] * sh + 16) >> 5;
@@ -170,54 +176,51 @@ __device__ __forceinline__ int pred_pixel(int mode, int r, int c, const uint16_t
 
 struct SbCtx {
   const Av1miDevParams *P;
-  SbLds *S;
   int lane;
   int sb_x, sb_y;          // superblock origin in luma pixels
 };
 
 // Fill edge_a / edge_l for an n x n block at (x0, y0) of `plane` (plane-local pixel coordinates
-// inside the superblock).  Tile == superblock, so nothing outside the superblock is available.
+// inside the superblock) from the line buffers.  Tile == superblock: nothing outside it is available.
 template <int LOG2N>
 __device__ __forceinline__ void prepare_edges(const SbCtx &cx, int plane, int x0, int y0, int have_ar, int have_bl) {
   constexpr int N = 1 << LOG2N;
-  SbLds *S = cx.S;
-  const int stride = plane ? 32 : 64;
-  const uint16_t *rec = plane ? S->rec_c[plane - 1] : S->rec_y;
   const int bd = cx.P->bit_depth;
   const int have_above = y0 > 0, have_left = x0 > 0;
   // frame limits in superblock-local coordinates of this plane
   const int max_x = ((plane ? cx.P->width >> 1 : cx.P->width) - 1) - (plane ? cx.sb_x >> 1 : cx.sb_x);
   const int max_y = ((plane ? cx.P->height >> 1 : cx.P->height) - 1) - (plane ? cx.sb_y >> 1 : cx.sb_y);
-  uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
   for (int i = cx.lane; i < 2 * N; i += 64) {
     int a, l;
-    if (!have_above && have_left) a = rec[y0 * stride + x0 - 1];
+    if (!have_above && have_left) a = S->left[plane][y0];           // pixel (y0, x0-1)
     else if (!have_above) a = (1 << (bd - 1)) - 1;
     else {
       int lim = x0 + (have_ar ? 2 * N : N) - 1;
       if (lim > max_x) lim = max_x;
-      int xx = x0 + i < lim ? x0 + i : lim;
-      a = rec[(y0 - 1) * stride + xx];
+      a = S->above[plane][x0 + i < lim ? x0 + i : lim];             // pixel (y0-1, .)
     }
-    if (!have_left && have_above) l = rec[(y0 - 1) * stride + x0];
+    if (!have_left && have_above) l = S->above[plane][x0];          // pixel (y0-1, x0)
     else if (!have_left) l = (1 << (bd - 1)) + 1;
     else {
       int lim = y0 + (have_bl ? 2 * N : N) - 1;
       if (lim > max_y) lim = max_y;
-      int yy = y0 + i < lim ? y0 + i : lim;
-      l = rec[yy * stride + x0 - 1];
+      l = S->left[plane][y0 + i < lim ? y0 + i : lim];              // pixel (., x0-1)
     }
-    A[i] = (uint16_t)a;
-    L[i] = (uint16_t)l;
+    S->edge_a[1 + i] = (uint16_t)a;
+    S->edge_l[1 + i] = (uint16_t)l;
   }
   if (cx.lane == 0) {
     int tl;
-    if (have_above && have_left) tl = rec[(y0 - 1) * stride + x0 - 1];
-    else if (have_above) tl = rec[(y0 - 1) * stride + x0];
-    else if (have_left) tl = rec[y0 * stride + x0 - 1];
+    if (have_above && have_left) tl = S->corner[plane][y0 >> 2][x0 >> 2];
+    else if (have_above) tl = S->above[plane][x0];
+    else if (have_left) tl = S->left[plane][y0];
     else tl = 1 << (bd - 1);
-    A[-1] = (uint16_t)tl;
-    L[-1] = (uint16_t)tl;
+    S->edge_a[0] = (uint16_t)tl;
+    S->edge_l[0] = (uint16_t)tl;
+  }
+  {  // smooth weights of this size
+    constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
+    if (cx.lane < N) S->smw[cx.lane] = c_sm_weights[WOFF + cx.lane];
   }
   __syncthreads();
 }
@@ -225,204 +228,172 @@ __device__ __forceinline__ void prepare_edges(const SbCtx &cx, int plane, int x0
 template <int LOG2N>
 __device__ __forceinline__ int dc_value(const SbCtx &cx, int have_above, int have_left) {
   constexpr int N = 1 << LOG2N;
-  const uint16_t *A = cx.S->edge_a + 1, *L = cx.S->edge_l + 1;
   int s = 0;
-  if (cx.lane < N) s = (have_above ? A[cx.lane] : 0) + (have_left ? L[cx.lane] : 0);
+  if (cx.lane < N) s = (have_above ? S->edge_a[1 + cx.lane] : 0) + (have_left ? S->edge_l[1 + cx.lane] : 0);
   s = wave_sum(s);
   if (have_above && have_left) return (s + N) >> (LOG2N + 1);
   if (have_above || have_left) return (s + (N >> 1)) >> LOG2N;
   return 1 << (cx.P->bit_depth - 1);
 }
 
-// Predict + transform + quantise + reconstruct one n x n transform block.
-// src: this lane's source pixels (pixel p = lane + 64*k -> row p / N, col p % N).
-// Returns eob; levels (row-major n x n int16) go to `lv_out` (global) when eob > 0.
-template <int LOG2N, int PPL>
-__device__ __forceinline__ int code_tx_block(const SbCtx &cx, int plane, int x0, int y0, int mode, int dcval,
-                                             const int (&src)[PPL], int16_t *lv_out) {
+// One transform block of `plane` at plane-local (x0, y0): [luma: mode decision by closed-loop SAD,
+// first minimum in mode order wins] -> prediction -> forward transform -> dead-zone quantiser ->
+// normative dequantiser + inverse transform -> reconstruction (to HBM + line buffers).
+// `mode_io`: in = mode to use (chroma), out = decided mode (luma).  Returns eob.
+// Exactly one instantiation per size exists (see the plane loop in encode_superblock).
+template <typename PIX, int LOG2N>
+__device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane, int x0, int y0, int &mode_io,
+                                       int16_t *lv_out) {
   constexpr int N = 1 << LOG2N;
   constexpr int ST = N + 1;
-  SbLds *S = cx.S;
   const Av1miDevParams *P = cx.P;
-  const int stride = plane ? 32 : 64;
-  uint16_t *rec = plane ? S->rec_c[plane - 1] : S->rec_y;
-  const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
+  const int lane = cx.lane;
   const int bd = P->bit_depth;
-  const int txt = LOG2N <= 4 ? c_mode_txfm[mode] : 0;
-  const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
-  constexpr int SH0 = 2, SH1 = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : (LOG2N == 4 ? 2 : 4));
-  constexpr int RS = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : 2);
-  // 1. prediction -> rec, residual -> scratch
-#pragma unroll
-  for (int k = 0; k < PPL; k++) {
-    int p = cx.lane + 64 * k;
-    if (p < N * N) {
-      int r = p >> LOG2N, c = p & (N - 1);
-      int pv = pred_pixel<LOG2N>(mode, r, c, A, L, dcval);
-      rec[(y0 + r) * stride + x0 + c] = (uint16_t)pv;
-      S->scratch[r * ST + c] = src[k] - pv;
-    }
-  }
-  __syncthreads();
-  // 2. forward columns
-  int32_t x[N];
-  if (cx.lane < N) {
-#pragma unroll
-    for (int i = 0; i < N; i++) x[i] = S->scratch[i * ST + cx.lane] << SH0;
-    Tx1d<LOG2N>::fwd(x, vt);
-#pragma unroll
-    for (int i = 0; i < N; i++) S->scratch[i * ST + cx.lane] = rshift_round(x[i], SH1);
-  }
-  __syncthreads();
-  // 3. forward rows, quantise, dequantise, inverse rows
-  int my_eob = 0;
-  if (cx.lane < N) {
-    const int row = cx.lane;
-#pragma unroll
-    for (int j = 0; j < N; j++) x[j] = S->scratch[row * ST + j];
-    Tx1d<LOG2N>::fwd(x, ht);
-    constexpr int TSH = LOG2N == 5 ? 1 : 0;  // dequant shift of the size class (§7.12.3)
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-      int v = x[j];
-      bool dc = (row | j) == 0;
-      uint32_t q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
-      uint32_t recip = dc ? P->dc_recip : P->ac_recip;
-      uint32_t a = ((uint32_t)iabs(v) << TSH) + ((3 * q) >> 3);
-      uint32_t lv = __umulhi(a, recip);
-      if (lv > 0x7FFF) lv = 0x7FFF;
-      int slv = v < 0 ? -(int)lv : (int)lv;
-      S->lvl[row * N + j] = (int16_t)slv;
-      if (lv) {
-        int si = scan_index(row, j, N) + 1;
-        my_eob = si > my_eob ? si : my_eob;
-        int d = (int)(((uint32_t)lv * q) & 0xFFFFFF) >> TSH;
-        int lim = 1 << (7 + bd);
-        d = v < 0 ? -d : d;
-        d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
-        x[j] = clamp_bits(d, bd + 8);
-      } else {
-        x[j] = 0;
-      }
-    }
-  }
-  const int eob = wave_max(my_eob);
-  if (eob == 0) return 0;  // reconstruction = prediction
-  if (cx.lane < N) {
-    const int row = cx.lane;
-    Tx1d<LOG2N>::inv(x, ht);
-#pragma unroll
-    for (int j = 0; j < N; j++) S->scratch[row * ST + j] = clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
-  }
-  __syncthreads();
-  // 4. inverse columns + reconstruction
-  if (cx.lane < N) {
-    const int col = cx.lane;
-    const int maxv = (1 << bd) - 1;
-#pragma unroll
-    for (int i = 0; i < N; i++) x[i] = S->scratch[i * ST + col];
-    Tx1d<LOG2N>::inv(x, vt);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      int v = rec[(y0 + i) * stride + x0 + col] + ((x[i] + 8) >> 4);
-      rec[(y0 + i) * stride + x0 + col] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
-    }
-  }
-  // 5. levels out (staged in LDS, coalesced)
+  // decoded-block map lookups (spec §5.11.35): above-right / below-left availability
+  const int pc = plane > 0;
+  const int r4 = y0 >> 2, c4 = x0 >> 2;
+  constexpr int step = (N >> 2) > 0 ? (N >> 2) : 1;
+  const int have_ar = S->blkdec[pc][r4 - 1 + 1][c4 + step + 1];
+  const int have_bl = S->blkdec[pc][r4 + step + 1][c4 - 1 + 1];
+  const long poff = plane == 0 ? 0 : (plane == 1 ? P->plane_off_u : P->plane_off_v);
+  const int gs = plane ? P->stride_c : P->stride_y;
+  const int gx = (plane ? cx.sb_x >> 1 : cx.sb_x) + x0, gy = (plane ? cx.sb_y >> 1 : cx.sb_y) + y0;
+  // source block -> LDS (coalesced rows)
   {
-    constexpr int WORDS = N * N / 2;  // 32-bit words
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(S->lvl);
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(lv_out);
-    for (int i = cx.lane; i < WORDS; i += 64) d32[i] = s32[i];
+    const PIX *pl = frame + poff;
+#pragma unroll 4
+    for (int p = lane; p < N * N; p += 64) S->srcblk[p] = (uint16_t)pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))];
   }
-  __syncthreads();
-  return eob;
-}
-
-template <typename PIX, int LOG2N, int PPL>
-__device__ __forceinline__ void load_src(const PIX *plane, int stride, int gx, int gy, int lane, int (&src)[PPL]) {
-  constexpr int N = 1 << LOG2N;
-#pragma unroll
-  for (int k = 0; k < PPL; k++) {
-    int p = lane + 64 * k;
-    src[k] = 0;
-    if (p < N * N) {
-      int r = p >> LOG2N, c = p & (N - 1);
-      src[k] = plane[(size_t)(gy + r) * stride + gx + c];
-    }
-  }
-}
-
-// One leaf block: luma mode decision (closed-loop SAD over the candidate modes, first minimum in
-// mode order wins), luma + both chroma transform blocks.
-template <typename PIX, int LOG2N>
-__device__ __forceinline__ void encode_block(const SbCtx &cx, const PIX *frame, int bx, int by,
-                                             int16_t *sb_levels, Av1miBlkInfo *info, int b8_stride) {
-  constexpr int N = 1 << LOG2N;
-  constexpr int PPL = (N * N + 63) / 64;
-  constexpr int LOG2C = LOG2N - 1;
-  constexpr int NC = N >> 1;
-  constexpr int PPLC = (NC * NC + 63) / 64;
-  SbLds *S = cx.S;
-  const Av1miDevParams *P = cx.P;
-  // availability of above-right / below-left from the decoded-block map (spec §5.11.35)
-  const int r4 = by >> 2, c4 = bx >> 2, step = N >> 2;
-  const int have_ar = S->blkdec[0][r4 - 1 + 1][c4 + step + 1];
-  const int have_bl = S->blkdec[0][r4 + step + 1][c4 - 1 + 1];
-  constexpr int stepc = (NC >> 2) > 0 ? (NC >> 2) : 1;
-  const int have_ar_c = S->blkdec[1][(r4 >> 1) - 1 + 1][(c4 >> 1) + stepc + 1];
-  const int have_bl_c = S->blkdec[1][(r4 >> 1) + stepc + 1][(c4 >> 1) - 1 + 1];
-  int src[PPL];
-  load_src<PIX, LOG2N, PPL>(frame, P->stride_y, cx.sb_x + bx, cx.sb_y + by, cx.lane, src);
-  prepare_edges<LOG2N>(cx, 0, bx, by, have_ar, have_bl);
-  const int have_above = by > 0, have_left = bx > 0;
+  prepare_edges<LOG2N>(cx, plane, x0, y0, have_ar, have_bl);
+  const int have_above = y0 > 0, have_left = x0 > 0;
   const int dcv = dc_value<LOG2N>(cx, have_above, have_left);
-  // ---- mode decision
-  int best_mode = 0, best_sad = 0x7FFFFFFF;
-  {
-    const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
-    for (int m = 0; m < 13; m++) {
-      if (!((P->mode_mask >> m) & 1)) continue;
-      int sad = 0;
-#pragma unroll
-      for (int k = 0; k < PPL; k++) {
-        int p = cx.lane + 64 * k;
-        if (p < N * N) sad += iabs(src[k] - pred_pixel<LOG2N>(m, p >> LOG2N, p & (N - 1), A, L, dcv));
+  // ---- mode decision (luma) + final prediction: one loop, the last trip writes the prediction
+  int best_mode = mode_io, best_sad = 0x7FFFFFFF;
+  const int first = plane == 0 ? 0 : 13;
+#pragma nounroll
+  for (int m = first; m <= 13; m++) {
+    const bool final_trip = m == 13;
+    const int mode = final_trip ? best_mode : m;
+    if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
+    int ang = 0, dx = 0, dy = 0;
+    if (mode >= V_PRED && mode <= D67_PRED) {
+      ang = c_mode_angle[mode];
+      if (ang < 90) dx = c_dr_deriv[ang];
+      else if (ang > 90 && ang < 180) { dx = c_dr_deriv[180 - ang]; dy = c_dr_deriv[ang - 90]; }
+      else if (ang > 180) dy = c_dr_deriv[270 - ang];
+    }
+    int sad = 0;
+#pragma unroll 4
+    for (int p = lane; p < N * N; p += 64) {
+      const int r = p >> LOG2N, c = p & (N - 1);
+      const int pv = pred_pixel<LOG2N>(mode, r, c, dcv, ang, dx, dy);
+      const int sv = S->srcblk[p];
+      if (final_trip) {
+        S->blkpix[p] = (uint16_t)pv;
+        S->scratch[r * ST + c] = (int16_t)(sv - pv);
+      } else {
+        sad += iabs(sv - pv);
       }
+    }
+    if (!final_trip) {
       sad = wave_sum(sad);
       if (sad < best_sad) { best_sad = sad; best_mode = m; }
     }
   }
-  const int mode = best_mode;
-  int16_t *lv_y = sb_levels + by * 64 + bx * N;
-  const int eob_y = code_tx_block<LOG2N, PPL>(cx, 0, bx, by, mode, dcv, src, lv_y);
-  // ---- chroma (uv_mode = y mode)
-  int eob_c[2];
-#pragma unroll
-  for (int pl = 1; pl < 3; pl++) {
-    const PIX *cplane = frame + (pl == 1 ? P->plane_off_u : P->plane_off_v);
-    int csrc[PPLC];
-    load_src<PIX, LOG2C, PPLC>(cplane, P->stride_c, (cx.sb_x + bx) >> 1, (cx.sb_y + by) >> 1, cx.lane, csrc);
-    prepare_edges<LOG2C>(cx, pl, bx >> 1, by >> 1, have_ar_c, have_bl_c);
-    const int dcc = dc_value<LOG2C>(cx, have_above, have_left);
-    int16_t *lv_c = sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * NC;
-    eob_c[pl - 1] = code_tx_block<LOG2C, PPLC>(cx, pl, bx >> 1, by >> 1, mode, dcc, csrc, lv_c);
-  }
-  // ---- bookkeeping
-  const int skip = (eob_y | eob_c[0] | eob_c[1]) == 0;
-  if (cx.lane == 0) {
-    const int n8 = N >> 3 ? N >> 3 : 1;
-    for (int i = 0; i < n8; i++)
-      for (int j = 0; j < n8; j++) {
-        Av1miBlkInfo bi;
-        bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)skip; bi.bsl = (uint8_t)LOG2N; bi.pad = 0;
-        bi.eob[0] = (uint16_t)eob_y; bi.eob[1] = (uint16_t)eob_c[0]; bi.eob[2] = (uint16_t)eob_c[1]; bi.pad2 = 0;
-        info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
-      }
-  }
-  for (int t = cx.lane; t < step * step; t += 64) S->blkdec[0][r4 + t / step + 1][c4 + t % step + 1] = 1;
-  for (int t = cx.lane; t < stepc * stepc; t += 64) S->blkdec[1][(r4 >> 1) + t / stepc + 1][(c4 >> 1) + t % stepc + 1] = 1;
+  mode_io = best_mode;
   __syncthreads();
+  // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
+  const int txt = LOG2N <= 4 ? c_mode_txfm[best_mode] : 0;
+  const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
+  constexpr int SH0 = 2, SH1 = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : (LOG2N == 4 ? 2 : 4));
+  constexpr int RS = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : 2);
+  constexpr int TSH = LOG2N == 5 ? 1 : 0;  // dequant shift of the size class (§7.12.3)
+  int32_t x[N];
+  if (lane < N) {
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = (int)S->scratch[i * ST + lane] << SH0;
+    Tx1d<LOG2N>::fwd(x, vt);
+#pragma unroll
+    for (int i = 0; i < N; i++) S->scratch[i * ST + lane] = (int16_t)rshift_round(x[i], SH1);
+  }
+  __syncthreads();
+  int my_eob = 0;
+  if (lane < N) {
+    const int row = lane;
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = S->scratch[row * ST + j];
+    Tx1d<LOG2N>::fwd(x, ht);
+    int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk);  // source block is dead: reuse for the levels
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const int v = x[j];
+      const bool dc = (row | j) == 0;
+      const uint32_t q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
+      const uint32_t recip = dc ? P->dc_recip : P->ac_recip;
+      const uint32_t a = ((uint32_t)iabs(v) << TSH) + ((3 * q) >> 3);
+      uint32_t lv = __umulhi(a, recip);
+      if (lv > 0x7FFF) lv = 0x7FFF;
+      lvl[row * N + j] = (int16_t)(v < 0 ? -(int)lv : (int)lv);
+      int d = 0;
+      if (lv) {
+        const int si = scan_index(row, j, N) + 1;
+        my_eob = si > my_eob ? si : my_eob;
+        d = (int)(((uint32_t)lv * q) & 0xFFFFFF) >> TSH;
+        const int lim = 1 << (7 + bd);
+        d = v < 0 ? -d : d;
+        d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
+      }
+      x[j] = d;
+    }
+  }
+  const int eob = wave_max(my_eob);
+  if (eob) {
+    if (lane < N) {
+      Tx1d<LOG2N>::inv(x, ht);
+#pragma unroll
+      for (int j = 0; j < N; j++) S->scratch[lane * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
+    }
+    __syncthreads();
+    if (lane < N) {
+      const int maxv = (1 << bd) - 1;
+#pragma unroll
+      for (int i = 0; i < N; i++) x[i] = S->scratch[i * ST + lane];
+      Tx1d<LOG2N>::inv(x, vt);
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        int v = S->blkpix[i * N + lane] + ((x[i] + 8) >> 4);
+        S->blkpix[i * N + lane] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+      }
+    }
+    // levels out (coalesced 32-bit words)
+    {
+      constexpr int WORDS = N * N / 2;
+      const int16_t *lvl = reinterpret_cast<const int16_t *>(S->srcblk);
+      uint32_t *d32 = reinterpret_cast<uint32_t *>(lv_out);
+      for (int i = lane; i < WORDS; i += 64) d32[i] = (uint32_t)(uint16_t)lvl[2 * i] | ((uint32_t)(uint16_t)lvl[2 * i + 1] << 16);
+    }
+  }
+  __syncthreads();
+  // ---- reconstruction -> HBM (coalesced rows) and -> line buffers for the neighbours to come
+  {
+    PIX *pl = rec_frame + poff;
+#pragma unroll 4
+    for (int p = lane; p < N * N; p += 64) pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))] = (PIX)S->blkpix[p];
+    if (lane < N) {
+      S->above[plane][x0 + lane] = S->blkpix[(N - 1) * N + lane];
+      S->left[plane][y0 + lane] = S->blkpix[lane * N + (N - 1)];
+    }
+    if (lane < step) {  // corners at every 4-aligned position of the bottom row and right column
+      const int j = lane + 1;
+      S->corner[plane][(y0 + N) >> 2][(x0 >> 2) + j] = S->blkpix[(N - 1) * N + 4 * j - 1];
+      S->corner[plane][(y0 >> 2) + j][(x0 + N) >> 2] = S->blkpix[(4 * j - 1) * N + (N - 1)];
+    }
+    if (plane != 1) {  // chroma map is shared by U and V: mark after V
+      for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
+    }
+  }
+  __syncthreads();
+  return eob;
 }
 
 // Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
@@ -444,19 +415,43 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
 }
 
 template <typename PIX>
-__device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, int16_t *sb_levels,
+__device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
                                                   Av1miBlkInfo *info, int b8_stride) {
   const Av1miDevParams &P = *cx.P;
+#pragma nounroll
   for (int z = 0; z < 64; z++) {  // 8x8 units in Z (partition) order
     const int bx = (((z >> 0) & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) << 3;
     const int by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) << 3;
     if (cx.sb_y + by >= P.height || cx.sb_x + bx >= P.width) continue;
     const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
-    switch (bsl) {
-      case 3: encode_block<PIX, 3>(cx, frame, bx, by, sb_levels, info, b8_stride); break;
-      case 4: encode_block<PIX, 4>(cx, frame, bx, by, sb_levels, info, b8_stride); break;
-      case 5: encode_block<PIX, 5>(cx, frame, bx, by, sb_levels, info, b8_stride); break;
-      default: break;
+    if (bsl == 0) continue;
+    const int n = 1 << bsl;
+    int mode = 0, eobs[3] = { 0, 0, 0 };
+    // the three planes of a leaf block run through ONE dispatch so that each size is instantiated once
+#pragma nounroll
+    for (int pl = 0; pl < 3; pl++) {
+      const int l2 = pl ? bsl - 1 : bsl;
+      const int x0 = pl ? bx >> 1 : bx, y0 = pl ? by >> 1 : by;
+      int16_t *lv = pl == 0 ? sb_levels + by * 64 + bx * n : sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * (n >> 1);
+      int e;
+      switch (l2) {
+        case 5: e = tx_item<PIX, 5>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
+        case 4: e = tx_item<PIX, 4>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
+        case 3: e = tx_item<PIX, 3>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
+        default: e = tx_item<PIX, 2>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
+      }
+      if (pl == 0) eobs[0] = e; else if (pl == 1) eobs[1] = e; else eobs[2] = e;
+    }
+    const int skip = (eobs[0] | eobs[1] | eobs[2]) == 0;
+    if (cx.lane == 0) {
+      const int n8 = n >> 3;
+      for (int i = 0; i < n8; i++)
+        for (int j = 0; j < n8; j++) {
+          Av1miBlkInfo bi;
+          bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)skip; bi.bsl = (uint8_t)bsl; bi.pad = 0;
+          bi.eob[0] = (uint16_t)eobs[0]; bi.eob[1] = (uint16_t)eobs[1]; bi.eob[2] = (uint16_t)eobs[2]; bi.pad2 = 0;
+          info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
+        }
     }
   }
 }
@@ -464,12 +459,11 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
 template <typename PIX>
 __global__ void __launch_bounds__(64) recon_sb_kernel(Av1miDevParams P, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk) {
-  __shared__ SbLds S;
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
   const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
   SbCtx cx;
-  cx.P = &P; cx.S = &S; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
+  cx.P = &P; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
   const PIX *frame = src + (size_t)f * P.frame_samples;
   // decoded-block map (clear_block_decoded_flags, spec §5.11.3) with tile == superblock
   {
@@ -484,32 +478,15 @@ __global__ void __launch_bounds__(64) recon_sb_kernel(Av1miDevParams P, const PI
         else if (x < 0 && y < sh) v = 1;
         if (y == sz && x == -1) v = 0;
       }
-      S.blkdec[pl][y + 1][x + 1] = (uint8_t)v;
+      S->blkdec[pl][y + 1][x + 1] = (uint8_t)v;
     }
   }
   __syncthreads();
   int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
   Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
-  encode_superblock<PIX>(cx, frame, sb_levels, info, P.b8_cols);
-  __syncthreads();
-  // superblock reconstruction -> HBM (in-frame part only)
-  PIX *out = rec + (size_t)f * P.frame_samples;
-  {
-    const int w = P.width - cx.sb_x < 64 ? P.width - cx.sb_x : 64, h = P.height - cx.sb_y < 64 ? P.height - cx.sb_y : 64;
-    for (int t = cx.lane; t < 64 * h; t += 64) {
-      int r = t >> 6, c = t & 63;
-      if (c < w) out[(size_t)(cx.sb_y + r) * P.stride_y + cx.sb_x + c] = (PIX)S.rec_y[r * 64 + c];
-    }
-    const int wc = w >> 1, hc = h >> 1;
-    for (int pl = 1; pl < 3; pl++) {
-      PIX *op = out + (pl == 1 ? P.plane_off_u : P.plane_off_v);
-      for (int t = cx.lane; t < 32 * hc; t += 64) {
-        int r = t >> 5, c = t & 31;
-        if (c < wc) op[(size_t)((cx.sb_y >> 1) + r) * P.stride_c + (cx.sb_x >> 1) + c] = (PIX)S.rec_c[pl - 1][r * 32 + c];
-      }
-    }
-  }
+  encode_superblock<PIX>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols);
 }
+#undef S
 
 }  // namespace
 
