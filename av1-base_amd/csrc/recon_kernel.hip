@@ -330,7 +330,9 @@ __device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *fra
       const bool dc = (row | j) == 0;
       const uint32_t q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
       const uint32_t recip = dc ? P->dc_recip : P->ac_recip;
-      const uint32_t a = ((uint32_t)iabs(v) << TSH) + ((3 * q) >> 3);
+      // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above
+      const uint32_t rnd = (row + j) < (N >> 2) ? (3 * q) >> 3 : ((row + j) < (N >> 1) ? (q >> 2) : (q >> 3));
+      const uint32_t a = ((uint32_t)iabs(v) << TSH) + rnd;
       uint32_t lv = __umulhi(a, recip);
       if (lv > 0x7FFF) lv = 0x7FFF;
       lvl[row * N + j] = (int16_t)(v < 0 ? -(int)lv : (int)lv);

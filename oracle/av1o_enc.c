@@ -615,7 +615,8 @@ static void prepare_edges(const Enc *e, int plane, int x, int y, int n, int have
 static int tx_scale_shift(int log2n) { return log2n >= 6 ? 2 : (log2n == 5 ? 1 : 0); }
 
 /* forward transform + dead-zone quantise -> levels; dequantise + inverse -> recon in place.
- * Returns eob.  DESIGN.md §3.5: level = ((|coef| << s) + (3q >> 3)) * ceil(2^32/q) >> 32. */
+ * Returns eob.  DESIGN.md §3.5: level = ((|coef| << s) + rnd) * ceil(2^32/q) >> 32 with the
+ * frequency-dependent dead zone rnd = 3q/8 (row+col < n/4), q/4 (< n/2), q/8 (else). */
 static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type, TxbCoefs *t) {
   const int n = 1 << log2n, bd = e->cfg->bit_depth;
   const int cw = n > 32 ? 32 : n, bwl = log2n > 5 ? 5 : log2n;
@@ -647,7 +648,8 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
         int32_t v = coef[i * n + j];
         uint32_t q = (uint32_t)((i | j) ? e->ac_q : e->dc_q);
         uint32_t recip = (uint32_t)((((uint64_t)1 << 32) + q - 1) / q);
-        uint32_t a = ((uint32_t)abs(v) << sh) + ((3 * q) >> 3);
+        uint32_t rnd = (i + j) < (cw >> 2) ? (3 * q) >> 3 : ((i + j) < (cw >> 1) ? (q >> 2) : (q >> 3));
+        uint32_t a = ((uint32_t)abs(v) << sh) + rnd;
         uint32_t lv = (uint32_t)(((uint64_t)a * recip) >> 32);
         if (lv > 0x7FFF) lv = 0x7FFF;
         t->level[(i << bwl) + j] = v < 0 ? -(int32_t)lv : (int32_t)lv;
