@@ -22,67 +22,76 @@ __constant__ int c_div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
 
 #define CDEF_NA 0xFFFFu
 
+// LDS: one plane tile at a time (luma 68x68, then U, then V as 36x36 in the same buffer) plus the
+// per-8x8 decisions: 9.5 KB per wave.
 struct CdefLds {
-  uint16_t y[68 * 68];
-  uint16_t c[2][36 * 36];
+  uint16_t t[68 * 68];
+  uint8_t dir[64];       // luma direction of each 8x8 block
+  uint8_t on[64];        // block is filtered
+  uint16_t pri_y[64];    // variance-adjusted luma primary strength
 };
+__shared__ CdefLds g_cdef;
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
-__device__ __forceinline__ int constrain(int diff, int threshold, int damping) {
-  if (!threshold) return 0;
-  int adj = damping - (31 - __builtin_clz((unsigned)threshold));
-  if (adj < 0) adj = 0;
+__device__ __forceinline__ int constrain(int diff, int threshold, int shift) {
+  // shift = max(0, damping - floor(log2(threshold))), precomputed by the caller; threshold != 0
   const int mag = iabs(diff);
-  int lim = threshold - (mag >> adj);
+  int lim = threshold - (mag >> shift);
   lim = lim < 0 ? 0 : (lim > mag ? mag : lim);
   return diff < 0 ? -lim : lim;
 }
+__device__ __forceinline__ int damp_shift(int threshold, int damping) {
+  if (!threshold) return 0;
+  const int a = damping - (31 - __builtin_clz((unsigned)threshold));
+  return a < 0 ? 0 : a;
+}
 
-template <int W, int LDS_STRIDE>
-__device__ __forceinline__ void filter_block(const uint16_t *t /* block origin in LDS tile */, int pri, int sec, int damping,
-                                             int dir, int coeff_shift, uint16_t (&out)[W * W]) {
-  const int pt0 = ((pri >> coeff_shift) & 1) ? 3 : 4, pt1 = ((pri >> coeff_shift) & 1) ? 3 : 2;
+// filter one pixel at LDS position `c` (tile stride ST); taps of direction dir
+template <int ST>
+__device__ __forceinline__ int cdef_pixel(int c, int pri, int sec, int pri_shift, int sec_shift, int dir, int coeff_shift) {
+  const uint16_t *t = g_cdef.t;
+  const int x = t[c];
+  int sum = 0, mx = x, mn = x;
+  const int odd = (pri >> coeff_shift) & 1;
 #pragma unroll
-  for (int i = 0; i < W; i++)
+  for (int k = 0; k < 2; k++) {
+    const int ptap = k ? (odd ? 3 : 2) : (odd ? 3 : 4), stap = k ? 1 : 2;
+    const int o0 = c_cdef_dir[dir][k][0] * ST + c_cdef_dir[dir][k][1];
+    const int o1 = c_cdef_dir[(dir + 2) & 7][k][0] * ST + c_cdef_dir[(dir + 2) & 7][k][1];
+    const int o2 = c_cdef_dir[(dir + 6) & 7][k][0] * ST + c_cdef_dir[(dir + 6) & 7][k][1];
 #pragma unroll
-    for (int j = 0; j < W; j++) {
-      const int x = t[i * LDS_STRIDE + j];
-      int sum = 0, mx = x, mn = x;
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const int ptap = k ? pt1 : pt0, stap = k ? 1 : 2;
-#pragma unroll
-        for (int sg = -1; sg <= 1; sg += 2) {
-          {
-            const int p = t[(i + sg * c_cdef_dir[dir][k][0]) * LDS_STRIDE + j + sg * c_cdef_dir[dir][k][1]];
-            if (p != CDEF_NA) {
-              sum += ptap * constrain(p - x, pri, damping);
-              mx = p > mx ? p : mx;
-              mn = p < mn ? p : mn;
-            }
-          }
-#pragma unroll
-          for (int d = -2; d <= 2; d += 4) {
-            const int dd = (dir + d) & 7;
-            const int s = t[(i + sg * c_cdef_dir[dd][k][0]) * LDS_STRIDE + j + sg * c_cdef_dir[dd][k][1]];
-            if (s != CDEF_NA) {
-              sum += stap * constrain(s - x, sec, damping);
-              mx = s > mx ? s : mx;
-              mn = s < mn ? s : mn;
-            }
-          }
+    for (int sg = -1; sg <= 1; sg += 2) {
+      // every available tap widens the clamp range, whatever its strength (spec §7.15.3)
+      {
+        const int p = t[c + sg * o0];
+        if (p != CDEF_NA) {
+          if (pri) sum += ptap * constrain(p - x, pri, pri_shift);
+          mx = p > mx ? p : mx;
+          mn = p < mn ? p : mn;
         }
       }
-      int v = x + ((8 + sum - (sum < 0)) >> 4);
-      v = v < mn ? mn : (v > mx ? mx : v);
-      out[i * W + j] = (uint16_t)v;
+      {
+        const int s1 = t[c + sg * o2], s2 = t[c + sg * o1];  // dir-2, dir+2 (order is irrelevant to the result)
+        if (s1 != CDEF_NA) {
+          if (sec) sum += stap * constrain(s1 - x, sec, sec_shift);
+          mx = s1 > mx ? s1 : mx;
+          mn = s1 < mn ? s1 : mn;
+        }
+        if (s2 != CDEF_NA) {
+          if (sec) sum += stap * constrain(s2 - x, sec, sec_shift);
+          mx = s2 > mx ? s2 : mx;
+          mn = s2 < mn ? s2 : mn;
+        }
+      }
     }
+  }
+  int v = x + ((8 + sum - (sum < 0)) >> 4);
+  return v < mn ? mn : (v > mx ? mx : v);
 }
 
 template <typename PIX>
 __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
                                                     const Av1miBlkInfo *__restrict__ blk) {
-  __shared__ CdefLds S;
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
   const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
@@ -90,118 +99,136 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
   const PIX *fr = rec + (size_t)f * P.frame_samples;
   PIX *fo = fin + (size_t)f * P.frame_samples;
   const int x0 = sbc * 64, y0 = sbr * 64;
-  // stage luma 68x68 and chroma 36x36 (x2) with halo; outside-frame -> sentinel
+  const int bd = P.bit_depth, coeff_shift = bd - 8;
+  const int w = P.width - x0 < 64 ? P.width - x0 : 64, h = P.height - y0 < 64 ? P.height - y0 : 64;
+  // ---- luma tile 68x68 incl. 2-px halo; outside-frame samples -> sentinel
   for (int t = lane; t < 68 * 68; t += 64) {
     const int r = t / 68, c = t % 68;
     const int gy = y0 + r - 2, gx = x0 + c - 2;
-    S.y[t] = (gy >= 0 && gx >= 0 && gy < P.height && gx < P.width) ? (uint16_t)fr[(size_t)gy * P.stride_y + gx] : (uint16_t)CDEF_NA;
+    g_cdef.t[t] = (gy >= 0 && gx >= 0 && gy < P.height && gx < P.width) ? (uint16_t)fr[(size_t)gy * P.stride_y + gx] : (uint16_t)CDEF_NA;
   }
-  for (int pl = 0; pl < 2; pl++) {
-    const PIX *cp = fr + (pl ? P.plane_off_v : P.plane_off_u);
-    for (int t = lane; t < 36 * 36; t += 64) {
-      const int r = t / 36, c = t % 36;
-      const int gy = (y0 >> 1) + r - 2, gx = (x0 >> 1) + c - 2;
-      S.c[pl][t] = (gy >= 0 && gx >= 0 && gy < (P.height >> 1) && gx < (P.width >> 1)) ? (uint16_t)cp[(size_t)gy * P.stride_c + gx] : (uint16_t)CDEF_NA;
-    }
-  }
-  __syncthreads();
+  // ---- per-8x8 decisions: lane = 8x8 block
   const int b8r = lane >> 3, b8c = lane & 7;
   const bool inside = (sbr * 8 + b8r) < P.b8_rows && (sbc * 8 + b8c) < P.b8_cols;
   int skip = 1;
   if (inside) skip = blk[(size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8 + b8r) * P.b8_cols + sbc * 8 + b8c].skip;
-  // cdef_idx of the superblock is coded (== 0) iff some block in it is not skipped
+  // cdef_idx of the superblock is coded (== 0) iff some block in it is not skipped (§5.11.56)
   const bool sb_on = __ballot(inside && !skip) != 0ull;
-  if (!inside) return;
-  const int bd = P.bit_depth, coeff_shift = bd - 8;
-  const uint16_t *ty = S.y + (b8r * 8 + 2) * 68 + b8c * 8 + 2;
-  uint16_t outy[64];
-  const bool do_filter = P.enable_cdef && sb_on && !skip;
-  int ydir = 0, var = 0;
-  if (do_filter) {
-    // direction search §7.15.2
-    int cost[8], partial[8][15];
+  const bool do_filter = P.enable_cdef && sb_on && inside && !skip;
+  __syncthreads();
+  {
+    int ydir = 0, var = 0;
+    if (do_filter) {
+      // direction search §7.15.2
+      const uint16_t *ty = g_cdef.t + (b8r * 8 + 2) * 68 + b8c * 8 + 2;
+      int cost[8], partial[8][15];
 #pragma unroll
-    for (int a = 0; a < 8; a++) {
-      cost[a] = 0;
+      for (int a = 0; a < 8; a++) {
+        cost[a] = 0;
 #pragma unroll
-      for (int b = 0; b < 15; b++) partial[a][b] = 0;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int x = (ty[i * 68 + j] >> coeff_shift) - 128;
-        partial[0][i + j] += x;
-        partial[1][i + j / 2] += x;
-        partial[2][i] += x;
-        partial[3][3 + i - j / 2] += x;
-        partial[4][7 + i - j] += x;
-        partial[5][3 - i / 2 + j] += x;
-        partial[6][j] += x;
-        partial[7][i / 2 + j] += x;
+        for (int b = 0; b < 15; b++) partial[a][b] = 0;
       }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      cost[2] += partial[2][i] * partial[2][i];
-      cost[6] += partial[6][i] * partial[6][i];
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int x = (ty[i * 68 + j] >> coeff_shift) - 128;
+          partial[0][i + j] += x;
+          partial[1][i + j / 2] += x;
+          partial[2][i] += x;
+          partial[3][3 + i - j / 2] += x;
+          partial[4][7 + i - j] += x;
+          partial[5][3 - i / 2 + j] += x;
+          partial[6][j] += x;
+          partial[7][i / 2 + j] += x;
+        }
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        cost[2] += partial[2][i] * partial[2][i];
+        cost[6] += partial[6][i] * partial[6][i];
+      }
+      cost[2] *= 105;
+      cost[6] *= 105;
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * c_div_table[i + 1];
+        cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * c_div_table[i + 1];
+      }
+      cost[0] += partial[0][7] * partial[0][7] * 105;
+      cost[4] += partial[4][7] * partial[4][7] * 105;
+#pragma unroll
+      for (int i = 1; i < 8; i += 2) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
+        cost[i] *= 105;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * c_div_table[2 * j + 2];
+      }
+      int best = 0;
+#pragma unroll
+      for (int d = 0; d < 8; d++)
+        if (cost[d] > best) { best = cost[d]; ydir = d; }
+      int opp = 0;
+#pragma unroll
+      for (int d = 0; d < 8; d++)
+        if (d == ((ydir + 4) & 7)) opp = cost[d];
+      var = (best - opp) >> 10;
     }
-    cost[2] *= 105;
-    cost[6] *= 105;
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-      cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * c_div_table[i + 1];
-      cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * c_div_table[i + 1];
-    }
-    cost[0] += partial[0][7] * partial[0][7] * 105;
-    cost[4] += partial[4][7] * partial[4][7] * 105;
-#pragma unroll
-    for (int i = 1; i < 8; i += 2) {
-#pragma unroll
-      for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
-      cost[i] *= 105;
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * c_div_table[2 * j + 2];
-    }
-    int best = 0;
-#pragma unroll
-    for (int d = 0; d < 8; d++)
-      if (cost[d] > best) { best = cost[d]; ydir = d; }
-    int opp = 0;
-#pragma unroll
-    for (int d = 0; d < 8; d++)
-      if (d == ((ydir + 4) & 7)) opp = cost[d];
-    var = (best - opp) >> 10;
-  }
-  PIX *oy = fo + (size_t)(y0 + b8r * 8) * P.stride_y + x0 + b8c * 8;
-  if (do_filter) {
     int pri = P.cdef_y_pri << coeff_shift;
-    const int sec = (P.cdef_y_sec == 3 ? 4 : P.cdef_y_sec) << coeff_shift;
-    const int dir = pri == 0 ? 0 : ydir;
     const int v6 = var >> 6;
     const int var_str = v6 ? ((31 - __builtin_clz((unsigned)v6)) < 12 ? (31 - __builtin_clz((unsigned)v6)) : 12) : 0;
     pri = var ? (pri * (4 + var_str) + 8) >> 4 : 0;
-    filter_block<8, 68>(ty, pri, sec, P.cdef_damping + coeff_shift, dir, coeff_shift, outy);
-    for (int i = 0; i < 8; i++)
-      for (int j = 0; j < 8; j++) oy[(size_t)i * P.stride_y + j] = (PIX)outy[i * 8 + j];
-  } else {
-    for (int i = 0; i < 8; i++)
-      for (int j = 0; j < 8; j++) oy[(size_t)i * P.stride_y + j] = (PIX)ty[i * 68 + j];
+    g_cdef.dir[lane] = (uint8_t)ydir;
+    g_cdef.on[lane] = (uint8_t)do_filter;
+    g_cdef.pri_y[lane] = (uint16_t)pri;
   }
+  __syncthreads();
+  // ---- luma filter: lane = column, loop over rows (coalesced LDS reads and HBM row stores)
+  {
+    const int sec = (P.cdef_y_sec == 3 ? 4 : P.cdef_y_sec) << coeff_shift;
+    const int damping = P.cdef_damping + coeff_shift;
+    const int sec_shift = damp_shift(sec, damping);
+    const int ypri0 = P.cdef_y_pri;
+    if (lane < w) {
+      for (int r = 0; r < h; r++) {
+        const int b = (r >> 3) * 8 + (lane >> 3);
+        const int c = (r + 2) * 68 + lane + 2;
+        int v = g_cdef.t[c];
+        if (g_cdef.on[b]) {
+          const int pri = g_cdef.pri_y[b];
+          const int dir = ypri0 == 0 ? 0 : g_cdef.dir[b];
+          v = cdef_pixel<68>(c, pri, sec, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
+        }
+        fo[(size_t)(y0 + r) * P.stride_y + x0 + lane] = (PIX)v;
+      }
+    }
+  }
+  // ---- chroma planes, one at a time through the same tile buffer (stride 36)
   for (int pl = 0; pl < 2; pl++) {
-    const uint16_t *tc = S.c[pl] + (b8r * 4 + 2) * 36 + b8c * 4 + 2;
-    PIX *oc = fo + (pl ? P.plane_off_v : P.plane_off_u) + (size_t)((y0 >> 1) + b8r * 4) * P.stride_c + (x0 >> 1) + b8c * 4;
-    if (do_filter) {
-      const int pri = P.cdef_uv_pri << coeff_shift;
-      const int sec = (P.cdef_uv_sec == 3 ? 4 : P.cdef_uv_sec) << coeff_shift;
-      const int dir = pri == 0 ? 0 : ydir;
-      uint16_t outc[16];
-      filter_block<4, 36>(tc, pri, sec, P.cdef_damping + coeff_shift - 1, dir, coeff_shift, outc);
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) oc[(size_t)i * P.stride_c + j] = (PIX)outc[i * 4 + j];
-    } else {
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) oc[(size_t)i * P.stride_c + j] = (PIX)tc[i * 36 + j];
+    __syncthreads();
+    const PIX *cp = fr + (pl ? P.plane_off_v : P.plane_off_u);
+    for (int t = lane; t < 36 * 36; t += 64) {
+      const int r = t / 36, c = t % 36;
+      const int gy = (y0 >> 1) + r - 2, gx = (x0 >> 1) + c - 2;
+      g_cdef.t[t] = (gy >= 0 && gx >= 0 && gy < (P.height >> 1) && gx < (P.width >> 1)) ? (uint16_t)cp[(size_t)gy * P.stride_c + gx] : (uint16_t)CDEF_NA;
+    }
+    __syncthreads();
+    const int pri = P.cdef_uv_pri << coeff_shift;
+    const int sec = (P.cdef_uv_sec == 3 ? 4 : P.cdef_uv_sec) << coeff_shift;
+    const int damping = P.cdef_damping + coeff_shift - 1;
+    const int pri_shift = damp_shift(pri, damping), sec_shift = damp_shift(sec, damping);
+    PIX *op = fo + (pl ? P.plane_off_v : P.plane_off_u);
+    const int wc = w >> 1, hc = h >> 1;
+    const int col = lane & 31;
+    if (col < wc) {
+      for (int r = lane >> 5; r < hc; r += 2) {
+        const int b = (r >> 2) * 8 + (col >> 2);
+        const int c = (r + 2) * 36 + col + 2;
+        int v = g_cdef.t[c];
+        if (g_cdef.on[b]) v = cdef_pixel<36>(c, pri, sec, pri_shift, sec_shift, pri == 0 ? 0 : g_cdef.dir[b], coeff_shift);
+        op[(size_t)((y0 >> 1) + r) * P.stride_c + (x0 >> 1) + col] = (PIX)v;
+      }
     }
   }
 }
