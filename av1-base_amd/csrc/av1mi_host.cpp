@@ -352,7 +352,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.dc_recip = (uint32_t)((((uint64_t)1 << 32) + P.dc_q - 1) / P.dc_q);
   P.ac_recip = (uint32_t)((((uint64_t)1 << 32) + P.ac_q - 1) / P.ac_q);
   P.min_bs_log2 = P.max_bs_log2 = (int)p.block_log2;
-  P.mode_mask = 0x1FFF;
+  P.mode_mask = p.reserved[0] ? (p.reserved[0] & 0x1FFF) : 0x0007;  // reserved[0]: intra candidate mask (default DC, V, H)
   P.enable_cdef = p.enable_cdef ? 1 : 0;
   P.cdef_y_pri = p.cdef_y_pri; P.cdef_y_sec = p.cdef_y_sec; P.cdef_uv_pri = p.cdef_uv_pri; P.cdef_uv_sec = p.cdef_uv_sec;
   P.cdef_damping = p.cdef_damping;

@@ -268,11 +268,15 @@ __device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *fra
   const int have_above = y0 > 0, have_left = x0 > 0;
   const int dcv = dc_value<LOG2N>(cx, have_above, have_left);
   // ---- mode decision (luma) + final prediction: one loop, the last trip writes the prediction
-  int best_mode = mode_io, best_sad = 0x7FFFFFFF;
+  int best_mode = mode_io, best_sad = 0x7FFFFFFF, sad_dc = -1;
   const int first = plane == 0 ? 0 : 13;
 #pragma nounroll
   for (int m = first; m <= 13; m++) {
     const bool final_trip = m == 13;
+    if (final_trip && plane == 0) {
+      // DC is kept unless the best other candidate at least halves its SAD
+      if (sad_dc >= 0 && (best_sad == 0x7FFFFFFF || 2 * (long)best_sad >= (long)sad_dc)) best_mode = DC_PRED;
+    }
     const int mode = final_trip ? best_mode : m;
     if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
     int ang = 0, dx = 0, dy = 0;
@@ -297,7 +301,8 @@ __device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *fra
     }
     if (!final_trip) {
       sad = wave_sum(sad);
-      if (sad < best_sad) { best_sad = sad; best_mode = m; }
+      if (m == DC_PRED) sad_dc = sad;
+      else if (sad < best_sad) { best_sad = sad; best_mode = m; }
     }
   }
   mode_io = best_mode;

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--block-log2", type=int, default=5)
     ap.add_argument("--static-cdf", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode-mask", type=int, default=0, help="experiment: intra mode candidate mask (0 = all 13)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +103,7 @@ def main():
     d_frames = torch.frombuffer(bytearray(clip), dtype=torch.uint8).to(dev)  # HBM-resident input
     torch.cuda.synchronize(dev)
     params = av1mi.default_params(w, h, bd, block_log2=args.block_log2, cdf_update=0 if args.static_cdf else 1)
+    params.reserved[0] = args.mode_mask
     ctx = av1mi.Context(local_rank)
 
     def step():

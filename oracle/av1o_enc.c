@@ -95,7 +95,7 @@ void av1o_default_config(Av1oConfig *c, int w, int h, int bit_depth) {
   c->cdef_uv_pri = 1;
   c->cdef_uv_sec = 1;
   c->cdef_damping = 5;
-  c->mode_mask = 0x1FFF;
+  c->mode_mask = 0x0007; /* DC, V, H */
   c->fuzz_density = 8;
   c->fuzz_maxlevel = 40;
 }
@@ -731,13 +731,18 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
       while (!((cfg->mode_mask >> md.uvmode) & 1)) md.uvmode = (md.uvmode + 1) % 13;
       md.uvangle = (md.uvmode >= V_PRED && md.uvmode <= D67_PRED) ? (int)(fuzz_rand(e) % 7) - 3 : 0;
     } else {
+      /* closed-loop SAD over the candidate modes; DC is kept unless the best other
+       * candidate at least halves its SAD (SAD alone over-rates directional modes on gradients). */
+      int sad_dc = -1;
       for (m = 0; m < 13; m++) {
         int sad;
         if (!((cfg->mode_mask >> m) & 1)) continue;
         av1o_predict_intra(pred, n, bsl, m, 0, edge_a, edge_l, avail_u, avail_l, bd);
         sad = block_sad(src, e->src->stride[0], pred, n, n);
+        if (m == DC_PRED) { sad_dc = sad; continue; }
         if (best < 0 || sad < best) { best = sad; md.ymode = m; }
       }
+      if (sad_dc >= 0 && (best < 0 || 2 * (long)best >= (long)sad_dc)) md.ymode = DC_PRED;
       md.uvmode = md.ymode;
     }
     av1o_predict_intra(e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0], bsl, md.ymode, md.yangle,

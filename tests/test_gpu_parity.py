@@ -62,6 +62,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
             continue
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs,
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_cdef=cfgk.get("enable_cdef", 1))
+        p.reserved[0] = cfgk.get("mode_mask", 0)
         for k in ("cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping"):
             if k in cfgk:
                 setattr(p, k, cfgk[k])

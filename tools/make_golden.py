@@ -33,6 +33,8 @@ CASES = [
     ("k64_bs3", 64, 64, 8, 7, 0, dict(min_bs_log2=3, max_bs_log2=3)),
     ("k64_bs6", 64, 64, 8, 7, 0, dict(min_bs_log2=6, max_bs_log2=6)),
     ("k200x120_bs5", 200, 120, 8, 1080, 0, dict(min_bs_log2=5, max_bs_log2=5)),
+    ("k200x120_bs4_all13", 200, 120, 8, 1080, 3, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF)),
+    ("k200x120_bs3_all13_10b", 200, 120, 10, 1080, 4, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF)),
     ("k200x120_bs4", 200, 120, 8, 1080, 1, dict(min_bs_log2=4, max_bs_log2=4)),
     ("k200x120_bs3", 200, 120, 8, 1080, 2, dict(min_bs_log2=3, max_bs_log2=3)),
     ("k200x120_bs5_10b", 200, 120, 10, 1080, 0, dict(min_bs_log2=5, max_bs_log2=5)),
