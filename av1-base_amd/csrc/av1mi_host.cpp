@@ -249,7 +249,8 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
 struct av1mi_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[9] = {};
+  hipStream_t stream2 = nullptr;  // CDEF + SSE run here, beside the entropy kernels on `stream`
+  hipEvent_t ev[12] = {};
   std::string err;
   // workspace (device)
   size_t cap_frames = 0;
@@ -403,7 +404,8 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   av1mi_ctx *c = new (std::nothrow) av1mi_ctx();
   if (!c) return AV1MI_E_OOM;
   c->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return AV1MI_E_NO_DEVICE;
   }
@@ -419,6 +421,7 @@ void av1mi_ctx_destroy(av1mi_ctx *c) {
   free_workspace(c);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
 
@@ -460,11 +463,19 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   HIPCHK(c, av1mi_launch_recon(&P, d_src, c->d_rec, c->d_levels, c->d_blk, s));
   HIPCHK(c, hipEventRecord(c->ev[2], s));
-  HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s));
-  HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s));
+  // CDEF (+SSE) depends only on the reconstruction.  The range-coding kernel is a latency-bound
+  // serial chain (one lane per tile: 480 waves, half the SIMDs idle), so CDEF runs beside IT on a
+  // second stream; symbolize and CDEF are both throughput-bound and would only slow each other.
+  hipStream_t s2 = c->stream2;
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, s, c->ev[7]));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
+  HIPCHK(c, hipStreamWaitEvent(s2, c->ev[7], 0));  // ev[7]: recorded between symbolize and range-code
+  HIPCHK(c, hipEventRecord(c->ev[8], s2));
+  HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s2));
+  HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s2));
+  HIPCHK(c, hipEventRecord(c->ev[9], s2));
+  HIPCHK(c, hipStreamWaitEvent(s, c->ev[9], 0));  // join: everything below sees the CDEF output too
   HIPCHK(c, av1mi_launch_pack(&P, c->d_slots, c->d_tile_bytes, c->d_tile_off, c->d_frame_size, c->d_payload, c->d_frame_off, c->d_hdr,
                               c->d_out, c->d_overflow, 0, s));
   HIPCHK(c, av1mi_launch_pack(&P, c->d_slots, c->d_tile_bytes, c->d_tile_off, c->d_frame_size, c->d_payload, c->d_frame_off, c->d_hdr,
@@ -523,7 +534,7 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
     for (uint32_t v : syms) report->n_symbols += v;
     (void)hipEventElapsedTime(&report->ms_h2d, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&report->ms_recon, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&report->ms_cdef, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&report->ms_cdef, c->ev[8], c->ev[9]);
     (void)hipEventElapsedTime(&report->ms_entropy, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&report->ms_symbolize, c->ev[3], c->ev[7]);
     (void)hipEventElapsedTime(&report->ms_pack, c->ev[4], c->ev[5]);

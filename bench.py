@@ -119,13 +119,13 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    stage = {"recon": 0.0, "cdef": 0.0, "entropy": 0.0, "pack": 0.0, "d2h": 0.0}
+    stage = {"recon": 0.0, "cdef": 0.0, "entropy": 0.0, "symbolize": 0.0, "pack": 0.0, "d2h": 0.0}
     last = None
     for _ in range(args.steps):
         data, sizes, rep, _ = step()
         last = (data, rep)
         stage["recon"] += rep.ms_recon; stage["cdef"] += rep.ms_cdef; stage["entropy"] += rep.ms_entropy
-        stage["pack"] += rep.ms_pack; stage["d2h"] += rep.ms_d2h
+        stage["pack"] += rep.ms_pack; stage["d2h"] += rep.ms_d2h; stage["symbolize"] += rep.ms_symbolize
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
