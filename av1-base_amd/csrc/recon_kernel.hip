@@ -57,6 +57,7 @@ struct SbLds {
   uint16_t edge_l[2 * 64 + 8];
   uint8_t blkdec[2][19][19];    // luma, chroma (U and V decode together)
   uint8_t smw[64];              // smooth weights of the current block size
+  int eobs[4];                  // eob of the current block's Y, U, V transform blocks
 };
 __shared__ SbLds g_sb;
 #define S (&g_sb)
@@ -121,11 +122,11 @@ __device__ __forceinline__ int scan_index(int row, int col, int n) {
 }
 
 // ---- intra prediction of one pixel (spec §7.11.2, no edge filter / upsampling) -------------------
-// A = edge_a + 1, L = edge_l + 1 (index -1 valid); dx/dy = Dr_Intra_Derivative values of the mode.
+// A = edge_a + 1 (+ group offset), L likewise (index -1 valid); dx/dy = Dr_Intra_Derivative values.
 template <int LOG2N>
-__device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int ang, int dx, int dy) {
+__device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int ang, int dx, int dy, int eo) {
   constexpr int N = 1 << LOG2N;
-  const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
+  const uint16_t *A = S->edge_a + 1 + eo, *L = S->edge_l + 1 + eo;
   switch (mode) {
     case DC_PRED: return dcval;
     case V_PRED: return A[c];
@@ -180,100 +181,97 @@ struct SbCtx {
   int sb_x, sb_y;          // superblock origin in luma pixels
 };
 
-// Fill edge_a / edge_l for an n x n block at (x0, y0) of `plane` (plane-local pixel coordinates
-// inside the superblock) from the line buffers.  Tile == superblock: nothing outside it is available.
-template <int LOG2N>
-__device__ __forceinline__ void prepare_edges(const SbCtx &cx, int plane, int x0, int y0, int have_ar, int have_bl) {
-  constexpr int N = 1 << LOG2N;
-  const int bd = cx.P->bit_depth;
-  const int have_above = y0 > 0, have_left = x0 > 0;
-  // frame limits in superblock-local coordinates of this plane
-  const int max_x = ((plane ? cx.P->width >> 1 : cx.P->width) - 1) - (plane ? cx.sb_x >> 1 : cx.sb_x);
-  const int max_y = ((plane ? cx.P->height >> 1 : cx.P->height) - 1) - (plane ? cx.sb_y >> 1 : cx.sb_y);
-  for (int i = cx.lane; i < 2 * N; i += 64) {
-    int a, l;
-    if (!have_above && have_left) a = S->left[plane][y0];           // pixel (y0, x0-1)
-    else if (!have_above) a = (1 << (bd - 1)) - 1;
-    else {
-      int lim = x0 + (have_ar ? 2 * N : N) - 1;
-      if (lim > max_x) lim = max_x;
-      a = S->above[plane][x0 + i < lim ? x0 + i : lim];             // pixel (y0-1, .)
-    }
-    if (!have_left && have_above) l = S->above[plane][x0];          // pixel (y0-1, x0)
-    else if (!have_left) l = (1 << (bd - 1)) + 1;
-    else {
-      int lim = y0 + (have_bl ? 2 * N : N) - 1;
-      if (lim > max_y) lim = max_y;
-      l = S->left[plane][y0 + i < lim ? y0 + i : lim];              // pixel (., x0-1)
-    }
-    S->edge_a[1 + i] = (uint16_t)a;
-    S->edge_l[1 + i] = (uint16_t)l;
-  }
-  if (cx.lane == 0) {
-    int tl;
-    if (have_above && have_left) tl = S->corner[plane][y0 >> 2][x0 >> 2];
-    else if (have_above) tl = S->above[plane][x0];
-    else if (have_left) tl = S->left[plane][y0];
-    else tl = 1 << (bd - 1);
-    S->edge_a[0] = (uint16_t)tl;
-    S->edge_l[0] = (uint16_t)tl;
-  }
-  {  // smooth weights of this size
-    constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
-    if (cx.lane < N) S->smw[cx.lane] = c_sm_weights[WOFF + cx.lane];
-  }
-  __syncthreads();
-}
-
-template <int LOG2N>
-__device__ __forceinline__ int dc_value(const SbCtx &cx, int have_above, int have_left) {
-  constexpr int N = 1 << LOG2N;
-  int s = 0;
-  if (cx.lane < N) s = (have_above ? S->edge_a[1 + cx.lane] : 0) + (have_left ? S->edge_l[1 + cx.lane] : 0);
-  s = wave_sum(s);
-  if (have_above && have_left) return (s + N) >> (LOG2N + 1);
-  if (have_above || have_left) return (s + (N >> 1)) >> LOG2N;
-  return 1 << (cx.P->bit_depth - 1);
-}
-
-// One transform block of `plane` at plane-local (x0, y0): [luma: mode decision by closed-loop SAD,
-// first minimum in mode order wins] -> prediction -> forward transform -> dead-zone quantiser ->
-// normative dequantiser + inverse transform -> reconstruction (to HBM + line buffers).
-// `mode_io`: in = mode to use (chroma), out = decided mode (luma).  Returns eob.
-// Exactly one instantiation per size exists (see the plane loop in encode_superblock).
-template <typename PIX, int LOG2N>
-__device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane, int x0, int y0, int &mode_io,
-                                       int16_t *lv_out) {
+// One transform block per lane GROUP.  NPL = 1: the whole wave works on one block of `plane0` (luma,
+// with the mode decision).  NPL = 2: lanes 0-31 work on the U block and lanes 32-63 on the V block of
+// the same position at the same time (same mode, independent data) - chroma transforms are at most
+// 16 wide, so this doubles the lanes that do useful work.  Steps: [luma: mode decision by closed-loop
+// SAD, DESIGN.md §3.3] -> prediction -> forward transform -> dead-zone quantiser -> normative
+// dequantiser + inverse transform -> reconstruction (HBM + line buffers).
+// `mode_io`: in = mode to use (chroma), out = decided mode (luma).  eob_out[g] = eob of group g.
+template <typename PIX, int LOG2N, int NPL>
+__device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
+                                                  int &mode_io, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
   constexpr int N = 1 << LOG2N;
   constexpr int ST = N + 1;
+  constexpr int G = 64 / NPL;              // lanes per group
+  constexpr int PIXO = NPL == 1 ? 0 : 512; // per-group offset inside srcblk / blkpix (N*N <= 256 when NPL == 2)
+  constexpr int SCRO = NPL == 1 ? 0 : 16 * 17;
+  constexpr int EDGO = NPL == 1 ? 0 : 68;
   const Av1miDevParams *P = cx.P;
   const int lane = cx.lane;
+  const int grp = NPL == 1 ? 0 : lane >> 5, sl = NPL == 1 ? lane : lane & 31;
+  const int plane = plane0 + grp;
+  const int po = grp * PIXO, so = grp * SCRO, eo = grp * EDGO;
   const int bd = P->bit_depth;
   // decoded-block map lookups (spec §5.11.35): above-right / below-left availability
-  const int pc = plane > 0;
+  const int pc = plane0 > 0;
   const int r4 = y0 >> 2, c4 = x0 >> 2;
   constexpr int step = (N >> 2) > 0 ? (N >> 2) : 1;
   const int have_ar = S->blkdec[pc][r4 - 1 + 1][c4 + step + 1];
   const int have_bl = S->blkdec[pc][r4 + step + 1][c4 - 1 + 1];
   const long poff = plane == 0 ? 0 : (plane == 1 ? P->plane_off_u : P->plane_off_v);
-  const int gs = plane ? P->stride_c : P->stride_y;
-  const int gx = (plane ? cx.sb_x >> 1 : cx.sb_x) + x0, gy = (plane ? cx.sb_y >> 1 : cx.sb_y) + y0;
-  // source block -> LDS (coalesced rows)
+  const int gs = plane0 ? P->stride_c : P->stride_y;
+  const int gx = (plane0 ? cx.sb_x >> 1 : cx.sb_x) + x0, gy = (plane0 ? cx.sb_y >> 1 : cx.sb_y) + y0;
+  const int have_above = y0 > 0, have_left = x0 > 0;
+  // ---- source block -> LDS (coalesced rows)
   {
     const PIX *pl = frame + poff;
 #pragma unroll 4
-    for (int p = lane; p < N * N; p += 64) S->srcblk[p] = (uint16_t)pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))];
+    for (int p = sl; p < N * N; p += G) S->srcblk[po + p] = (uint16_t)pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))];
   }
-  prepare_edges<LOG2N>(cx, plane, x0, y0, have_ar, have_bl);
-  const int have_above = y0 > 0, have_left = x0 > 0;
-  const int dcv = dc_value<LOG2N>(cx, have_above, have_left);
+  // ---- edges from the line buffers (spec §7.11.2; tile == superblock: nothing outside it is available)
+  {
+    const int max_x = ((plane0 ? P->width >> 1 : P->width) - 1) - (plane0 ? cx.sb_x >> 1 : cx.sb_x);
+    const int max_y = ((plane0 ? P->height >> 1 : P->height) - 1) - (plane0 ? cx.sb_y >> 1 : cx.sb_y);
+    for (int i = sl; i < 2 * N; i += G) {
+      int a, l;
+      if (!have_above && have_left) a = S->left[plane][y0];           // pixel (y0, x0-1)
+      else if (!have_above) a = (1 << (bd - 1)) - 1;
+      else {
+        int lim = x0 + (have_ar ? 2 * N : N) - 1;
+        if (lim > max_x) lim = max_x;
+        a = S->above[plane][x0 + i < lim ? x0 + i : lim];             // pixel (y0-1, .)
+      }
+      if (!have_left && have_above) l = S->above[plane][x0];          // pixel (y0-1, x0)
+      else if (!have_left) l = (1 << (bd - 1)) + 1;
+      else {
+        int lim = y0 + (have_bl ? 2 * N : N) - 1;
+        if (lim > max_y) lim = max_y;
+        l = S->left[plane][y0 + i < lim ? y0 + i : lim];              // pixel (., x0-1)
+      }
+      S->edge_a[eo + 1 + i] = (uint16_t)a;
+      S->edge_l[eo + 1 + i] = (uint16_t)l;
+    }
+    if (sl == 0) {
+      int tl;
+      if (have_above && have_left) tl = S->corner[plane][y0 >> 2][x0 >> 2];
+      else if (have_above) tl = S->above[plane][x0];
+      else if (have_left) tl = S->left[plane][y0];
+      else tl = 1 << (bd - 1);
+      S->edge_a[eo] = (uint16_t)tl;
+      S->edge_l[eo] = (uint16_t)tl;
+    }
+    constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
+    if (lane < N) S->smw[lane] = c_sm_weights[WOFF + lane];
+  }
+  __syncthreads();
+  // ---- DC value (sum within the lane group)
+  int dcv;
+  {
+    int s = 0;
+    if (sl < N) s = (have_above ? S->edge_a[eo + 1 + sl] : 0) + (have_left ? S->edge_l[eo + 1 + sl] : 0);
+    for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (have_above && have_left) dcv = (s + N) >> (LOG2N + 1);
+    else if (have_above || have_left) dcv = (s + (N >> 1)) >> LOG2N;
+    else dcv = 1 << (bd - 1);
+  }
   // ---- mode decision (luma) + final prediction: one loop, the last trip writes the prediction
   int best_mode = mode_io, best_sad = 0x7FFFFFFF, sad_dc = -1;
-  const int first = plane == 0 ? 0 : 13;
+  const int first = (NPL == 1 && plane0 == 0) ? 0 : 13;
 #pragma nounroll
   for (int m = first; m <= 13; m++) {
     const bool final_trip = m == 13;
-    if (final_trip && plane == 0) {
+    if (final_trip && NPL == 1 && plane0 == 0) {
       // DC is kept unless the best other candidate at least halves its SAD
       if (sad_dc >= 0 && (best_sad == 0x7FFFFFFF || 2 * (long)best_sad >= (long)sad_dc)) best_mode = DC_PRED;
     }
@@ -288,13 +286,13 @@ __device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *fra
     }
     int sad = 0;
 #pragma unroll 4
-    for (int p = lane; p < N * N; p += 64) {
+    for (int p = sl; p < N * N; p += G) {
       const int r = p >> LOG2N, c = p & (N - 1);
-      const int pv = pred_pixel<LOG2N>(mode, r, c, dcv, ang, dx, dy);
-      const int sv = S->srcblk[p];
+      const int pv = pred_pixel<LOG2N>(mode, r, c, dcv, ang, dx, dy, eo);
+      const int sv = S->srcblk[po + p];
       if (final_trip) {
-        S->blkpix[p] = (uint16_t)pv;
-        S->scratch[r * ST + c] = (int16_t)(sv - pv);
+        S->blkpix[po + p] = (uint16_t)pv;
+        S->scratch[so + r * ST + c] = (int16_t)(sv - pv);
       } else {
         sad += iabs(sv - pv);
       }
@@ -314,21 +312,22 @@ __device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *fra
   constexpr int RS = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : 2);
   constexpr int TSH = LOG2N == 5 ? 1 : 0;  // dequant shift of the size class (§7.12.3)
   int32_t x[N];
-  if (lane < N) {
+  const bool tx_lane = sl < N;
+  if (tx_lane) {
 #pragma unroll
-    for (int i = 0; i < N; i++) x[i] = (int)S->scratch[i * ST + lane] << SH0;
+    for (int i = 0; i < N; i++) x[i] = (int)S->scratch[so + i * ST + sl] << SH0;
     Tx1d<LOG2N>::fwd(x, vt);
 #pragma unroll
-    for (int i = 0; i < N; i++) S->scratch[i * ST + lane] = (int16_t)rshift_round(x[i], SH1);
+    for (int i = 0; i < N; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
   }
   __syncthreads();
-  int my_eob = 0;
-  if (lane < N) {
-    const int row = lane;
+  int my_key = -1;  // (anti-diagonal << 6 | position inside it) of the last nonzero level in scan order
+  int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk) + po;  // source block is dead: reuse for the levels
+  if (tx_lane) {
+    const int row = sl;
 #pragma unroll
-    for (int j = 0; j < N; j++) x[j] = S->scratch[row * ST + j];
+    for (int j = 0; j < N; j++) x[j] = S->scratch[so + row * ST + j];
     Tx1d<LOG2N>::fwd(x, ht);
-    int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk);  // source block is dead: reuse for the levels
 #pragma unroll
     for (int j = 0; j < N; j++) {
       const int v = x[j];
@@ -336,15 +335,17 @@ __device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *fra
       const uint32_t q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
       const uint32_t recip = dc ? P->dc_recip : P->ac_recip;
       // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above
-      const uint32_t rnd = (row + j) < (N >> 2) ? (3 * q) >> 3 : ((row + j) < (N >> 1) ? (q >> 2) : (q >> 3));
+      const int d0 = row + j;
+      const uint32_t rnd = d0 < (N >> 2) ? (3 * q) >> 3 : (d0 < (N >> 1) ? (q >> 2) : (q >> 3));
       const uint32_t a = ((uint32_t)iabs(v) << TSH) + rnd;
       uint32_t lv = __umulhi(a, recip);
       if (lv > 0x7FFF) lv = 0x7FFF;
       lvl[row * N + j] = (int16_t)(v < 0 ? -(int)lv : (int)lv);
       int d = 0;
       if (lv) {
-        const int si = scan_index(row, j, N) + 1;
-        my_eob = si > my_eob ? si : my_eob;
+        // scan order: by anti-diagonal, odd ones by increasing row, even ones by increasing column
+        const int key = (d0 << 6) | ((d0 & 1) ? row : j);
+        my_key = key > my_key ? key : my_key;
         d = (int)(((uint32_t)lv * q) & 0xFFFFFF) >> TSH;
         const int lim = 1 << (7 + bd);
         d = v < 0 ? -d : d;
@@ -353,54 +354,53 @@ __device__ __attribute__((noinline)) int tx_item(const SbCtx &cx, const PIX *fra
       x[j] = d;
     }
   }
-  const int eob = wave_max(my_eob);
-  if (eob) {
-    if (lane < N) {
-      Tx1d<LOG2N>::inv(x, ht);
+  for (int o = G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(my_key, o, 64); my_key = t > my_key ? t : my_key; }
+  int eob = 0;
+  if (my_key >= 0) {
+    const int d0 = my_key >> 6, w = my_key & 63;
+    eob = scan_index((d0 & 1) ? w : d0 - w, (d0 & 1) ? d0 - w : w, N) + 1;
+  }
+  if (tx_lane && eob) {
+    Tx1d<LOG2N>::inv(x, ht);
 #pragma unroll
-      for (int j = 0; j < N; j++) S->scratch[lane * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
-    }
-    __syncthreads();
-    if (lane < N) {
-      const int maxv = (1 << bd) - 1;
+    for (int j = 0; j < N; j++) S->scratch[so + sl * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
+  }
+  __syncthreads();
+  if (tx_lane && eob) {
+    const int maxv = (1 << bd) - 1;
 #pragma unroll
-      for (int i = 0; i < N; i++) x[i] = S->scratch[i * ST + lane];
-      Tx1d<LOG2N>::inv(x, vt);
+    for (int i = 0; i < N; i++) x[i] = S->scratch[so + i * ST + sl];
+    Tx1d<LOG2N>::inv(x, vt);
 #pragma unroll
-      for (int i = 0; i < N; i++) {
-        int v = S->blkpix[i * N + lane] + ((x[i] + 8) >> 4);
-        S->blkpix[i * N + lane] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
-      }
+    for (int i = 0; i < N; i++) {
+      int v = S->blkpix[po + i * N + sl] + ((x[i] + 8) >> 4);
+      S->blkpix[po + i * N + sl] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
     }
-    // levels out (coalesced 32-bit words)
-    {
-      constexpr int WORDS = N * N / 2;
-      const int16_t *lvl = reinterpret_cast<const int16_t *>(S->srcblk);
-      uint32_t *d32 = reinterpret_cast<uint32_t *>(lv_out);
-      for (int i = lane; i < WORDS; i += 64) d32[i] = (uint32_t)(uint16_t)lvl[2 * i] | ((uint32_t)(uint16_t)lvl[2 * i + 1] << 16);
-    }
+  }
+  if (eob) {  // levels out (32-bit words, coalesced inside the group)
+    constexpr int WORDS = N * N / 2;
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(grp ? lv_out1 : lv_out0);
+    for (int i = sl; i < WORDS; i += G) d32[i] = (uint32_t)(uint16_t)lvl[2 * i] | ((uint32_t)(uint16_t)lvl[2 * i + 1] << 16);
   }
   __syncthreads();
   // ---- reconstruction -> HBM (coalesced rows) and -> line buffers for the neighbours to come
   {
     PIX *pl = rec_frame + poff;
 #pragma unroll 4
-    for (int p = lane; p < N * N; p += 64) pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))] = (PIX)S->blkpix[p];
-    if (lane < N) {
-      S->above[plane][x0 + lane] = S->blkpix[(N - 1) * N + lane];
-      S->left[plane][y0 + lane] = S->blkpix[lane * N + (N - 1)];
+    for (int p = sl; p < N * N; p += G) pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))] = (PIX)S->blkpix[po + p];
+    if (sl < N) {
+      S->above[plane][x0 + sl] = S->blkpix[po + (N - 1) * N + sl];
+      S->left[plane][y0 + sl] = S->blkpix[po + sl * N + (N - 1)];
     }
-    if (lane < step) {  // corners at every 4-aligned position of the bottom row and right column
-      const int j = lane + 1;
-      S->corner[plane][(y0 + N) >> 2][(x0 >> 2) + j] = S->blkpix[(N - 1) * N + 4 * j - 1];
-      S->corner[plane][(y0 >> 2) + j][(x0 + N) >> 2] = S->blkpix[(4 * j - 1) * N + (N - 1)];
+    if (sl < step) {  // corners at every 4-aligned position of the bottom row and right column
+      const int j = sl + 1;
+      S->corner[plane][(y0 + N) >> 2][(x0 >> 2) + j] = S->blkpix[po + (N - 1) * N + 4 * j - 1];
+      S->corner[plane][(y0 >> 2) + j][(x0 + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
     }
-    if (plane != 1) {  // chroma map is shared by U and V: mark after V
-      for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
-    }
+    for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
   }
+  if (sl == 0) eob_out[grp] = eob;
   __syncthreads();
-  return eob;
 }
 
 // Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
@@ -433,30 +433,29 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
     if (bsl == 0) continue;
     const int n = 1 << bsl;
-    int mode = 0, eobs[3] = { 0, 0, 0 };
-    // the three planes of a leaf block run through ONE dispatch so that each size is instantiated once
-#pragma nounroll
-    for (int pl = 0; pl < 3; pl++) {
-      const int l2 = pl ? bsl - 1 : bsl;
-      const int x0 = pl ? bx >> 1 : bx, y0 = pl ? by >> 1 : by;
-      int16_t *lv = pl == 0 ? sb_levels + by * 64 + bx * n : sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * (n >> 1);
-      int e;
-      switch (l2) {
-        case 5: e = tx_item<PIX, 5>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
-        case 4: e = tx_item<PIX, 4>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
-        case 3: e = tx_item<PIX, 3>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
-        default: e = tx_item<PIX, 2>(cx, frame, rec_frame, pl, x0, y0, mode, lv); break;
-      }
-      if (pl == 0) eobs[0] = e; else if (pl == 1) eobs[1] = e; else eobs[2] = e;
+    int mode = 0;
+    int16_t *lv_y = sb_levels + by * 64 + bx * n;
+    int16_t *lv_u = sb_levels + 4096 + (by >> 1) * 32 + (bx >> 1) * (n >> 1), *lv_v = lv_u + 1024;
+    // luma (mode decision inside), then U and V together
+    switch (bsl) {
+      case 5: tx_item<PIX, 5, 1>(cx, frame, rec_frame, 0, bx, by, mode, lv_y, lv_y, S->eobs); break;
+      case 4: tx_item<PIX, 4, 1>(cx, frame, rec_frame, 0, bx, by, mode, lv_y, lv_y, S->eobs); break;
+      default: tx_item<PIX, 3, 1>(cx, frame, rec_frame, 0, bx, by, mode, lv_y, lv_y, S->eobs); break;
     }
-    const int skip = (eobs[0] | eobs[1] | eobs[2]) == 0;
+    switch (bsl) {
+      case 5: tx_item<PIX, 4, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, lv_u, lv_v, S->eobs + 1); break;
+      case 4: tx_item<PIX, 3, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, lv_u, lv_v, S->eobs + 1); break;
+      default: tx_item<PIX, 2, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, lv_u, lv_v, S->eobs + 1); break;
+    }
     if (cx.lane == 0) {
+      const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
+      const int skip = (e0 | e1 | e2) == 0;
       const int n8 = n >> 3;
       for (int i = 0; i < n8; i++)
         for (int j = 0; j < n8; j++) {
           Av1miBlkInfo bi;
           bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)skip; bi.bsl = (uint8_t)bsl; bi.pad = 0;
-          bi.eob[0] = (uint16_t)eobs[0]; bi.eob[1] = (uint16_t)eobs[1]; bi.eob[2] = (uint16_t)eobs[2]; bi.pad2 = 0;
+          bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2; bi.pad2 = 0;
           info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
         }
     }
