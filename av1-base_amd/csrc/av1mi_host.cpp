@@ -86,7 +86,7 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.keyint != 1) return AV1MI_E_UNSUPPORTED;
   if (p.block_log2 == 0) p.block_log2 = 5;
   if (p.block_log2 < 3 || p.block_log2 > 5) return AV1MI_E_INVALID_ARG;
-  if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 1; p.cdef_uv_pri = 1; p.cdef_uv_sec = 1; p.cdef_damping = 5; }
+  if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
   r->sb_cols = (p.width + 63) / 64;
@@ -379,7 +379,7 @@ void av1mi_default_params(av1mi_params *p, uint32_t w, uint32_t h, uint32_t bd) 
   memset(p, 0, sizeof(*p));
   p->width = w; p->height = h; p->bit_depth = bd;
   p->cq_level = 30; p->keyint = 1; p->block_log2 = 5; p->cdf_update = 1; p->enable_cdef = 1;
-  p->cdef_y_pri = 2; p->cdef_y_sec = 1; p->cdef_uv_pri = 1; p->cdef_uv_sec = 1; p->cdef_damping = 5;
+  p->cdef_y_pri = 2; p->cdef_y_sec = 0; p->cdef_uv_pri = 1; p->cdef_uv_sec = 0; p->cdef_damping = 5;
 }
 
 int av1mi_write_headers(const av1mi_params *p, uint8_t *seq_hdr, size_t *seq_len, uint8_t *frame_hdr, size_t *frame_hdr_bits) {

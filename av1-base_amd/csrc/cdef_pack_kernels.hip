@@ -70,15 +70,17 @@ __device__ __forceinline__ int cdef_pixel(int c, int pri, int sec, int pri_shift
           mn = p < mn ? p : mn;
         }
       }
-      {
+      // with sec == 0 the secondary taps add nothing to the sum and cannot change the clamp either
+      // (|sum| / 16 <= 12/16 of the largest primary difference), so they are not even read
+      if (sec) {
         const int s1 = t[c + sg * o2], s2 = t[c + sg * o1];  // dir-2, dir+2 (order is irrelevant to the result)
         if (s1 != CDEF_NA) {
-          if (sec) sum += stap * constrain(s1 - x, sec, sec_shift);
+          sum += stap * constrain(s1 - x, sec, sec_shift);
           mx = s1 > mx ? s1 : mx;
           mn = s1 < mn ? s1 : mn;
         }
         if (s2 != CDEF_NA) {
-          if (sec) sum += stap * constrain(s2 - x, sec, sec_shift);
+          sum += stap * constrain(s2 - x, sec, sec_shift);
           mx = s2 > mx ? s2 : mx;
           mn = s2 < mn ? s2 : mn;
         }
@@ -195,8 +197,8 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
         const int b = (r >> 3) * 8 + (lane >> 3);
         const int c = (r + 2) * 68 + lane + 2;
         int v = g_cdef.t[c];
-        if (g_cdef.on[b]) {
-          const int pri = g_cdef.pri_y[b];
+        const int pri = g_cdef.on[b] ? (int)g_cdef.pri_y[b] : 0;
+        if (g_cdef.on[b] && (pri | sec)) {
           const int dir = ypri0 == 0 ? 0 : g_cdef.dir[b];
           v = cdef_pixel<68>(c, pri, sec, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
         }
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
         const int b = (r >> 2) * 8 + (col >> 2);
         const int c = (r + 2) * 36 + col + 2;
         int v = g_cdef.t[c];
-        if (g_cdef.on[b]) v = cdef_pixel<36>(c, pri, sec, pri_shift, sec_shift, pri == 0 ? 0 : g_cdef.dir[b], coeff_shift);
+        if (g_cdef.on[b] && (pri | sec)) v = cdef_pixel<36>(c, pri, sec, pri_shift, sec_shift, pri == 0 ? 0 : g_cdef.dir[b], coeff_shift);
         op[(size_t)((y0 >> 1) + r) * P.stride_c + (x0 >> 1) + col] = (PIX)v;
       }
     }

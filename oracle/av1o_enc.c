@@ -91,9 +91,9 @@ void av1o_default_config(Av1oConfig *c, int w, int h, int bit_depth) {
   c->max_bs_log2 = 4;
   c->enable_cdef = 1;
   c->cdef_y_pri = 2;
-  c->cdef_y_sec = 1;
+  c->cdef_y_sec = 0;
   c->cdef_uv_pri = 1;
-  c->cdef_uv_sec = 1;
+  c->cdef_uv_sec = 0;
   c->cdef_damping = 5;
   c->mode_mask = 0x0007; /* DC, V, H */
   c->fuzz_density = 8;
