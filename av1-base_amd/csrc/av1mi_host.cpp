@@ -531,7 +531,7 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
       const double npx = (double)n_frames * P.width * P.height / (pl ? 4 : 1);
       report->psnr[pl] = t > 0 ? 10.0 * log10(mx * mx * npx / t) : 99.0;
     }
-    for (uint32_t v : syms) report->n_symbols += v;
+    for (uint32_t v : syms) { report->n_symbols += v; if (v > report->max_tile_symbols) report->max_tile_symbols = v; }
     (void)hipEventElapsedTime(&report->ms_h2d, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&report->ms_recon, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&report->ms_cdef, c->ev[8], c->ev[9]);

@@ -446,91 +446,92 @@ __global__ void __launch_bounds__(64) rangecode_tiles_kernel(Av1miDevParams P, i
   }
   // ---- per-lane range coder
   uint32_t low = 0, rng = 0x8000;
-  int cnt = -9, pending = -1, ff_run = 0, out_pos = 0;
+  int cnt = -9, out_pos = 0;
   uint32_t acc = 0;  // up to 3 buffered output bytes
   uint8_t *const out = slots + (size_t)(live ? tile : 0) * P.tile_slot_bytes;
   const int out_cap = P.tile_slot_bytes;
   const uint32_t *st = streams + (size_t)(live ? tile : 0) * P.stream_cap;
   const int adapt = !P.disable_cdf_update;
 
-#define RAW_BYTE(b_)                                                                     \
-  do {                                                                                   \
-    acc |= (uint32_t)((b_) & 0xFF) << (8 * (out_pos & 3));                               \
-    out_pos++;                                                                           \
-    if ((out_pos & 3) == 0) {                                                            \
-      if (out_pos <= out_cap) *reinterpret_cast<uint32_t *>(out + out_pos - 4) = acc;    \
-      acc = 0;                                                                           \
-    }                                                                                    \
-  } while (0)
-#define PUT_BYTE(v_)                                                                     \
-  do {                                                                                   \
-    const unsigned pv = (v_);                                                            \
-    const int carry = (pv >> 8) & 1, pb = pv & 0xFF;                                     \
-    if (carry) {                                                                         \
-      RAW_BYTE(pending + 1);                                                             \
-      for (int q = 0; q < ff_run; q++) RAW_BYTE(0x00);                                   \
-      ff_run = 0;                                                                        \
-      pending = pb;                                                                      \
-    } else if (pb == 0xFF) {                                                             \
-      if (pending < 0) pending = pb; else ff_run++;                                      \
-    } else {                                                                             \
-      if (pending >= 0) RAW_BYTE(pending);                                               \
-      for (int q = 0; q < ff_run; q++) RAW_BYTE(0xFF);                                   \
-      ff_run = 0;                                                                        \
-      pending = pb;                                                                      \
-    }                                                                                    \
+  // Output: append-only big-endian byte string.  A carry out of the coder (bit 8 of an emitted value)
+  // adds 1 to the number formed by the bytes written so far - first inside the partially filled
+  // word `acc`, then (rare) by read-modify-write of bytes already in HBM.
+#define EMIT(v_)                                                                               \
+  do {                                                                                         \
+    const unsigned ev = (v_);                                                                  \
+    if (ev & 0x100u) {                                                                         \
+      int k = out_pos - 1;                                                                     \
+      for (; k >= (out_pos & ~3); k--) {                                                       \
+        const int sh = 8 * (k & 3);                                                            \
+        if (((acc >> sh) & 0xFF) == 0xFF) acc &= ~(0xFFu << sh);                               \
+        else { acc += 1u << sh; k = -2; break; }                                               \
+      }                                                                                        \
+      for (; k >= 0; k--) {                                                                    \
+        const unsigned ob = out[k];                                                            \
+        if (ob == 0xFF) out[k] = 0;                                                            \
+        else { out[k] = (uint8_t)(ob + 1); break; }                                            \
+      }                                                                                        \
+    }                                                                                          \
+    acc |= (ev & 0xFFu) << (8 * (out_pos & 3));                                                \
+    out_pos++;                                                                                 \
+    if ((out_pos & 3) == 0) {                                                                  \
+      if (out_pos <= out_cap) *reinterpret_cast<uint32_t *>(out + out_pos - 4) = acc;          \
+      acc = 0;                                                                                 \
+    }                                                                                          \
   } while (0)
 
   const int n_iter = overflow ? 0 : count;
-  uint4 buf = make_uint4(0, 0, 0, 0);
+  // stream entries arrive 4 at a time (16 B per lane); the load of the NEXT four is in flight while
+  // the current four are coded.  stream_cap is a multiple of 4: reading a whole group is always in
+  // bounds of the tile's stream.
+  uint4 buf = make_uint4(0, 0, 0, 0), nxt = make_uint4(0, 0, 0, 0);
+  if (n_iter > 0) nxt = *reinterpret_cast<const uint4 *>(st);
   for (int i = 0; i < n_iter; i++) {
-    if ((i & 3) == 0) buf = *reinterpret_cast<const uint4 *>(st + i);  // stream_cap is a multiple of 4
+    if ((i & 3) == 0) {
+      buf = nxt;
+      if (i + 4 < n_iter) nxt = *reinterpret_cast<const uint4 *>(st + i + 4);
+    }
     const uint32_t ent = (i & 3) == 0 ? buf.x : ((i & 3) == 1 ? buf.y : ((i & 3) == 2 ? buf.z : buf.w));
-    uint32_t fl6, fh6;
-    int ns;
-    if (ent & 0x80000000u) {
-      fl6 = (ent >> 14) & 0x3FF; fh6 = (ent >> 4) & 0x3FF; ns = ent & 15;
-    } else {
+    uint32_t fl6 = (ent >> 14) & 0x3FF, fh6 = (ent >> 4) & 0x3FF;
+    int ns = ent & 15;
+    if (!(ent & 0x80000000u)) {
       const int slot = (ent >> 2) & 0x1FF, s = ent & 3;
-      uint64_t rw = g_rc.row[slot][lane];
-      const uint32_t c0 = rw & 0xFFFF, c1 = (rw >> 16) & 0xFFFF, c2 = (rw >> 32) & 0xFFFF, cn = (uint32_t)(rw >> 48);
-      const uint32_t fl = s == 0 ? 32768u : (s == 1 ? c0 : (s == 2 ? c1 : c2));
-      const uint32_t fh = s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : 0u));
+      const uint64_t rw = g_rc.row[slot][lane];
+      const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
+      // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): 16-bit fields of the row
+      const uint64_t cdf48 = rw & 0x0000FFFFFFFFFFFFull;
+      const uint32_t fh = s == 3 ? 0u : (uint32_t)(cdf48 >> (16 * s)) & 0xFFFFu;
+      const uint32_t fl = s == 0 ? 32768u : (uint32_t)(cdf48 >> (16 * (s - 1))) & 0xFFFFu;
       fl6 = fl >> 6; fh6 = fh >> 6; ns = 3 - s;
       if (adapt) {
+        const uint32_t cn = c2n >> 16;
         const int rate = 5 + (cn > 15) + (cn > 31);
+        const uint32_t c0 = c01 & 0xFFFF, c1 = c01 >> 16, c2 = c2n & 0xFFFF;
         const uint32_t n0 = 0 < s ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
         const uint32_t n1 = 1 < s ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
         const uint32_t n2 = 2 < s ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
-        rw = (uint64_t)n0 | ((uint64_t)n1 << 16) | ((uint64_t)n2 << 32) | ((uint64_t)(cn + (cn < 32)) << 48);
-        g_rc.row[slot][lane] = rw;
+        g_rc.row[slot][lane] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | ((cn + (cn < 32)) << 16)) << 32);
       }
     }
-    // range update (od_ec_encode_q15, the mirror of spec §8.2.6)
+    // range update (od_ec_encode_q15, the mirror of spec §8.2.6), branch-free: fl6 == 512 <=> s == 0
     uint32_t l = low, r = rng;
-    if (fl6 < 512) {
-      const uint32_t u = (((r >> 8) * fl6) >> 1) + 4 * (uint32_t)(ns + 1);
-      const uint32_t v = (((r >> 8) * fh6) >> 1) + 4 * (uint32_t)ns;
-      l += r - u;
-      r = u - v;
-    } else {
-      r -= (((r >> 8) * fh6) >> 1) + 4 * (uint32_t)ns;
-    }
-    int c = cnt;
+    const uint32_t r8 = r >> 8;
+    const uint32_t v = ((r8 * fh6) >> 1) + 4u * (uint32_t)ns;
+    const uint32_t u = fl6 >= 512 ? r : ((r8 * fl6) >> 1) + 4u * (uint32_t)ns + 4u;
+    l += r - u;
+    r = u - v;
     const int d = __builtin_clz(r) - 16;
-    int s2 = c + d;
+    int s2 = cnt + d;
     if (s2 >= 0) {
-      c += 16;
-      uint32_t m = (1u << c) - 1;
+      int c = cnt + 16;
       if (s2 >= 8) {
-        PUT_BYTE(l >> c);
-        l &= m;
+        EMIT(l >> c);
+        l &= (1u << c) - 1;
         c -= 8;
-        m >>= 8;
       }
-      PUT_BYTE(l >> c);
+      EMIT(l >> c);
+      l &= (1u << c) - 1;
       s2 = c + d - 24;
-      l &= m;
     }
     low = l << d;
     rng = r << d;
@@ -546,19 +547,18 @@ __global__ void __launch_bounds__(64) rangecode_tiles_kernel(Av1miDevParams P, i
     if (s > 0) {
       uint32_t n = (1u << (c + 16)) - 1;
       do {
-        PUT_BYTE(v >> (c + 16));
+        EMIT(v >> (c + 16));
         v &= n;
         s -= 8;
         c -= 8;
         n >>= 8;
       } while (s > 0);
     }
-    if (pending >= 0) RAW_BYTE(pending);
-    for (int i = 0; i < ff_run; i++) RAW_BYTE(0xFF);
     if ((out_pos & 3) && ((out_pos + 3) & ~3) <= out_cap) *reinterpret_cast<uint32_t *>(out + (out_pos & ~3)) = acc;
   }
   if (live) tile_bytes[tile] = overflow ? 0xFFFFFFFFu : (uint32_t)out_pos;
 }
+#undef EMIT
 
 }  // namespace
 

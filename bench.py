@@ -161,7 +161,7 @@ def main():
             "stage_ms": {s: round(v, 3) for s, v in stage.items()},
             "bytes_per_frame": round(len(data) / n, 1),
             "psnr_db": [round(rep.psnr[i], 2) for i in range(3)],
-            "symbols_per_frame": int(rep.n_symbols // n),
+            "symbols_per_frame": int(rep.n_symbols // n), "max_tile_symbols": int(rep.max_tile_symbols),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, bd, args.block_log2)

@@ -67,6 +67,8 @@ typedef struct {
   float ms_h2d, ms_recon, ms_cdef, ms_entropy, ms_pack, ms_d2h, ms_total;
   float ms_symbolize;       /* part of ms_entropy spent in the symbolize kernel */
   uint64_t n_symbols;       /* arithmetic-coded symbols */
+  uint32_t max_tile_symbols; /* longest tile: the serial chain that bounds the range-coding kernel */
+  uint32_t reserved0;
 } av1mi_report;
 
 void av1mi_default_params(av1mi_params *p, uint32_t width, uint32_t height, uint32_t bit_depth);
