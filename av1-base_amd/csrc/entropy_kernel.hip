@@ -36,8 +36,11 @@ typedef Av1miCdfLayout CL;
 #define SLOTS_PER_COMBO 63   // 42 coeff_base + 21 coeff_br rows of one (tx size, plane type)
 #define MAX_COMBOS 2
 
+// The coefficient (narrow) rows are 57 % of the CDF set; a regular tile in adaptive mode never
+// touches them here (they adapt per lane in K4), so only the FULL kernel variant holds them in LDS.
+__shared__ uint16_t g_cdf_narrow[CL::TOTAL - CL::COEFF_BASE + 64];
 struct SymLds {
-  uint16_t cdf[CL::TOTAL + 64];   // +64: whole-row reads by 17 lanes may run past the last row
+  uint16_t cdf[CL::COEFF_BASE + 64];   // wide rows; +64: whole-row reads by 17 lanes may run past the last row
   int16_t lv[32 * 32];
   uint16_t scan[1024 + 256 + 64 + 16];  // scan index -> position, for n = 32, 16, 8, 4
   Av1miBlkInfo info[64];
@@ -80,6 +83,21 @@ __device__ __forceinline__ void sym_wide(Sym &y, int lane, int adapt, int s, int
   }
   emit1(y, lane, ENT_RESOLVED(fl >> 6, fh >> 6, n - 1 - s));
 }
+// same for a 4-symbol coefficient row kept in the narrow LDS array (FULL variant only)
+__device__ __forceinline__ void sym_narrow_resolved(Sym &y, int lane, int adapt, int s, int off) {
+  s = uni(s); off = uni(off) - CL::COEFF_BASE;
+  const int v = g_cdf_narrow[off + (lane < 5 ? lane : 4)];
+  const uint32_t fl = s > 0 ? (uint32_t)__builtin_amdgcn_readlane(v, s - 1) : 32768u;
+  const uint32_t fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
+  if (adapt) {
+    const int cntr = __builtin_amdgcn_readlane(v, 4);
+    const int rate = 5 + (cntr > 15) + (cntr > 31);
+    int nv = lane < s ? v + ((32768 - v) >> rate) : v - (v >> rate);
+    nv = lane == 4 ? cntr + (cntr < 32) : nv;
+    if (lane <= 4) g_cdf_narrow[off + lane] = (uint16_t)nv;
+  }
+  emit1(y, lane, ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s));
+}
 __device__ __forceinline__ void sym_bool(Sym &y, int lane, int val, uint32_t f) {
   // P(val == 1) = f / 32768, no adaptation
   emit1(y, lane, val ? ENT_RESOLVED(f >> 6, 0, 0) : ENT_RESOLVED(512, f >> 6, 1));
@@ -116,6 +134,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
 }
 
 // coefficients of one transform block (spec §5.11.39); x4/y4 in plane 4x4 units local to the SB.
+template <bool FULL>
 __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int adapt, const TileGeo &tg, int plane, int log2n, int x4,
                                            int y4, int eob, int ymode, const int16_t *lv_global) {
   const int ptype = plane > 0;
@@ -218,16 +237,16 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
           }
         }
         y.pos += total;
-      } else {
+      } else if (FULL) {
         // resolved path (static CDFs, or a third size class in an edge tile): walk the items
         const int top = imin(c_hi, 63);
         for (int i = 0; i <= top; i++) {
           const int lv_i = __builtin_amdgcn_readlane(level, i), cb_i = __builtin_amdgcn_readlane(cb, i), cbr_i = __builtin_amdgcn_readlane(cbr, i);
-          if (c_hi - i != eob - 1) sym_wide(y, lane, adapt, imin(lv_i, 3), base_off0 + cb_i * 5, 4);
+          if (c_hi - i != eob - 1) sym_narrow_resolved(y, lane, adapt, imin(lv_i, 3), base_off0 + cb_i * 5);
           if (lv_i > 2) {
             for (int idx = 0; idx < 4; idx++) {
               const int k3 = imin(lv_i - 3 - idx * 3, 3);
-              sym_wide(y, lane, adapt, k3, br_off0 + cbr_i * 5, 4);
+              sym_narrow_resolved(y, lane, adapt, k3, br_off0 + cbr_i * 5);
               if (k3 < 3) break;
             }
           }
@@ -303,6 +322,10 @@ __device__ __forceinline__ bool node_split(const Av1miDevParams &P, int sb_x, in
   return split;
 }
 
+// FULL = false: regular tiles (superblock entirely inside the frame) in adaptive mode - exactly two
+// (tx size, plane type) classes, no narrow rows in LDS (10.4 KB -> ~4 waves per SIMD).
+// FULL = true: frame-edge tiles and static-CDF mode.  Each variant skips the other's tiles.
+template <bool FULL>
 __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, const uint16_t *__restrict__ cdf_init,
                                                            const int16_t *__restrict__ levels, const Av1miBlkInfo *__restrict__ blk,
                                                            uint32_t *__restrict__ streams, uint32_t *__restrict__ stream_len,
@@ -311,8 +334,16 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
   const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
   const int lane = threadIdx.x;
-  for (int i = lane; i < CL::TOTAL; i += 64) S->cdf[i] = cdf_init[i];
-  S->cdf[CL::TOTAL + lane] = 0;
+  {
+    const bool regular = !P.disable_cdf_update && (sbc + 1) * 64 <= P.width && (sbr + 1) * 64 <= P.height;
+    if (regular == FULL) return;
+  }
+  for (int i = lane; i < CL::COEFF_BASE; i += 64) S->cdf[i] = cdf_init[i];
+  S->cdf[CL::COEFF_BASE + lane] = 0;
+  if (FULL) {
+    for (int i = lane; i < CL::TOTAL - CL::COEFF_BASE; i += 64) g_cdf_narrow[i] = cdf_init[CL::COEFF_BASE + i];
+    g_cdf_narrow[CL::TOTAL - CL::COEFF_BASE + lane] = 0;
+  }
   for (int l2 = 5; l2 >= 2; l2--) {
     const int n = 1 << l2;
     const int to = scan_table_off(l2);
@@ -338,21 +369,22 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   tg.max_x4_c = (P.mi_cols >> 1) - sbc * 8; tg.max_y4_c = (P.mi_rows >> 1) - sbr * 8;
   const int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
 
+#pragma nounroll
   for (int z = 0; z < 64; z++) {
     const int bx = (((z >> 0) & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) << 3;
     const int by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) << 3;
     if (tg.sb_y + by >= P.height || tg.sb_x + bx >= P.width) continue;
-    for (int bsl = 6; bsl >= 3; bsl--) {
+    const int b8x = bx >> 3, b8y = by >> 3;
+    // leaf containing this 8x8 unit (written by the recon kernel); it is coded at its origin only
+    const int leaf = uni(S->info[b8y * 8 + b8x].bsl);
+    if ((bx | by) & ((1 << leaf) - 1)) continue;
+    // nodes whose origin is (bx, by): every level above the leaf down to the leaf, largest first.
+    // A node at level l > leaf with this origin contains a smaller leaf, so it is a SPLIT node.
+    const int top = imin(6, __builtin_ctz((unsigned)(bx | by | 64)));
+#pragma nounroll
+    for (int bsl = top; bsl >= leaf; bsl--) {
       const int n = 1 << bsl;
-      if ((bx | by) & (n - 1)) continue;
-      bool reached = true;
-      for (int a = 6; a > bsl; a--) {
-        const int an = 1 << a;
-        if (!node_split(P, tg.sb_x, tg.sb_y, bx & ~(an - 1), by & ~(an - 1), a)) { reached = false; break; }
-      }
-      if (!reached) break;
-      const bool split = node_split(P, tg.sb_x, tg.sb_y, bx, by, bsl);
-      const int b8x = bx >> 3, b8y = by >> 3;
+      const bool split = bsl > leaf;
       {
         const int half = n >> 1;
         const bool has_rows = tg.sb_y + by + half < P.height, has_cols = tg.sb_x + bx + half < P.width;
@@ -401,11 +433,10 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
           for (int pl = 0; pl < 3; pl++) {
             const int l2 = pl ? log2c : bsl;
             const int16_t *lvp = pl == 0 ? sb_levels + by * 64 + bx * n : sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * (n >> 1);
-            sym_coeffs(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, lvp);
+            sym_coeffs<FULL>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, lvp);
           }
         }
       }
-      break;
     }
   }
   if (lane == 0) {
@@ -566,7 +597,8 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
                                            const Av1miBlkInfo *blk, uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos,
                                            uint8_t *slots, uint32_t *tile_bytes, hipStream_t stream, hipEvent_t mid) {
   const int n_tiles = P->n_frames * P->sb_rows * P->sb_cols;
-  hipLaunchKernelGGL(symbolize_tile_kernel, dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+  hipLaunchKernelGGL(symbolize_tile_kernel<false>, dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+  hipLaunchKernelGGL(symbolize_tile_kernel<true>, dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
   if (mid) (void)hipEventRecord(mid, stream);
   hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
                      tile_combos, slots, tile_bytes);
