@@ -20,12 +20,10 @@ __constant__ int8_t c_cdef_dir[8][2][2] = {
   { { 1, 1 }, { 2, 2 } },   { { 1, 0 }, { 2, 1 } },  { { 1, 0 }, { 2, 0 } }, { { 1, 0 }, { 2, -1 } } };
 __constant__ int c_div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
 
-#define CDEF_NA 0xFFFFu
-
-// LDS: one plane tile at a time (luma 68x68, then U, then V as 36x36 in the same buffer) plus the
-// per-8x8 decisions: 9.5 KB per wave.
+// CDEF reads the reconstruction straight from HBM/L2 through the vector L1 (every sample is touched ~5
+// times by neighbouring lanes/rows of the same wave) and keeps only the per-8x8 decisions in LDS (256 B):
+// the kernel can share a CU with the range-coding kernel, which holds 129 KB of LDS per CU.
 struct CdefLds {
-  uint16_t t[68 * 68];
   uint8_t dir[64];       // luma direction of each 8x8 block
   uint8_t on[64];        // block is filtered
   uint16_t pri_y[64];    // variance-adjusted luma primary strength
@@ -46,25 +44,23 @@ __device__ __forceinline__ int damp_shift(int threshold, int damping) {
   return a < 0 ? 0 : a;
 }
 
-// filter one pixel at LDS position `c` (tile stride ST); taps of direction dir
-template <int ST>
-__device__ __forceinline__ int cdef_pixel(int c, int pri, int sec, int pri_shift, int sec_shift, int dir, int coeff_shift) {
-  const uint16_t *t = g_cdef.t;
-  const int x = t[c];
+// filter the sample at (gx, gy) of a plane (w x h, row stride `stride`).  EDGE = false: the whole
+// tap neighbourhood of the superblock is inside the frame (no availability tests).
+template <typename PIX, bool EDGE>
+__device__ __forceinline__ int cdef_pixel(const PIX *pl, int stride, int w, int h, int gx, int gy, int x, int pri, int sec,
+                                          int pri_shift, int sec_shift, int dir, int coeff_shift) {
   int sum = 0, mx = x, mn = x;
   const int odd = (pri >> coeff_shift) & 1;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const int ptap = k ? (odd ? 3 : 2) : (odd ? 3 : 4), stap = k ? 1 : 2;
-    const int o0 = c_cdef_dir[dir][k][0] * ST + c_cdef_dir[dir][k][1];
-    const int o1 = c_cdef_dir[(dir + 2) & 7][k][0] * ST + c_cdef_dir[(dir + 2) & 7][k][1];
-    const int o2 = c_cdef_dir[(dir + 6) & 7][k][0] * ST + c_cdef_dir[(dir + 6) & 7][k][1];
 #pragma unroll
     for (int sg = -1; sg <= 1; sg += 2) {
       // every available tap widens the clamp range, whatever its strength (spec §7.15.3)
       {
-        const int p = t[c + sg * o0];
-        if (p != CDEF_NA) {
+        const int yy = gy + sg * c_cdef_dir[dir][k][0], xx = gx + sg * c_cdef_dir[dir][k][1];
+        if (!EDGE || (yy >= 0 && xx >= 0 && yy < h && xx < w)) {
+          const int p = pl[(size_t)yy * stride + xx];
           if (pri) sum += ptap * constrain(p - x, pri, pri_shift);
           mx = p > mx ? p : mx;
           mn = p < mn ? p : mn;
@@ -73,22 +69,69 @@ __device__ __forceinline__ int cdef_pixel(int c, int pri, int sec, int pri_shift
       // with sec == 0 the secondary taps add nothing to the sum and cannot change the clamp either
       // (|sum| / 16 <= 12/16 of the largest primary difference), so they are not even read
       if (sec) {
-        const int s1 = t[c + sg * o2], s2 = t[c + sg * o1];  // dir-2, dir+2 (order is irrelevant to the result)
-        if (s1 != CDEF_NA) {
-          sum += stap * constrain(s1 - x, sec, sec_shift);
-          mx = s1 > mx ? s1 : mx;
-          mn = s1 < mn ? s1 : mn;
-        }
-        if (s2 != CDEF_NA) {
-          sum += stap * constrain(s2 - x, sec, sec_shift);
-          mx = s2 > mx ? s2 : mx;
-          mn = s2 < mn ? s2 : mn;
+#pragma unroll
+        for (int dd = 2; dd <= 6; dd += 4) {
+          const int d2 = (dir + dd) & 7;
+          const int yy = gy + sg * c_cdef_dir[d2][k][0], xx = gx + sg * c_cdef_dir[d2][k][1];
+          if (!EDGE || (yy >= 0 && xx >= 0 && yy < h && xx < w)) {
+            const int s1 = pl[(size_t)yy * stride + xx];
+            sum += stap * constrain(s1 - x, sec, sec_shift);
+            mx = s1 > mx ? s1 : mx;
+            mn = s1 < mn ? s1 : mn;
+          }
         }
       }
     }
   }
   int v = x + ((8 + sum - (sum < 0)) >> 4);
   return v < mn ? mn : (v > mx ? mx : v);
+}
+
+template <typename PIX, bool EDGE>
+__device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PIX *fr, PIX *fo, int x0, int y0, int w, int h, int lane) {
+  const int coeff_shift = P.bit_depth - 8;
+  // ---- luma: lane = column, loop over rows (row-contiguous HBM loads and stores)
+  {
+    const int sec = (P.cdef_y_sec == 3 ? 4 : P.cdef_y_sec) << coeff_shift;
+    const int damping = P.cdef_damping + coeff_shift;
+    const int sec_shift = damp_shift(sec, damping);
+    const int ypri0 = P.cdef_y_pri;
+    if (lane < w) {
+      for (int r = 0; r < h; r++) {
+        const int b = (r >> 3) * 8 + (lane >> 3);
+        const int gx = x0 + lane, gy = y0 + r;
+        int v = fr[(size_t)gy * P.stride_y + gx];
+        const int pri = g_cdef.on[b] ? (int)g_cdef.pri_y[b] : 0;
+        if (g_cdef.on[b] && (pri | sec)) {
+          const int dir = ypri0 == 0 ? 0 : g_cdef.dir[b];
+          v = cdef_pixel<PIX, EDGE>(fr, P.stride_y, P.width, P.height, gx, gy, v, pri, sec, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
+        }
+        fo[(size_t)gy * P.stride_y + gx] = (PIX)v;
+      }
+    }
+  }
+  // ---- chroma: lanes 0-31 = columns of U, lanes 32-63 = columns of V
+  {
+    const int pl = lane >> 5, col = lane & 31;
+    const PIX *cp = fr + (pl ? P.plane_off_v : P.plane_off_u);
+    PIX *op = fo + (pl ? P.plane_off_v : P.plane_off_u);
+    const int pri = P.cdef_uv_pri << coeff_shift;
+    const int sec = (P.cdef_uv_sec == 3 ? 4 : P.cdef_uv_sec) << coeff_shift;
+    const int damping = P.cdef_damping + coeff_shift - 1;
+    const int pri_shift = damp_shift(pri, damping), sec_shift = damp_shift(sec, damping);
+    const int wc = w >> 1, hc = h >> 1;
+    if (col < wc) {
+      for (int r = 0; r < hc; r++) {
+        const int b = (r >> 2) * 8 + (col >> 2);
+        const int gx = (x0 >> 1) + col, gy = (y0 >> 1) + r;
+        int v = cp[(size_t)gy * P.stride_c + gx];
+        if (g_cdef.on[b] && (pri | sec))
+          v = cdef_pixel<PIX, EDGE>(cp, P.stride_c, P.width >> 1, P.height >> 1, gx, gy, v, pri, sec, pri_shift, sec_shift,
+                                    pri == 0 ? 0 : (int)g_cdef.dir[b], coeff_shift);
+        op[(size_t)gy * P.stride_c + gx] = (PIX)v;
+      }
+    }
+  }
 }
 
 template <typename PIX>
@@ -101,14 +144,8 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
   const PIX *fr = rec + (size_t)f * P.frame_samples;
   PIX *fo = fin + (size_t)f * P.frame_samples;
   const int x0 = sbc * 64, y0 = sbr * 64;
-  const int bd = P.bit_depth, coeff_shift = bd - 8;
+  const int coeff_shift = P.bit_depth - 8;
   const int w = P.width - x0 < 64 ? P.width - x0 : 64, h = P.height - y0 < 64 ? P.height - y0 : 64;
-  // ---- luma tile 68x68 incl. 2-px halo; outside-frame samples -> sentinel
-  for (int t = lane; t < 68 * 68; t += 64) {
-    const int r = t / 68, c = t % 68;
-    const int gy = y0 + r - 2, gx = x0 + c - 2;
-    g_cdef.t[t] = (gy >= 0 && gx >= 0 && gy < P.height && gx < P.width) ? (uint16_t)fr[(size_t)gy * P.stride_y + gx] : (uint16_t)CDEF_NA;
-  }
   // ---- per-8x8 decisions: lane = 8x8 block
   const int b8r = lane >> 3, b8c = lane & 7;
   const bool inside = (sbr * 8 + b8r) < P.b8_rows && (sbc * 8 + b8c) < P.b8_cols;
@@ -117,12 +154,11 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
   // cdef_idx of the superblock is coded (== 0) iff some block in it is not skipped (§5.11.56)
   const bool sb_on = __ballot(inside && !skip) != 0ull;
   const bool do_filter = P.enable_cdef && sb_on && inside && !skip;
-  __syncthreads();
   {
     int ydir = 0, var = 0;
     if (do_filter) {
-      // direction search §7.15.2
-      const uint16_t *ty = g_cdef.t + (b8r * 8 + 2) * 68 + b8c * 8 + 2;
+      // direction search §7.15.2 on the block's 8 rows of 8 samples (16-byte / 8-byte row loads)
+      const PIX *ty = fr + (size_t)(y0 + b8r * 8) * P.stride_y + x0 + b8c * 8;
       int cost[8], partial[8][15];
 #pragma unroll
       for (int a = 0; a < 8; a++) {
@@ -131,10 +167,13 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
         for (int b = 0; b < 15; b++) partial[a][b] = 0;
       }
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < 8; i++) {
+        PIX rowpx[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) rowpx[j] = ty[(size_t)i * P.stride_y + j];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const int x = (ty[i * 68 + j] >> coeff_shift) - 128;
+          const int x = ((int)rowpx[j] >> coeff_shift) - 128;
           partial[0][i + j] += x;
           partial[1][i + j / 2] += x;
           partial[2][i] += x;
@@ -144,6 +183,7 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
           partial[6][j] += x;
           partial[7][i / 2 + j] += x;
         }
+      }
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         cost[2] += partial[2][i] * partial[2][i];
@@ -186,53 +226,10 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
     g_cdef.pri_y[lane] = (uint16_t)pri;
   }
   __syncthreads();
-  // ---- luma filter: lane = column, loop over rows (coalesced LDS reads and HBM row stores)
-  {
-    const int sec = (P.cdef_y_sec == 3 ? 4 : P.cdef_y_sec) << coeff_shift;
-    const int damping = P.cdef_damping + coeff_shift;
-    const int sec_shift = damp_shift(sec, damping);
-    const int ypri0 = P.cdef_y_pri;
-    if (lane < w) {
-      for (int r = 0; r < h; r++) {
-        const int b = (r >> 3) * 8 + (lane >> 3);
-        const int c = (r + 2) * 68 + lane + 2;
-        int v = g_cdef.t[c];
-        const int pri = g_cdef.on[b] ? (int)g_cdef.pri_y[b] : 0;
-        if (g_cdef.on[b] && (pri | sec)) {
-          const int dir = ypri0 == 0 ? 0 : g_cdef.dir[b];
-          v = cdef_pixel<68>(c, pri, sec, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
-        }
-        fo[(size_t)(y0 + r) * P.stride_y + x0 + lane] = (PIX)v;
-      }
-    }
-  }
-  // ---- chroma planes, one at a time through the same tile buffer (stride 36)
-  for (int pl = 0; pl < 2; pl++) {
-    __syncthreads();
-    const PIX *cp = fr + (pl ? P.plane_off_v : P.plane_off_u);
-    for (int t = lane; t < 36 * 36; t += 64) {
-      const int r = t / 36, c = t % 36;
-      const int gy = (y0 >> 1) + r - 2, gx = (x0 >> 1) + c - 2;
-      g_cdef.t[t] = (gy >= 0 && gx >= 0 && gy < (P.height >> 1) && gx < (P.width >> 1)) ? (uint16_t)cp[(size_t)gy * P.stride_c + gx] : (uint16_t)CDEF_NA;
-    }
-    __syncthreads();
-    const int pri = P.cdef_uv_pri << coeff_shift;
-    const int sec = (P.cdef_uv_sec == 3 ? 4 : P.cdef_uv_sec) << coeff_shift;
-    const int damping = P.cdef_damping + coeff_shift - 1;
-    const int pri_shift = damp_shift(pri, damping), sec_shift = damp_shift(sec, damping);
-    PIX *op = fo + (pl ? P.plane_off_v : P.plane_off_u);
-    const int wc = w >> 1, hc = h >> 1;
-    const int col = lane & 31;
-    if (col < wc) {
-      for (int r = lane >> 5; r < hc; r += 2) {
-        const int b = (r >> 2) * 8 + (col >> 2);
-        const int c = (r + 2) * 36 + col + 2;
-        int v = g_cdef.t[c];
-        if (g_cdef.on[b] && (pri | sec)) v = cdef_pixel<36>(c, pri, sec, pri_shift, sec_shift, pri == 0 ? 0 : g_cdef.dir[b], coeff_shift);
-        op[(size_t)((y0 >> 1) + r) * P.stride_c + (x0 >> 1) + col] = (PIX)v;
-      }
-    }
-  }
+  // taps reach 2 samples beyond the superblock (1 in chroma): interior superblocks need no tests
+  const bool edge = x0 < 2 || y0 < 2 || x0 + 66 > P.width || y0 + 66 > P.height;
+  if (edge) cdef_filter_sb<PIX, true>(P, fr, fo, x0, y0, w, h, lane);
+  else cdef_filter_sb<PIX, false>(P, fr, fo, x0, y0, w, h, lane);
 }
 
 // ------------------------------------------------------------------------------ SSE (PSNR)
