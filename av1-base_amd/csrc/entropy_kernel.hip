@@ -447,23 +447,38 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
 #undef S
 
 // ================================================================================= K4
-// One lane per tile.  LDS: adaptive 4-symbol rows, [slot][lane] x 8 bytes {c0, c1, c2, counter}.
+// One lane per tile, 64 tiles per workgroup, TWO waves per workgroup working as a pipeline:
+//   wave 0 (resolver): walks the tile's stream, adapts the tile's narrow CDF rows (LDS, [slot][lane] x
+//           8 bytes {c0, c1, c2, counter}) and turns every entry into a RESOLVED one in an LDS ring;
+//   wave 1 (coder):    runs the range coder over the ring and writes the tile's bytes.
+// The kernel's duration is the serial chain of its longest tile (~4.8 k symbols at 1080p), so halving
+// the instructions per link of that chain matters more than anything else here.
+#define RC_BATCH 16
 struct RcLds {
   uint64_t row[MAX_COMBOS * SLOTS_PER_COMBO][64];
+  uint32_t ring[2][RC_BATCH][64];
 };
 __shared__ RcLds g_rc;
 
-__global__ void __launch_bounds__(64) rangecode_tiles_kernel(Av1miDevParams P, int n_tiles, const uint16_t *__restrict__ cdf_init,
-                                                            const uint32_t *__restrict__ streams, const uint32_t *__restrict__ stream_len,
-                                                            const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
-                                                            uint32_t *__restrict__ tile_bytes) {
-  const int lane = threadIdx.x;
+__global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, int n_tiles, const uint16_t *__restrict__ cdf_init,
+                                                             const uint32_t *__restrict__ streams, const uint32_t *__restrict__ stream_len,
+                                                             const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
+                                                             uint32_t *__restrict__ tile_bytes) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 64 + lane;
   const bool live = tile < n_tiles;
-  const int count = live ? (int)stream_len[tile] : 0;
-  const bool overflow = count > P.stream_cap;
-  // ---- per-lane CDF rows from the defaults of this tile's two (tx size, plane type) classes
-  {
+  const int count_raw = live ? (int)stream_len[tile] : 0;
+  const bool overflow = count_raw > P.stream_cap;
+  const int count = overflow ? 0 : count_raw;
+  int maxcount = count;
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(maxcount, o, 64); maxcount = t > maxcount ? t : maxcount; }
+  const int nb = (maxcount + RC_BATCH - 1) / RC_BATCH;
+  const uint32_t *st = streams + (size_t)(live ? tile : 0) * P.stream_cap;
+  const int adapt = !P.disable_cdf_update;
+
+  // ---- resolver state
+  if (wave == 0) {
+    // per-lane CDF rows from the defaults of this tile's two (tx size, plane type) classes
     const uint32_t cm = live ? tile_combos[tile] : 0xFFFFu;
     for (int k = 0; k < MAX_COMBOS; k++) {
       const int combo = (cm >> (8 * k)) & 0xFF;
@@ -475,18 +490,17 @@ __global__ void __launch_bounds__(64) rangecode_tiles_kernel(Av1miDevParams P, i
       for (int j = 0; j < 21; j++) g_rc.row[k * SLOTS_PER_COMBO + 42 + j][lane] = (uint64_t)r[j * 5] | ((uint64_t)r[j * 5 + 1] << 16) | ((uint64_t)r[j * 5 + 2] << 32);
     }
   }
-  // ---- per-lane range coder
+  // ---- coder state
   uint32_t low = 0, rng = 0x8000;
   int cnt = -9, out_pos = 0;
   uint32_t acc = 0;  // up to 3 buffered output bytes
   uint8_t *const out = slots + (size_t)(live ? tile : 0) * P.tile_slot_bytes;
   const int out_cap = P.tile_slot_bytes;
-  const uint32_t *st = streams + (size_t)(live ? tile : 0) * P.stream_cap;
-  const int adapt = !P.disable_cdf_update;
 
   // Output: append-only big-endian byte string.  A carry out of the coder (bit 8 of an emitted value)
   // adds 1 to the number formed by the bytes written so far - first inside the partially filled
-  // word `acc`, then (rare) by read-modify-write of bytes already in HBM.
+  // word `acc`, then (rare) by read-modify-write of words already stored (after waiting for the
+  // wave's own stores; agent-scope accesses so that no stale L1 line can be read).
 #define EMIT(v_)                                                                               \
   do {                                                                                         \
     const unsigned ev = (v_);                                                                  \
@@ -497,10 +511,19 @@ __global__ void __launch_bounds__(64) rangecode_tiles_kernel(Av1miDevParams P, i
         if (((acc >> sh) & 0xFF) == 0xFF) acc &= ~(0xFFu << sh);                               \
         else { acc += 1u << sh; k = -2; break; }                                               \
       }                                                                                        \
-      for (; k >= 0; k--) {                                                                    \
-        const unsigned ob = out[k];                                                            \
-        if (ob == 0xFF) out[k] = 0;                                                            \
-        else { out[k] = (uint8_t)(ob + 1); break; }                                            \
+      if (k >= 0) {                                                                            \
+        /* words already stored: wait for this wave's stores, then read-modify-write through L2 */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        for (; k >= 0; k--) {                                                                  \
+          uint32_t *wp = reinterpret_cast<uint32_t *>(out + (k & ~3));                         \
+          uint32_t wv = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
+          const int sh = 8 * (k & 3);                                                          \
+          const bool ff = ((wv >> sh) & 0xFF) == 0xFF;                                         \
+          wv = ff ? (wv & ~(0xFFu << sh)) : wv + (1u << sh);                                   \
+          __hip_atomic_store(wp, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+          if (!ff) break;                                                                      \
+        }                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
       }                                                                                        \
     }                                                                                          \
     acc |= (ev & 0xFFu) << (8 * (out_pos & 3));                                                \
@@ -511,83 +534,99 @@ __global__ void __launch_bounds__(64) rangecode_tiles_kernel(Av1miDevParams P, i
     }                                                                                          \
   } while (0)
 
-  const int n_iter = overflow ? 0 : count;
-  // stream entries arrive 4 at a time (16 B per lane); the load of the NEXT four is in flight while
-  // the current four are coded.  stream_cap is a multiple of 4: reading a whole group is always in
-  // bounds of the tile's stream.
-  uint4 buf = make_uint4(0, 0, 0, 0), nxt = make_uint4(0, 0, 0, 0);
-  if (n_iter > 0) nxt = *reinterpret_cast<const uint4 *>(st);
-  for (int i = 0; i < n_iter; i++) {
-    if ((i & 3) == 0) {
-      buf = nxt;
-      if (i + 4 < n_iter) nxt = *reinterpret_cast<const uint4 *>(st + i + 4);
-    }
-    const uint32_t ent = (i & 3) == 0 ? buf.x : ((i & 3) == 1 ? buf.y : ((i & 3) == 2 ? buf.z : buf.w));
-    uint32_t fl6 = (ent >> 14) & 0x3FF, fh6 = (ent >> 4) & 0x3FF;
-    int ns = ent & 15;
-    if (!(ent & 0x80000000u)) {
-      const int slot = (ent >> 2) & 0x1FF, s = ent & 3;
-      const uint64_t rw = g_rc.row[slot][lane];
-      const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
-      // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): 16-bit fields of the row
-      const uint64_t cdf48 = rw & 0x0000FFFFFFFFFFFFull;
-      const uint32_t fh = s == 3 ? 0u : (uint32_t)(cdf48 >> (16 * s)) & 0xFFFFu;
-      const uint32_t fl = s == 0 ? 32768u : (uint32_t)(cdf48 >> (16 * (s - 1))) & 0xFFFFu;
-      fl6 = fl >> 6; fh6 = fh >> 6; ns = 3 - s;
-      if (adapt) {
-        const uint32_t cn = c2n >> 16;
-        const int rate = 5 + (cn > 15) + (cn > 31);
-        const uint32_t c0 = c01 & 0xFFFF, c1 = c01 >> 16, c2 = c2n & 0xFFFF;
-        const uint32_t n0 = 0 < s ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
-        const uint32_t n1 = 1 < s ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
-        const uint32_t n2 = 2 < s ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
-        g_rc.row[slot][lane] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | ((cn + (cn < 32)) << 16)) << 32);
+  __syncthreads();
+  // batch k is resolved by wave 0 in trip k and coded by wave 1 in trip k + 1
+  for (int k = 0; k <= nb; k++) {
+    if (wave == 0) {
+      if (k < nb) {
+#pragma unroll 4
+        for (int j = 0; j < RC_BATCH; j += 4) {
+          const int i0 = k * RC_BATCH + j;
+          // 4 entries per 16-byte load; stream_cap is a multiple of 4 so the group is in bounds
+          const uint4 q = i0 < count ? *reinterpret_cast<const uint4 *>(st + i0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) {
+            uint32_t ent = jj == 0 ? q.x : (jj == 1 ? q.y : (jj == 2 ? q.z : q.w));
+            if (i0 + jj < count && !(ent & 0x80000000u)) {
+              const int slot = (ent >> 2) & 0x1FF, s = ent & 3;
+              const uint64_t rw = g_rc.row[slot][lane];
+              const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
+              // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): 16-bit fields of the row
+              const uint64_t cdf48 = rw & 0x0000FFFFFFFFFFFFull;
+              const uint32_t fh = s == 3 ? 0u : (uint32_t)(cdf48 >> (16 * s)) & 0xFFFFu;
+              const uint32_t fl = s == 0 ? 32768u : (uint32_t)(cdf48 >> (16 * (s - 1))) & 0xFFFFu;
+              ent = ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s);
+              if (adapt) {
+                const uint32_t cn = c2n >> 16;
+                const int rate = 5 + (cn > 15) + (cn > 31);
+                const uint32_t c0 = c01 & 0xFFFF, c1 = c01 >> 16, c2 = c2n & 0xFFFF;
+                const uint32_t n0 = 0 < s ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
+                const uint32_t n1 = 1 < s ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
+                const uint32_t n2 = 2 < s ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
+                g_rc.row[slot][lane] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | ((cn + (cn < 32)) << 16)) << 32);
+              }
+            }
+            g_rc.ring[k & 1][j + jj][lane] = ent;
+          }
+        }
+      }
+    } else if (k > 0) {
+      const int base = (k - 1) * RC_BATCH;
+#pragma unroll 2
+      for (int j = 0; j < RC_BATCH; j++) {
+        if (base + j < count) {
+          const uint32_t ent = g_rc.ring[(k - 1) & 1][j][lane];
+          const uint32_t fl6 = (ent >> 14) & 0x3FF, fh6 = (ent >> 4) & 0x3FF, ns = ent & 15;
+          // range update (od_ec_encode_q15, the mirror of spec §8.2.6), branch-free: fl6 == 512 <=> s == 0
+          uint32_t l = low, r = rng;
+          const uint32_t r8 = r >> 8;
+          const uint32_t v = ((r8 * fh6) >> 1) + 4u * ns;
+          const uint32_t u = fl6 >= 512 ? r : ((r8 * fl6) >> 1) + 4u * ns + 4u;
+          l += r - u;
+          r = u - v;
+          const int d = __builtin_clz(r) - 16;
+          int s2 = cnt + d;
+          if (s2 >= 0) {
+            int c = cnt + 16;
+            if (s2 >= 8) {
+              EMIT(l >> c);
+              l &= (1u << c) - 1;
+              c -= 8;
+            }
+            EMIT(l >> c);
+            l &= (1u << c) - 1;
+            s2 = c + d - 24;
+          }
+          low = l << d;
+          rng = r << d;
+          cnt = s2;
+        }
       }
     }
-    // range update (od_ec_encode_q15, the mirror of spec §8.2.6), branch-free: fl6 == 512 <=> s == 0
-    uint32_t l = low, r = rng;
-    const uint32_t r8 = r >> 8;
-    const uint32_t v = ((r8 * fh6) >> 1) + 4u * (uint32_t)ns;
-    const uint32_t u = fl6 >= 512 ? r : ((r8 * fl6) >> 1) + 4u * (uint32_t)ns + 4u;
-    l += r - u;
-    r = u - v;
-    const int d = __builtin_clz(r) - 16;
-    int s2 = cnt + d;
-    if (s2 >= 0) {
-      int c = cnt + 16;
-      if (s2 >= 8) {
-        EMIT(l >> c);
-        l &= (1u << c) - 1;
-        c -= 8;
+    __syncthreads();
+  }
+  // ---- finish (od_ec_enc_done), coder wave
+  if (wave == 1) {
+    if (live && !overflow) {
+      uint32_t l = low;
+      int c = cnt, s = 10;
+      const uint32_t m = 0x3FFF;
+      uint32_t v = ((l + m) & ~m) | (m + 1);
+      s += c;
+      if (s > 0) {
+        uint32_t n = (1u << (c + 16)) - 1;
+        do {
+          EMIT(v >> (c + 16));
+          v &= n;
+          s -= 8;
+          c -= 8;
+          n >>= 8;
+        } while (s > 0);
       }
-      EMIT(l >> c);
-      l &= (1u << c) - 1;
-      s2 = c + d - 24;
+      if ((out_pos & 3) && ((out_pos + 3) & ~3) <= out_cap) *reinterpret_cast<uint32_t *>(out + (out_pos & ~3)) = acc;
     }
-    low = l << d;
-    rng = r << d;
-    cnt = s2;
+    if (live) tile_bytes[tile] = overflow ? 0xFFFFFFFFu : (uint32_t)out_pos;
   }
-  // ---- finish (od_ec_enc_done)
-  if (live && !overflow) {
-    uint32_t l = low;
-    int c = cnt, s = 10;
-    const uint32_t m = 0x3FFF;
-    uint32_t v = ((l + m) & ~m) | (m + 1);
-    s += c;
-    if (s > 0) {
-      uint32_t n = (1u << (c + 16)) - 1;
-      do {
-        EMIT(v >> (c + 16));
-        v &= n;
-        s -= 8;
-        c -= 8;
-        n >>= 8;
-      } while (s > 0);
-    }
-    if ((out_pos & 3) && ((out_pos + 3) & ~3) <= out_cap) *reinterpret_cast<uint32_t *>(out + (out_pos & ~3)) = acc;
-  }
-  if (live) tile_bytes[tile] = overflow ? 0xFFFFFFFFu : (uint32_t)out_pos;
 }
 #undef EMIT
 
@@ -600,7 +639,7 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   hipLaunchKernelGGL(symbolize_tile_kernel<false>, dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
   hipLaunchKernelGGL(symbolize_tile_kernel<true>, dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
   if (mid) (void)hipEventRecord(mid, stream);
-  hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
+  hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
                      tile_combos, slots, tile_bytes);
   return hipGetLastError();
 }

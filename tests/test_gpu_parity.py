@@ -142,6 +142,7 @@ def test_device_resident_input_matches_host_input(av1mi, ctx, oracle):
     p = av1mi.default_params(w, h, bd)
     a = ctx.encode_chunk(p, raw, n)[0]
     d = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()   # the encoder runs on its own non-blocking stream
     b = ctx.encode_chunk(p, d.data_ptr(), n, on_device=True)[0]
     assert a == b
 
