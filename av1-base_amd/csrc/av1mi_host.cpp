@@ -466,7 +466,7 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
   // CDEF (+SSE) depends only on the reconstruction.  The range-coding kernel is a latency-bound
   // serial chain (one lane per tile: 480 waves, half the SIMDs idle), so CDEF runs beside IT on a
   // second stream; symbolize and CDEF are both throughput-bound and would only slow each other.
-  hipStream_t s2 = c->stream2;
+  hipStream_t s2 = getenv("AV1MI_SERIAL") ? c->stream : c->stream2;  // AV1MI_SERIAL: single-stream timing experiments
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, s, c->ev[7]));
   HIPCHK(c, hipEventRecord(c->ev[4], s));

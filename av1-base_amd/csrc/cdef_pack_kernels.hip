@@ -44,6 +44,19 @@ __device__ __forceinline__ int damp_shift(int threshold, int damping) {
   return a < 0 ? 0 : a;
 }
 
+// Cdef_Directions[d][k] = (dy, dx), packed 3 bits per direction (value + 2) so that the tap offsets cost
+// a shift and a mask instead of a dependent table load per tap.
+__device__ __forceinline__ void cdef_dir_offsets(int dir, int &dy0, int &dx0, int &dy1, int &dx1) {
+  //            d: 7  6  5  4  3  2  1  0
+  // k=0 dy+2:     3  3  3  3  2  2  2  1      dx+2: 2 2 2 3 3 3 3 3
+  // k=1 dy+2:     4  4  4  4  3  2  1  0      dx+2: 1 2 3 4 4 4 4 4
+  const int sh = 3 * dir;
+  dy0 = ((0x6DB491 >> sh) & 7) - 2;   // 011 011 011 011 010 010 010 001
+  dx0 = ((0x4936DB >> sh) & 7) - 2;   // 010 010 010 011 011 011 011 011
+  dy1 = ((0x924688 >> sh) & 7) - 2;   // 100 100 100 100 011 010 001 000
+  dx1 = ((0x29C924 >> sh) & 7) - 2;   // 001 010 011 100 100 100 100 100
+}
+
 // filter the sample at (gx, gy) of a plane (w x h, row stride `stride`).  EDGE = false: the whole
 // tap neighbourhood of the superblock is inside the frame (no availability tests).
 template <typename PIX, bool EDGE>
@@ -51,6 +64,12 @@ __device__ __forceinline__ int cdef_pixel(const PIX *pl, int stride, int w, int 
                                           int pri_shift, int sec_shift, int dir, int coeff_shift) {
   int sum = 0, mx = x, mn = x;
   const int odd = (pri >> coeff_shift) & 1;
+  int oy[2], ox[2], sy[2][2], sx[2][2];
+  cdef_dir_offsets(dir, oy[0], ox[0], oy[1], ox[1]);
+  if (sec) {
+    cdef_dir_offsets((dir + 2) & 7, sy[0][0], sx[0][0], sy[0][1], sx[0][1]);
+    cdef_dir_offsets((dir + 6) & 7, sy[1][0], sx[1][0], sy[1][1], sx[1][1]);
+  }
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const int ptap = k ? (odd ? 3 : 2) : (odd ? 3 : 4), stap = k ? 1 : 2;
@@ -58,7 +77,7 @@ __device__ __forceinline__ int cdef_pixel(const PIX *pl, int stride, int w, int 
     for (int sg = -1; sg <= 1; sg += 2) {
       // every available tap widens the clamp range, whatever its strength (spec §7.15.3)
       {
-        const int yy = gy + sg * c_cdef_dir[dir][k][0], xx = gx + sg * c_cdef_dir[dir][k][1];
+        const int yy = gy + sg * oy[k], xx = gx + sg * ox[k];
         if (!EDGE || (yy >= 0 && xx >= 0 && yy < h && xx < w)) {
           const int p = pl[(size_t)yy * stride + xx];
           if (pri) sum += ptap * constrain(p - x, pri, pri_shift);
@@ -70,9 +89,8 @@ __device__ __forceinline__ int cdef_pixel(const PIX *pl, int stride, int w, int 
       // (|sum| / 16 <= 12/16 of the largest primary difference), so they are not even read
       if (sec) {
 #pragma unroll
-        for (int dd = 2; dd <= 6; dd += 4) {
-          const int d2 = (dir + dd) & 7;
-          const int yy = gy + sg * c_cdef_dir[d2][k][0], xx = gx + sg * c_cdef_dir[d2][k][1];
+        for (int q = 0; q < 2; q++) {
+          const int yy = gy + sg * sy[q][k], xx = gx + sg * sx[q][k];
           if (!EDGE || (yy >= 0 && xx >= 0 && yy < h && xx < w)) {
             const int s1 = pl[(size_t)yy * stride + xx];
             sum += stap * constrain(s1 - x, sec, sec_shift);
@@ -97,7 +115,8 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
     const int sec_shift = damp_shift(sec, damping);
     const int ypri0 = P.cdef_y_pri;
     if (lane < w) {
-      for (int r = 0; r < h; r++) {
+#pragma unroll 8
+      for (int r = 0; r < h; r++) {   // h is a multiple of 8: the 8 rows of a block share the decisions and their loads overlap
         const int b = (r >> 3) * 8 + (lane >> 3);
         const int gx = x0 + lane, gy = y0 + r;
         int v = fr[(size_t)gy * P.stride_y + gx];
@@ -121,6 +140,7 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
     const int pri_shift = damp_shift(pri, damping), sec_shift = damp_shift(sec, damping);
     const int wc = w >> 1, hc = h >> 1;
     if (col < wc) {
+#pragma unroll 4
       for (int r = 0; r < hc; r++) {
         const int b = (r >> 2) * 8 + (col >> 2);
         const int gx = (x0 >> 1) + col, gy = (y0 >> 1) + r;
