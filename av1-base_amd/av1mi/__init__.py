@@ -53,7 +53,7 @@ class Report(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("bytes", C.c_uint64), ("sse", C.c_double * 3), ("psnr", C.c_double * 3),
                 ("ms_h2d", C.c_float), ("ms_recon", C.c_float), ("ms_cdef", C.c_float), ("ms_entropy", C.c_float),
                 ("ms_pack", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float), ("ms_symbolize", C.c_float),
-                ("n_symbols", C.c_uint64), ("max_tile_symbols", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("n_symbols", C.c_uint64), ("max_tile_symbols", C.c_uint32), ("cap_scale", C.c_uint32)]
 
 
 class Job(C.Structure):

@@ -254,6 +254,8 @@ struct av1mi_ctx {
   std::string err;
   // workspace (device)
   size_t cap_frames = 0;
+  int cap_scale = 1;   // per-tile symbol-stream / bitstream-slot capacity multiplier (1, 2, 4, 8, 16)
+  int ws_scale = 0;    // the multiplier the workspace was allocated with
   Resolved res = {};
   void *d_src = nullptr, *d_rec = nullptr, *d_fin = nullptr;
   int16_t *d_levels = nullptr;
@@ -305,12 +307,17 @@ void free_workspace(av1mi_ctx *c) {
 
 int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   const av1mi_params &p = r.p;
-  bool same = c->cap_frames >= n_frames && c->res.p.width == p.width && c->res.p.height == p.height && c->res.p.bit_depth == p.bit_depth;
+  bool same = c->cap_frames >= n_frames && c->res.p.width == p.width && c->res.p.height == p.height && c->res.p.bit_depth == p.bit_depth &&
+              c->ws_scale == c->cap_scale;
   const int bps = p.bit_depth > 8 ? 2 : 1;
   const size_t frame_samples = (size_t)p.width * p.height * 3 / 2;
   const size_t nsb = (size_t)r.sb_cols * r.sb_rows;
-  const int slot = bps == 1 ? 8192 : 16384;
-  const int stream_cap = 16384;
+  // Per-tile capacities.  The x1 sizes hold any tile of ordinary content at the supported CQ range; a
+  // tile that outgrows them is detected on the device and the chunk is re-run at the next multiplier.
+  // x16 is the true worst case of a 64x64 4:2:0 tile (6144 coefficients x <= 37 stream entries:
+  // base + 4 range + sign + 31 Golomb bits; <= 10 output bytes per coefficient), so the retry ends.
+  const int slot = (bps == 1 ? 8192 : 16384) * c->cap_scale;
+  const int stream_cap = 16384 * c->cap_scale;
   if (!same) {
     free_workspace(c);
     const size_t nf = n_frames;
@@ -337,6 +344,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_sse, nf * 3 * 8));
     HIPCHK(c, hipMalloc((void **)&c->d_overflow, 4));
     c->cap_frames = n_frames;
+    c->ws_scale = c->cap_scale;
   }
   c->res = r;
   Av1miDevParams &P = c->P;
@@ -429,9 +437,21 @@ const char *av1mi_last_error(const av1mi_ctx *c) { return c ? c->err.c_str() : "
 
 void av1mi_free(void *p) { free(p); }
 
+static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const void *frames, uint32_t n_frames, int frames_on_device,
+                             av1mi_buf *out, uint32_t *frame_sizes, void *recon, av1mi_report *report);
+
 int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *frames, uint32_t n_frames, int frames_on_device,
                        av1mi_buf *out, uint32_t *frame_sizes, void *recon, av1mi_report *report) {
   if (!c || !frames || !out || n_frames == 0) return AV1MI_E_INVALID_ARG;
+  for (;;) {
+    const int rc = encode_chunk_once(c, params, frames, n_frames, frames_on_device, out, frame_sizes, recon, report);
+    if (rc != AV1MI_E_OVERFLOW || c->cap_scale >= 16) return rc;
+    c->cap_scale *= 2;  // stays raised for the following chunks of this context (same content)
+  }
+}
+
+static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const void *frames, uint32_t n_frames, int frames_on_device,
+                             av1mi_buf *out, uint32_t *frame_sizes, void *recon, av1mi_report *report) {
   out->data = nullptr; out->size = 0;
   Resolved r;
   int rc = resolve(params, &r);
@@ -487,7 +507,10 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
   HIPCHK(c, hipMemcpyAsync(foff.data(), c->d_frame_off, (n_frames + 1) * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(&overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
-  if (overflow) { set_err(c, "a tile outgrew its %d-byte bitstream slot", P.tile_slot_bytes); return AV1MI_E_OVERFLOW; }
+  if (overflow) {
+    set_err(c, "a tile outgrew its %d-byte bitstream slot or its %d-entry symbol stream", P.tile_slot_bytes, P.stream_cap);
+    return AV1MI_E_OVERFLOW;
+  }
   const size_t total = (size_t)foff[n_frames];
   if (total > c->out_cap) { set_err(c, "internal: packed size exceeds buffer"); return AV1MI_E_OVERFLOW; }
   uint8_t *host = (uint8_t *)malloc(total ? total : 1);
@@ -523,6 +546,7 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
     memset(report, 0, sizeof(*report));
     report->frames = n_frames;
     report->bytes = total;
+    report->cap_scale = (uint32_t)c->cap_scale;
     const double mx = (double)((1 << P.bit_depth) - 1);
     for (int pl = 0; pl < 3; pl++) {
       double t = 0;

@@ -289,6 +289,8 @@ __global__ void __launch_bounds__(256) frame_layout_kernel(Av1miDevParams P, con
   const int per = (nt + 255) / 256;
   uint32_t s = 0;
   for (int i = t * per; i < (t + 1) * per && i < nt; i++) {
+    // a tile that outgrew its slot or its symbol stream (0xFFFFFFFF): flag it; the host re-runs the
+    // chunk with larger capacities and pack_tiles_kernel does nothing in this pass
     if (tb[i] > (uint32_t)P.tile_slot_bytes) atomicExch(overflow, 1);
     s += tb[i] + (i < nt - 1 ? (uint32_t)P.tile_size_bytes : 0u);
   }
@@ -321,7 +323,9 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
                                                        const uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ tile_off,
                                                        const uint32_t *__restrict__ payload_size,
                                                        const unsigned long long *__restrict__ frame_off,
-                                                       const uint8_t *__restrict__ hdr_blob, uint8_t *__restrict__ out) {
+                                                       const uint8_t *__restrict__ hdr_blob, uint8_t *__restrict__ out,
+                                                       const int *__restrict__ overflow) {
+  if (*overflow) return;  // sizes and offsets are meaningless: nothing may be written
   const int nt = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / nt, t = blockIdx.x % nt, lane = threadIdx.x;
   const uint32_t pay = payload_size[f];
@@ -377,7 +381,7 @@ extern "C" hipError_t av1mi_launch_pack(const Av1miDevParams *P, const uint8_t *
     hipLaunchKernelGGL(frame_layout_kernel, dim3(P->n_frames), dim3(256), 0, stream, *P, tile_bytes, tile_off, frame_size, payload_size, overflow);
     hipLaunchKernelGGL(chunk_layout_kernel, dim3(1), dim3(64), 0, stream, P->n_frames, frame_size, frame_off);
   } else {
-    hipLaunchKernelGGL(pack_tiles_kernel, dim3(P->n_frames * nt), dim3(64), 0, stream, *P, slots, tile_bytes, tile_off, payload_size, frame_off, hdr_blob, out);
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(P->n_frames * nt), dim3(64), 0, stream, *P, slots, tile_bytes, tile_off, payload_size, frame_off, hdr_blob, out, overflow);
   }
   return hipGetLastError();
 }

@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
         /* words already stored: wait for this wave's stores, then read-modify-write through L2 */ \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
         for (; k >= 0; k--) {                                                                  \
+          if ((k | 3) >= out_cap) break; /* slot outgrown: the result is discarded anyway */      \
           uint32_t *wp = reinterpret_cast<uint32_t *>(out + (k & ~3));                         \
           uint32_t wv = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
           const int sh = 8 * (k & 3);                                                          \

@@ -68,7 +68,7 @@ typedef struct {
   float ms_symbolize;       /* part of ms_entropy spent in the symbolize kernel */
   uint64_t n_symbols;       /* arithmetic-coded symbols */
   uint32_t max_tile_symbols; /* longest tile: the serial chain that bounds the range-coding kernel */
-  uint32_t reserved0;
+  uint32_t cap_scale;          /* per-tile capacity multiplier the chunk finally ran with (1 unless a tile overflowed and the chunk was re-run) */
 } av1mi_report;
 
 void av1mi_default_params(av1mi_params *p, uint32_t width, uint32_t height, uint32_t bit_depth);

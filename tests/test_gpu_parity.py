@@ -172,3 +172,29 @@ def test_encode_file_y4m_to_ivf(av1mi, oracle, tmp_path):
         pos += 12 + sz
     assert pos == len(blob) and rep.frames == n and seen and seen[-1] == n
     assert not list(tmp_path.glob("*.tmp*"))
+
+
+def test_stress_carries_and_long_tiles(av1mi, ctx, oracle):
+    """High-rate content (uniform noise, low CQ) makes long tiles, many output bytes, 0xFF runs and
+    carries that ripple into words already stored - the paths of the range-coding kernel that ordinary
+    content rarely takes.  Bit-exact against the oracle on every frame."""
+    rng = np.random.default_rng(99)
+    w, h, n = 328, 248, 6
+    frames = []
+    for t in range(n):
+        y = rng.integers(0, 256, (h, w)).astype(np.uint16)
+        u = rng.integers(0, 256, (h // 2, w // 2)).astype(np.uint16)
+        v = rng.integers(0, 256, (h // 2, w // 2)).astype(np.uint16)
+        frames.append([y, u, v])
+    for cq, bs in ((4, 5), (12, 4), (20, 3)):
+        p = av1mi.default_params(w, h, 8, cq_level=cq, block_log2=bs)
+        data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, 8) for f in frames), n, want_recon=True)
+        cfg = oracle.default_config(w, h, 8, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq))
+        off = 0
+        for i, f in enumerate(frames):
+            tu, rec, st = oracle.encode_frame(cfg, f)
+            assert data[off:off + sizes[i]] == tu, (cq, bs, i)
+            off += sizes[i]
+        assert rep.max_tile_symbols > 3000
+        if cq == 4:  # 64x64 tiles of noise at CQ 4 outgrow the x1 capacities: the re-run path was taken
+            assert rep.max_tile_symbols > 16384 and rep.cap_scale > 1
