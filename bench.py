@@ -141,12 +141,25 @@ def main():
         for s in stage:
             stage[s] /= k
         # algorithmic HBM bytes per launch of each kernel
+        stage["rangecode"] = stage["entropy"] - stage["symbolize"]
         alg = {"recon": n * N * (2 * bps + 2),           # source read + reconstruction write + int16 levels write
-               "cdef": n * N * 2 * bps,                  # reconstruction read + filtered write
-               "entropy": n * N * 2 + len(data)}         # levels read + bitstream write
-        dom = max(("recon", "cdef", "entropy"), key=lambda s: stage[s])
+               "cdef": n * N * 2 * bps,                  # reconstruction read + filtered write (timed with the SSE kernel)
+               "symbolize": n * N * 2 + 4 * int(rep.n_symbols),   # levels read + 32-bit symbol entries write
+               "rangecode": 4 * int(rep.n_symbols) + len(data)}   # symbol entries read + bitstream write
+        dom = max(alg, key=lambda s: stage[s])
         achieved = alg[dom] / (stage[dom] * 1e-3) / 1e9
         peak = 8000.0
+        # HBM traffic of the dominant kernel from the committed PMC passes (separate FETCH_SIZE / WRITE_SIZE
+        # runs of this same workload, profiles/); gfx950 correction: FETCH_SIZE counts 64 B per 128-B request.
+        traffic = traffic_raw = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")))
+            if (w, h, n, bd, args.block_log2, args.static_cdf) == (1920, 1080, 60, 10, 5, False) and dom in pm["kernels"]:
+                kk = pm["kernels"][dom]
+                traffic_raw = (kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024
+                traffic = (2 * kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024
+        except OSError:
+            pass
         out = {
             "metric": "encoded frames/sec at CQ=30 (1080p intra-only)", "value": round(world * n * k / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(elapsed / k * 1e3, 3),
@@ -156,7 +169,7 @@ def main():
                                                                                     "static" if args.static_cdf else "adaptive"),
                        "frames_per_chunk": n, "chunks_per_gpu": 1, "parallelism": "chunk-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
-                         "frac": round(achieved / peak, 5), "traffic": None,
+                         "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
                          "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage[dom], 3)},
             "stage_ms": {s: round(v, 3) for s, v in stage.items()},
             "bytes_per_frame": round(len(data) / n, 1),
