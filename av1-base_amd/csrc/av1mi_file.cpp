@@ -77,7 +77,7 @@ int y4m_read_frame(Y4m *y, uint8_t *dst) {
 void put_le(uint8_t *p, uint64_t v, int n) { for (int i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * i)); }
 
 struct Chunk {
-  uint32_t index = 0, n_frames = 0;
+  uint32_t index = 0, n_frames = 0, first_frame = 0;
   std::vector<uint8_t> frames;
   av1mi_buf out = { nullptr, 0 };
   std::vector<uint32_t> sizes;
@@ -132,7 +132,9 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
         queue.pop_front();
       }
       ck->sizes.resize(ck->n_frames);
-      ck->rc = av1mi_encode_chunk(ctx, &prm, ck->frames.data(), ck->n_frames, 0, &ck->out, ck->sizes.data(), nullptr, &ck->rep);
+      av1mi_params cp = prm;
+      cp.first_frame = prm.first_frame + ck->first_frame;
+      ck->rc = av1mi_encode_chunk(ctx, &cp, ck->frames.data(), ck->n_frames, 0, &ck->out, ck->sizes.data(), nullptr, &ck->rep);
       std::vector<uint8_t>().swap(ck->frames);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -188,6 +190,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   for (;;) {
     Chunk *ck = new Chunk();
     ck->index = n_chunks;
+    ck->first_frame = (uint32_t)frames_read;
     ck->frames.resize((size_t)chunk_frames * y.frame_bytes);
     int r = 1;
     while (ck->n_frames < chunk_frames && (r = y4m_read_frame(&y, ck->frames.data() + (size_t)ck->n_frames * y.frame_bytes)) == 1) ck->n_frames++;

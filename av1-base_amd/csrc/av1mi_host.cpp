@@ -81,7 +81,7 @@ int resolve(const av1mi_params *in, Resolved *r) {
   av1mi_params &p = r->p;
   if (p.width < 8 || p.height < 8 || (p.width & 7) || (p.height & 7) || p.width > 65536 || p.height > 65536) return AV1MI_E_INVALID_ARG;
   if (p.bit_depth != 8 && p.bit_depth != 10) return AV1MI_E_INVALID_ARG;
-  if (p.cq_level > 63) return AV1MI_E_INVALID_ARG;
+  if (p.cq_level > 63 || p.film_grain > 50) return AV1MI_E_INVALID_ARG;
   if (p.keyint == 0) p.keyint = 1;
   if (p.keyint != 1) return AV1MI_E_UNSUPPORTED;
   if (p.block_log2 == 0) p.block_log2 = 5;
@@ -134,7 +134,7 @@ std::vector<uint8_t> make_sequence_header(const Resolved &r) {
   b.put(1, 1);                // color_range
   b.put(0, 2);                // chroma_sample_position
   b.put(0, 1);                // separate_uv_delta_q
-  b.put(0, 1);                // film_grain_params_present
+  b.put(p.film_grain ? 1 : 0, 1);  // film_grain_params_present
   b.trailing();
   std::vector<uint8_t> out;
   out.push_back((1 << 3) | 2);
@@ -145,7 +145,7 @@ std::vector<uint8_t> make_sequence_header(const Resolved &r) {
 
 // OBU_FRAME payload up to the first tile: frame_header_obu (§5.9) + byte_alignment +
 // tile_group_obu's tile_start_and_end_present_flag + byte_alignment (§5.11.1)
-std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits) {
+std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint32_t frame_number = 0) {
   const av1mi_params &p = r.p;
   BitWriter b;
   b.put(0, 1);  // show_existing_frame
@@ -199,6 +199,22 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits) {
   }
   b.put(0, 1);  // tx_mode_select = 0: TX_MODE_LARGEST
   b.put(0, 1);  // reduced_tx_set
+  if (p.film_grain) {  // film_grain_params (§5.9.30): fixed table, per-frame seed
+    const uint32_t sy = p.film_grain * 2 > 255 ? 255 : p.film_grain * 2, sc = p.film_grain;
+    b.put(1, 1);                                              // apply_grain
+    b.put((7391u + 173u * (p.first_frame + frame_number)) & 0xFFFFu, 16);  // grain_seed
+    b.put(2, 4); b.put(0, 8); b.put(sy, 8); b.put(255, 8); b.put(sy, 8);  // num_y_points + points
+    b.put(0, 1);                                              // chroma_scaling_from_luma
+    for (int pl = 0; pl < 2; pl++) { b.put(2, 4); b.put(0, 8); b.put(sc, 8); b.put(255, 8); b.put(sc, 8); }
+    b.put(3, 2);                                              // grain_scaling_minus_8
+    b.put(0, 2);                                              // ar_coeff_lag
+    b.put(128, 8); b.put(128, 8);                             // ar_coeffs_cb/cr_plus_128[0]
+    b.put(0, 2);                                              // ar_coeff_shift_minus_6
+    b.put(0, 2);                                              // grain_scale_shift
+    for (int pl = 0; pl < 2; pl++) { b.put(128, 8); b.put(192, 8); b.put(256, 9); }  // mult, luma_mult, offset
+    b.put(1, 1);                                              // overlap_flag
+    b.put(0, 1);                                              // clip_to_restricted_range
+  }
   if (hdr_bits) *hdr_bits = b.bits;
   b.align();
   if (r.sb_cols * r.sb_rows > 1) { b.put(0, 1); b.align(); }  // tile_start_and_end_present_flag
@@ -331,7 +347,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * nsb * slot));
     c->out_cap = nf * (nsb * (size_t)(slot + 4) + 256);
     HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));
-    HIPCHK(c, hipMalloc((void **)&c->d_hdr, 4096));
+    HIPCHK(c, hipMalloc((void **)&c->d_hdr, 256 + nf * 512));
     HIPCHK(c, hipMalloc((void **)&c->d_cdf, Av1miCdfLayout::TOTAL * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc((void **)&c->d_tile_bytes, nf * nsb * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_tile_off, nf * nsb * 4));
@@ -361,7 +377,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.dc_recip = (uint32_t)((((uint64_t)1 << 32) + P.dc_q - 1) / P.dc_q);
   P.ac_recip = (uint32_t)((((uint64_t)1 << 32) + P.ac_q - 1) / P.ac_q);
   P.min_bs_log2 = P.max_bs_log2 = (int)p.block_log2;
-  P.mode_mask = p.reserved[0] ? (p.reserved[0] & 0x1FFF) : 0x0007;  // reserved[0]: intra candidate mask (default DC, V, H)
+  P.mode_mask = p.intra_mode_mask ? (p.intra_mode_mask & 0x1FFF) : 0x0007;  // default candidates: DC, V, H
   P.enable_cdef = p.enable_cdef ? 1 : 0;
   P.cdef_y_pri = p.cdef_y_pri; P.cdef_y_sec = p.cdef_y_sec; P.cdef_uv_pri = p.cdef_uv_pri; P.cdef_uv_sec = p.cdef_uv_sec;
   P.cdef_damping = p.cdef_damping;
@@ -464,11 +480,16 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   const size_t chunk_bytes = (size_t)n_frames * P.frame_samples * bps;
   hipStream_t s = c->stream;
   // headers + CDFs
-  std::vector<uint8_t> seq = make_sequence_header(r), fh = make_frame_header(r, nullptr);
+  // header blob: sequence header OBU, then one frame header per frame (equal lengths; they differ only in grain_seed)
+  std::vector<uint8_t> seq = make_sequence_header(r), fh = make_frame_header(r, nullptr, 0);
   P.seq_hdr_bytes = (int)seq.size();
   P.frame_hdr_bytes = (int)fh.size();
+  if (seq.size() > 256 || fh.size() > 512) { set_err(c, "internal: header larger than its slot"); return AV1MI_E_OVERFLOW; }
   std::vector<uint8_t> blob(seq);
-  blob.insert(blob.end(), fh.begin(), fh.end());
+  for (uint32_t f = 0; f < n_frames; f++) {
+    if (f && r.p.film_grain) fh = make_frame_header(r, nullptr, f);
+    blob.insert(blob.end(), fh.begin(), fh.end());
+  }
   std::vector<uint16_t> cdf = make_cdf_blob(r.qidx);
   HIPCHK(c, hipMemcpyAsync(c->d_hdr, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemcpyAsync(c->d_cdf, cdf.data(), cdf.size() * 2, hipMemcpyHostToDevice, s));

@@ -15,9 +15,7 @@
 
 namespace {
 
-__constant__ int8_t c_cdef_dir[8][2][2] = {
-  { { -1, 1 }, { -2, 2 } }, { { 0, 1 }, { -1, 2 } }, { { 0, 1 }, { 0, 2 } }, { { 0, 1 }, { 1, 2 } },
-  { { 1, 1 }, { 2, 2 } },   { { 1, 0 }, { 2, 1 } },  { { 1, 0 }, { 2, 0 } }, { { 1, 0 }, { 2, -1 } } };
+// Cdef_Directions (spec §7.15.3) live in cdef_dir_offsets() as packed constants
 __constant__ int c_div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
 
 // CDEF reads the reconstruction straight from HBM/L2 through the vector L1 (every sample is touched ~5
@@ -341,7 +339,7 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
       for (int i = 0; i < ll; i++) { uint8_t b = v & 0x7F; v >>= 7; if (v) b |= 0x80; q[1 + i] = b; }
     }
     for (int i = lane; i < P.seq_hdr_bytes; i += 64) fo[2 + i] = hdr_blob[i];
-    for (int i = lane; i < P.frame_hdr_bytes; i += 64) fo[prefix + i] = hdr_blob[P.seq_hdr_bytes + i];
+    for (int i = lane; i < P.frame_hdr_bytes; i += 64) fo[prefix + i] = hdr_blob[P.seq_hdr_bytes + (size_t)f * P.frame_hdr_bytes + i];
   }
   const uint32_t n = tile_bytes[blockIdx.x];
   uint8_t *dst = fo + prefix + tile_off[blockIdx.x];

@@ -103,7 +103,7 @@ def main():
     d_frames = torch.frombuffer(bytearray(clip), dtype=torch.uint8).to(dev)  # HBM-resident input
     torch.cuda.synchronize(dev)
     params = av1mi.default_params(w, h, bd, block_log2=args.block_log2, cdf_update=0 if args.static_cdf else 1)
-    params.reserved[0] = args.mode_mask
+    params.intra_mode_mask = args.mode_mask
     ctx = av1mi.Context(local_rank)
 
     def step():

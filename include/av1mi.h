@@ -48,7 +48,12 @@ typedef struct {
   uint32_t cdf_update;      /* 1 = adaptive CDFs (default), 0 = static CDFs (disable_cdf_update) */
   uint32_t enable_cdef;     /* 1 = CDEF on (default) */
   uint32_t cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping; /* 0s = defaults */
-  uint32_t reserved[8];
+  uint32_t intra_mode_mask; /* bit m = luma intra mode m is a candidate (AV1 mode numbering); 0 = default {DC, V, H} */
+  uint32_t film_grain;      /* "--film-grain N" (av1an.rs:14): 0 = off; N = 1..50 writes a film-grain table into every
+                               frame header (2-point scaling functions, value 2N luma / N chroma, AR lag 0);
+                               synthesis is decoder-side */
+  uint32_t first_frame;     /* number of the chunk's first frame inside the clip (seeds grain_seed per frame) */
+  uint32_t reserved[5];
 } av1mi_params;
 
 typedef struct {

@@ -49,6 +49,11 @@ typedef struct {
   uint32_t mode_mask;     /* bit m set -> luma intra mode m is a candidate */
   int still_picture;      /* 1: reduced still-picture headers (AVIF style) */
   int disable_cdf_update; /* 1: static default CDFs (no per-symbol adaptation) */
+  /* film-grain table in every frame header (the reference runs `--film-grain 20`,
+   * av1an.rs:14): fixed 2-point luma / chroma scaling functions, AR lag 0.  Synthesis is decoder-side. */
+  int film_grain;         /* 1: film_grain_params_present + apply_grain */
+  int fg_y_scaling, fg_c_scaling; /* 0..255 scaling value of both points */
+  int fg_seed;            /* grain_seed of this frame (16 bits) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */

@@ -167,7 +167,7 @@ static size_t seq_header_payload(const Av1oConfig *cfg, uint8_t *buf, size_t cap
   bw_put(&b, cfg->enable_cdef, 1); /* enable_cdef */
   bw_put(&b, 0, 1);               /* enable_restoration */
   write_color_config(&b, cfg);
-  bw_put(&b, 0, 1); /* film_grain_params_present */
+  bw_put(&b, (uint32_t)(cfg->film_grain != 0), 1); /* film_grain_params_present */
   bw_trailing(&b);
   return b.pos >> 3;
 }
@@ -285,7 +285,35 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, uint8_t *b
   bw_put(&b, 0, 1); /* tx_mode_select = 0 -> TX_MODE_LARGEST */
   /* reference_select / skip_mode / warped motion: not coded for intra frames */
   bw_put(&b, 0, 1); /* reduced_tx_set */
-  /* global_motion_params: none for intra; film grain: not present */
+  /* global_motion_params: none for intra */
+  if (cfg->film_grain) { /* film_grain_params() §5.9.30 (show_frame = 1) */
+    int pl;
+    bw_put(&b, 1, 1);                                   /* apply_grain */
+    bw_put(&b, (uint32_t)cfg->fg_seed & 0xFFFF, 16);    /* grain_seed */
+    /* key frame: update_grain = 1 implied */
+    bw_put(&b, 2, 4);                                   /* num_y_points */
+    bw_put(&b, 0, 8);   bw_put(&b, (uint32_t)cfg->fg_y_scaling, 8);
+    bw_put(&b, 255, 8); bw_put(&b, (uint32_t)cfg->fg_y_scaling, 8);
+    bw_put(&b, 0, 1);                                   /* chroma_scaling_from_luma */
+    for (pl = 0; pl < 2; pl++) {                        /* num_cb_points, num_cr_points */
+      bw_put(&b, 2, 4);
+      bw_put(&b, 0, 8);   bw_put(&b, (uint32_t)cfg->fg_c_scaling, 8);
+      bw_put(&b, 255, 8); bw_put(&b, (uint32_t)cfg->fg_c_scaling, 8);
+    }
+    bw_put(&b, 3, 2);                                   /* grain_scaling_minus_8 */
+    bw_put(&b, 0, 2);                                   /* ar_coeff_lag: numPosLuma = 0, numPosChroma = 1 */
+    bw_put(&b, 128, 8);                                 /* ar_coeffs_cb_plus_128[0] (luma coupling 0) */
+    bw_put(&b, 128, 8);                                 /* ar_coeffs_cr_plus_128[0] */
+    bw_put(&b, 0, 2);                                   /* ar_coeff_shift_minus_6 */
+    bw_put(&b, 0, 2);                                   /* grain_scale_shift */
+    for (pl = 0; pl < 2; pl++) {
+      bw_put(&b, 128, 8);                               /* cb/cr_mult */
+      bw_put(&b, 192, 8);                               /* cb/cr_luma_mult */
+      bw_put(&b, 256, 9);                               /* cb/cr_offset */
+    }
+    bw_put(&b, 1, 1);                                   /* overlap_flag */
+    bw_put(&b, 0, 1);                                   /* clip_to_restricted_range */
+  }
   return b.pos;
 }
 

@@ -58,18 +58,19 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         cfgk = dict(m["config"])
         bs = cfgk.pop("min_bs_log2", 4)
         cfgk.pop("max_bs_log2", None)
-        if bs > 5 or any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("base_q_idx", 120) != 120:
+        if bs > 5 or any(k.startswith("fuzz") for k in cfgk) or (cfgk.get("film_grain") and cfgk.get("fg_seed") != 7391) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("base_q_idx", 120) != 120:
             continue
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs,
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_cdef=cfgk.get("enable_cdef", 1))
-        p.reserved[0] = cfgk.get("mode_mask", 0)
+        p.intra_mode_mask = cfgk.get("mode_mask", 0)
+        p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         for k in ("cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping"):
             if k in cfgk:
                 setattr(p, k, cfgk[k])
         src = oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=m["t"])
         data, sizes, rep, recon = ctx.encode_chunk(p, raw_of(src, m["bit_depth"]), 1, want_recon=True)
         assert data == m["obu"], m["name"]
-        assert sha(split_planes(recon.tobytes(), m["width"], m["height"], m["bit_depth"])) == m["dav1d_sha256"], m["name"]
+        assert sha(split_planes(recon.tobytes(), m["width"], m["height"], m["bit_depth"])) == m["recon_sha256"], m["name"]
         n += 1
     assert n >= 10
 
@@ -198,3 +199,26 @@ def test_stress_carries_and_long_tiles(av1mi, ctx, oracle):
         assert rep.max_tile_symbols > 3000
         if cq == 4:  # 64x64 tiles of noise at CQ 4 outgrow the x1 capacities: the re-run path was taken
             assert rep.max_tile_symbols > 16384 and rep.cap_scale > 1
+
+
+def test_film_grain_table_in_frame_headers(av1mi, ctx, oracle):
+    """`film_grain = N` (the reference's `--film-grain N`, av1an.rs:14): every frame header carries a
+    film-grain table with its own grain_seed; tile data and reconstruction are untouched.  Bit-exact
+    against the oracle writing the same table (the syntax itself is pinned by dav1d, tests/test_oracle.py)."""
+    w, h, n = 200, 120, 3
+    frames = [oracle.synthclip_frame(w, h, 10, seed=4, t=t) for t in range(n)]
+    raw = b"".join(raw_of(f, 10) for f in frames)
+    p0 = av1mi.default_params(w, h, 10)
+    d0, s0, _, _ = ctx.encode_chunk(p0, raw, n)
+    p = av1mi.default_params(w, h, 10)
+    p.film_grain, p.first_frame = 20, 7
+    d, s, rep, _ = ctx.encode_chunk(p, raw, n)
+    cfg = oracle.default_config(w, h, 10, min_bs_log2=5, max_bs_log2=5)
+    cfg.film_grain, cfg.fg_y_scaling, cfg.fg_c_scaling = 1, 40, 20
+    off = 0
+    for i, f in enumerate(frames):
+        cfg.fg_seed = (7391 + 173 * (7 + i)) & 0xFFFF
+        tu, _, _ = oracle.encode_frame(cfg, f)
+        assert d[off:off + s[i]] == tu, i
+        off += s[i]
+    assert len(d) > len(d0) and list(s) != list(s0)
