@@ -36,7 +36,7 @@ E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_OOM, E_OVERFLOW, E_FORMAT, E_UNSUPPORTED = 
 
 # every symbol include/av1mi.h declares
 ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", "av1mi_last_error", "av1mi_encode_chunk",
-               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers"]
+               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts"]
 
 
 class Params(C.Structure):
@@ -53,12 +53,17 @@ class Report(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("bytes", C.c_uint64), ("sse", C.c_double * 3), ("psnr", C.c_double * 3),
                 ("ms_h2d", C.c_float), ("ms_recon", C.c_float), ("ms_cdef", C.c_float), ("ms_entropy", C.c_float),
                 ("ms_pack", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float), ("ms_symbolize", C.c_float),
-                ("n_symbols", C.c_uint64), ("max_tile_symbols", C.c_uint32), ("cap_scale", C.c_uint32)]
+                ("n_symbols", C.c_uint64), ("max_tile_symbols", C.c_uint32), ("cap_scale", C.c_uint32), ("chunks", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class Job(C.Structure):
     _fields_ = [("input_path", C.c_char_p), ("output_path", C.c_char_p), ("temp_dir", C.c_char_p), ("workers", C.c_uint32),
                 ("chunk_frames", C.c_uint32), ("gpu_mask", C.c_int32), ("params", Params)]
+
+
+class SceneState(C.Structure):
+    """include/av1mi.h: av1mi_scene_state (zero-initialised = start of a clip)"""
+    _fields_ = [("frames_since_cut", C.c_uint32), ("hist_n", C.c_uint32), ("hist_q8", C.c_uint32 * 8)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64)
@@ -71,6 +76,8 @@ _lib.av1mi_last_error.restype = C.c_char_p
 _lib.av1mi_encode_chunk.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_int, C.POINTER(Buf),
                                     C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(Report)]
 _lib.av1mi_free.argtypes = [C.c_void_p]
+_lib.av1mi_scene_cuts.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(SceneState),
+                                  C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
 _lib.av1mi_encode_file.argtypes = [C.POINTER(Job), PROGRESS_CB, C.c_void_p, C.POINTER(Report)]
 _lib.av1mi_cq_to_qindex.argtypes = [C.c_uint32]
 _lib.av1mi_cq_to_qindex.restype = C.c_uint32
@@ -151,6 +158,25 @@ class Context:
 
     def last_error(self):
         return _lib.av1mi_last_error(self._h).decode()
+
+    def scene_cuts(self, params, frames, n_frames, prev_frame=None, state=None, min_scene_len=12, on_device=False):
+        """Scene-cut pass over `n_frames` frames (host bytes, or device pointers with on_device=True).
+        Returns ([luma SAD vs predecessor], [is_cut], state)."""
+        state = state if state is not None else SceneState()
+        sad = (C.c_uint64 * n_frames)()
+        cut = (C.c_uint8 * n_frames)()
+        if on_device:
+            fptr = C.c_void_p(int(frames))
+            pptr = C.c_void_p(int(prev_frame)) if prev_frame else None
+        else:
+            keep = bytes(frames)
+            fptr = C.cast(C.c_char_p(keep), C.c_void_p)
+            keep2 = bytes(prev_frame) if prev_frame is not None else None
+            pptr = C.cast(C.c_char_p(keep2), C.c_void_p) if keep2 is not None else None
+        rc = _lib.av1mi_scene_cuts(self._h, C.byref(params), fptr, n_frames, 1 if on_device else 0, pptr, C.byref(state),
+                                   min_scene_len, sad, cut)
+        _raise_for(rc, self.last_error())
+        return list(sad), list(cut), state
 
     def encode_chunk(self, params, frames, n_frames, on_device=False, want_recon=False, recon_ptr=None):
         """frames: bytes-like/numpy (host) or an int device pointer (on_device=True).

@@ -94,6 +94,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   if (rc) { if (y.f) fclose(y.f); return rc; }
   av1mi_params prm = job->params;
   prm.width = y.w; prm.height = y.h; prm.bit_depth = y.bd;
+  const bool scene_mode = job->chunk_frames == 0;
   const uint32_t chunk_frames = job->chunk_frames ? job->chunk_frames : 60;
   // contexts: `workers` chunks in flight, spread round-robin over the allowed GPUs
   int ndev = 0;
@@ -107,6 +108,12 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   for (uint32_t i = 0; i < workers; i++) {
     rc = av1mi_ctx_create(devs[i % devs.size()], &ctxs[i]);
     if (rc) { for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
+  }
+  av1mi_ctx *det_ctx = nullptr;  // the reader thread's own context for the scene-cut pass
+  if (scene_mode) {
+    rc = av1mi_ctx_create(devs[0], &det_ctx);
+    if (rc) { for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
+    ctxs.push_back(det_ctx);  // destroyed with the others; gets no worker thread
   }
   std::string tmp = std::string(job->output_path) + ".tmp." + std::to_string((long)getpid());
   FILE *fo = fopen(tmp.c_str(), "wb");
@@ -144,7 +151,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
     }
   };
   std::vector<std::thread> threads;
-  for (auto c : ctxs) threads.emplace_back(worker, c);
+  for (auto c : ctxs) if (c != det_ctx) threads.emplace_back(worker, c);
 
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t n_chunks = 0, next_write = 0, frames_done = 0, frames_read = 0;
@@ -186,16 +193,9 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
       next_write++;
     }
   };
-  // reader: split into chunks (fixed length; every chunk starts with a key frame)
-  for (;;) {
-    Chunk *ck = new Chunk();
+  auto enqueue = [&](Chunk *ck) {
     ck->index = n_chunks;
     ck->first_frame = (uint32_t)frames_read;
-    ck->frames.resize((size_t)chunk_frames * y.frame_bytes);
-    int r = 1;
-    while (ck->n_frames < chunk_frames && (r = y4m_read_frame(&y, ck->frames.data() + (size_t)ck->n_frames * y.frame_bytes)) == 1) ck->n_frames++;
-    if (r < 0 && !first_err) first_err = r;
-    if (ck->n_frames == 0) { delete ck; break; }
     frames_read += ck->n_frames;
     n_chunks++;
     {
@@ -206,7 +206,48 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
     }
     cv_work.notify_one();
     drain(false);
-    if (r != 1 || first_err) break;
+  };
+  if (!scene_mode) {
+    // reader: fixed-length chunks (every chunk starts with a key frame)
+    for (;;) {
+      Chunk *ck = new Chunk();
+      ck->frames.resize((size_t)chunk_frames * y.frame_bytes);
+      int r = 1;
+      while (ck->n_frames < chunk_frames && (r = y4m_read_frame(&y, ck->frames.data() + (size_t)ck->n_frames * y.frame_bytes)) == 1) ck->n_frames++;
+      if (r < 0 && !first_err) first_err = r;
+      if (ck->n_frames == 0) { delete ck; break; }
+      enqueue(ck);
+      if (r != 1 || first_err) break;
+    }
+  } else {
+    // reader: chunks end at scene cuts (GPU luma-SAD pass per window of frames, include/av1mi.h: av1mi_scene_cuts)
+    const uint32_t WIN = 32, MIN_SCENE = 12;
+    uint64_t cap = ((uint64_t)4 << 30) / y.frame_bytes;  // keep a chunk's frames under 4 GiB of host memory
+    const uint32_t max_len = (uint32_t)(cap < MIN_SCENE ? MIN_SCENE : (cap > 240 ? 240 : cap));
+    std::vector<uint8_t> win((size_t)WIN * y.frame_bytes), prev(y.frame_bytes);
+    std::vector<uint8_t> cuts(WIN);
+    bool has_prev = false;
+    av1mi_scene_state st = {};
+    Chunk *cur = new Chunk();
+    for (;;) {
+      uint32_t nw = 0;
+      int r = 1;
+      while (nw < WIN && (r = y4m_read_frame(&y, win.data() + (size_t)nw * y.frame_bytes)) == 1) nw++;
+      if (r < 0 && !first_err) first_err = r;
+      if (nw == 0) break;
+      int src = av1mi_scene_cuts(det_ctx, &prm, win.data(), nw, 0, has_prev ? prev.data() : nullptr, &st, MIN_SCENE, nullptr, cuts.data());
+      if (src && !first_err) { first_err = src; break; }
+      for (uint32_t t = 0; t < nw; t++) {
+        if ((cuts[t] && cur->n_frames > 0) || cur->n_frames == max_len) { enqueue(cur); cur = new Chunk(); }
+        const uint8_t *f = win.data() + (size_t)t * y.frame_bytes;
+        cur->frames.insert(cur->frames.end(), f, f + y.frame_bytes);
+        cur->n_frames++;
+      }
+      memcpy(prev.data(), win.data() + (size_t)(nw - 1) * y.frame_bytes, y.frame_bytes);
+      has_prev = true;
+      if (r != 1 || first_err) break;
+    }
+    if (cur->n_frames > 0 && !first_err) enqueue(cur); else delete cur;
   }
   {
     std::lock_guard<std::mutex> lk(mu);
@@ -231,6 +272,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
       const double npx = (double)tot.frames * y.w * y.h / (p ? 4 : 1);
       tot.psnr[p] = tot.sse[p] > 0 ? 10.0 * log10(mx * mx * npx / tot.sse[p]) : 99.0;
     }
+    tot.chunks = n_chunks;
     *total = tot;
   }
   return AV1MI_OK;

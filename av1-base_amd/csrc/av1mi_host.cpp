@@ -26,6 +26,7 @@
 
 extern "C" {
 hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, hipStream_t s);
+hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
                                 hipStream_t s, hipEvent_t mid);
@@ -453,6 +454,71 @@ const char *av1mi_last_error(const av1mi_ctx *c) { return c ? c->err.c_str() : "
 
 void av1mi_free(void *p) { free(p); }
 
+// Scene-cut rule (include/av1mi.h: av1mi_scene_cuts).  Integer only: d = mean absolute luma difference at 8-bit
+// scale in Q8.  Mirrored by oracle/scenecut.py.
+static int scene_rule_step(av1mi_scene_state *st, int has_prev, uint64_t sad, uint64_t luma_samples, int bit_depth, uint32_t min_len) {
+  if (!has_prev) { st->hist_n = 0; st->frames_since_cut = 1; return 1; }
+  const uint64_t d = ((sad >> (bit_depth - 8)) << 8) / luma_samples;
+  uint64_t sum = 0;
+  for (uint32_t i = 0; i < st->hist_n; i++) sum += st->hist_q8[i];
+  const bool strong = st->hist_n ? (2 * d * st->hist_n >= 5 * sum && d >= 8 * 256) : d >= 24 * 256;
+  if (strong && st->frames_since_cut >= min_len) { st->hist_n = 0; st->frames_since_cut = 1; return 1; }
+  if (!strong) {  // in-scene sample: keep the last 8
+    if (st->hist_n == 8) { for (int i = 0; i < 7; i++) st->hist_q8[i] = st->hist_q8[i + 1]; st->hist_n = 7; }
+    st->hist_q8[st->hist_n++] = (uint32_t)d;
+  }
+  st->frames_since_cut++;
+  return 0;
+}
+
+int av1mi_scene_cuts(av1mi_ctx *c, const av1mi_params *params, const void *frames, uint32_t n_frames, int frames_on_device,
+                     const void *prev_frame, av1mi_scene_state *state, uint32_t min_scene_len, uint64_t *sad_out, uint8_t *is_cut) {
+  if (!c || !frames || !state || n_frames == 0) return AV1MI_E_INVALID_ARG;
+  Resolved r;
+  int rc = resolve(params, &r);
+  if (rc) { set_err(c, "invalid parameters"); return rc; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int bps = r.p.bit_depth > 8 ? 2 : 1;
+  const size_t frame_bytes = (size_t)r.p.width * r.p.height * 3 / 2 * bps;
+  Av1miDevParams P;
+  memset(&P, 0, sizeof(P));
+  P.width = r.p.width; P.height = r.p.height; P.bit_depth = r.p.bit_depth; P.n_frames = (int)n_frames;
+  P.frame_samples = (long)(frame_bytes / bps);
+  hipStream_t s = c->stream;
+  // host input: stage [prev | frames] contiguously on the device (frame_bytes is a multiple of 32)
+  void *d_stage = nullptr;
+  unsigned long long *d_sad = nullptr;
+  const uint8_t *d_frames, *d_prev = nullptr;
+  auto cleanup = [&] { if (d_stage) (void)hipFree(d_stage); if (d_sad) (void)hipFree(d_sad); };
+  hipError_t e = hipMalloc((void **)&d_sad, (size_t)n_frames * 8);
+  if (e == hipSuccess) e = hipMemsetAsync(d_sad, 0, (size_t)n_frames * 8, s);
+  if (e == hipSuccess && !frames_on_device) {
+    e = hipMalloc(&d_stage, (size_t)(n_frames + 1) * frame_bytes);
+    if (e == hipSuccess && prev_frame) e = hipMemcpyAsync(d_stage, prev_frame, frame_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync((uint8_t *)d_stage + frame_bytes, frames, (size_t)n_frames * frame_bytes, hipMemcpyHostToDevice, s);
+    d_frames = (const uint8_t *)d_stage + frame_bytes;
+    d_prev = prev_frame ? (const uint8_t *)d_stage : nullptr;
+  } else {
+    d_frames = (const uint8_t *)frames;
+    d_prev = (const uint8_t *)prev_frame;
+    if (((uintptr_t)d_frames | (uintptr_t)d_prev) & 15) { cleanup(); set_err(c, "device frames must be 16-byte aligned"); return AV1MI_E_INVALID_ARG; }
+  }
+  std::vector<unsigned long long> sad(n_frames, 0);
+  if (e == hipSuccess) e = av1mi_launch_luma_sad(&P, d_frames, d_prev, d_sad, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(sad.data(), d_sad, (size_t)n_frames * 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  cleanup();
+  if (e != hipSuccess) { set_err(c, "scene-cut pass failed: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? AV1MI_E_OOM : AV1MI_E_HIP; }
+  const uint64_t luma = (uint64_t)r.p.width * r.p.height;
+  for (uint32_t t = 0; t < n_frames; t++) {
+    const int has_prev = t > 0 || prev_frame != nullptr;
+    const int cut = scene_rule_step(state, has_prev, sad[t], luma, (int)r.p.bit_depth, min_scene_len ? min_scene_len : 1);
+    if (is_cut) is_cut[t] = (uint8_t)cut;
+    if (sad_out) sad_out[t] = sad[t];
+  }
+  return AV1MI_OK;
+}
+
 static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const void *frames, uint32_t n_frames, int frames_on_device,
                              av1mi_buf *out, uint32_t *frame_sizes, void *recon, av1mi_report *report);
 
@@ -568,6 +634,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     report->frames = n_frames;
     report->bytes = total;
     report->cap_scale = (uint32_t)c->cap_scale;
+    report->chunks = 1;
     const double mx = (double)((1 << P.bit_depth) - 1);
     for (int pl = 0; pl < 3; pl++) {
       double t = 0;

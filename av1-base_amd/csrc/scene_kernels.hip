@@ -1,0 +1,59 @@
+// scene_kernels.hip - luma frame-difference statistics for the scene-cut chunker.
+//
+// Replaces the scene detection av1an runs before it splits a clip into chunks for its workers
+// (`--workers N --temp DIR`, /root/reference/crates/daemon/src/encode/av1an.rs:100-104; SURVEY.md §8a
+// row a9): SAD of the luma plane of every frame against its predecessor.  The cut rule itself is a few
+// integer comparisons per frame and runs on the host (av1mi_host.cpp: decide_scene_cuts).
+//
+// HBM-bound streaming kernel: every luma sample of the chunk is read twice (as frame t and as frame
+// t-1) with 16-byte loads per lane; algorithmic bytes 2*L*b per frame pair (L luma samples).
+#include <hip/hip_runtime.h>
+#include "av1mi_dev.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned sad_u8x4(unsigned a, unsigned b, unsigned acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+
+template <int BPS>
+__device__ __forceinline__ unsigned sad16(const uint4 &a, const uint4 &b) {
+  unsigned s = 0;
+  if (BPS == 1) {
+    s = sad_u8x4(a.x, b.x, s); s = sad_u8x4(a.y, b.y, s); s = sad_u8x4(a.z, b.z, s); s = sad_u8x4(a.w, b.w, s);
+  } else {
+    s = __builtin_amdgcn_sad_u16(a.x, b.x, s); s = __builtin_amdgcn_sad_u16(a.y, b.y, s);
+    s = __builtin_amdgcn_sad_u16(a.z, b.z, s); s = __builtin_amdgcn_sad_u16(a.w, b.w, s);
+  }
+  return s;
+}
+
+// grid (x = slices of a frame, y = frame index t).  prev0 = predecessor of frame 0 (may be null: sad[0] = 0).
+template <int BPS>
+__global__ void __launch_bounds__(256) luma_sad_kernel(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ prev0,
+                                                      size_t frame_bytes, size_t luma_bytes,
+                                                      unsigned long long *__restrict__ sad /* [n_frames] */) {
+  const int t = blockIdx.y;
+  const uint8_t *cur = frames + (size_t)t * frame_bytes;
+  const uint8_t *prv = t ? cur - frame_bytes : prev0;
+  if (!prv) return;
+  const size_t nvec = luma_bytes >> 4;  // luma_bytes is a multiple of 64 (width, height multiples of 8)
+  const uint4 *c4 = reinterpret_cast<const uint4 *>(cur), *p4 = reinterpret_cast<const uint4 *>(prv);
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) acc += sad16<BPS>(c4[i], p4[i]);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&sad[t], acc);
+}
+
+}  // namespace
+
+// `frames`/`prev0` must be 16-byte aligned device pointers (checked by the caller); sad[] zeroed by the caller.
+extern "C" hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad,
+                                            hipStream_t stream) {
+  const int bps = P->bit_depth > 8 ? 2 : 1;
+  const size_t frame_bytes = (size_t)P->frame_samples * bps, luma_bytes = (size_t)P->width * P->height * bps;
+  dim3 grid(128, P->n_frames);
+  if (bps == 1)
+    hipLaunchKernelGGL(luma_sad_kernel<1>, grid, dim3(256), 0, stream, (const uint8_t *)frames, (const uint8_t *)prev0, frame_bytes, luma_bytes, sad);
+  else
+    hipLaunchKernelGGL(luma_sad_kernel<2>, grid, dim3(256), 0, stream, (const uint8_t *)frames, (const uint8_t *)prev0, frame_bytes, luma_bytes, sad);
+  return hipGetLastError();
+}

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AV1MI_ABI_VERSION 1
+#define AV1MI_ABI_VERSION 2
 
 /* positive failure codes (-> Av1anFailed(code)) */
 enum {
@@ -73,7 +73,10 @@ typedef struct {
   float ms_symbolize;       /* part of ms_entropy spent in the symbolize kernel */
   uint64_t n_symbols;       /* arithmetic-coded symbols */
   uint32_t max_tile_symbols; /* longest tile: the serial chain that bounds the range-coding kernel */
-  uint32_t cap_scale;          /* per-tile capacity multiplier the chunk finally ran with (1 unless a tile overflowed and the chunk was re-run) */
+  uint32_t cap_scale;       /* per-tile capacity multiplier the chunk finally ran with (1 unless a tile overflowed
+                               and the chunk was re-run) */
+  uint32_t chunks;          /* av1mi_encode_file: chunks the clip was split into (1 for av1mi_encode_chunk) */
+  uint32_t reserved1;
 } av1mi_report;
 
 void av1mi_default_params(av1mi_params *p, uint32_t width, uint32_t height, uint32_t bit_depth);
@@ -98,6 +101,27 @@ int av1mi_encode_chunk(av1mi_ctx *ctx, const av1mi_params *params, const void *f
 
 void av1mi_free(void *p);
 
+/* ---- scene-cut detection (the chunker) ----------------------------------------------------
+ * Replaces the scene detection av1an performs before it hands chunks to its `--workers N` encoders
+ * (`--workers`, `--temp`: crates/daemon/src/encode/av1an.rs:100-104).
+ * Device: SAD of every frame's luma against its predecessor (one streaming kernel).  Host: frame t
+ * starts a new scene iff  2*d(t) >= 5*mean(d over the last <= 8 in-scene frames)  and  d(t) >= 8
+ * (d = mean absolute luma difference at 8-bit scale, Q8 integers; with no history yet: d(t) >= 24)
+ * and the current scene already holds `min_scene_len` frames.  A frame without predecessor
+ * (`prev_frame` NULL and t = 0) always starts a scene.  `state` (zero-initialised by the caller) carries
+ * the history across calls so a clip can be streamed window by window; `prev_frame` is the last frame of
+ * the previous window (same residency as `frames`).  Outputs (each n_frames entries, optional):
+ * `sad` = luma SAD against the predecessor (0 for a frame without one), `is_cut` = 1 where a scene starts. */
+typedef struct {
+  uint32_t frames_since_cut;
+  uint32_t hist_n;
+  uint32_t hist_q8[8];
+} av1mi_scene_state;
+
+int av1mi_scene_cuts(av1mi_ctx *ctx, const av1mi_params *params, const void *frames, uint32_t n_frames,
+                     int frames_on_device, const void *prev_frame, av1mi_scene_state *state,
+                     uint32_t min_scene_len, uint64_t *sad, uint8_t *is_cut);
+
 /* ---- the drop-in for `run_av1an` ---------------------------------------------------------
  * Replaces  pub fn run_av1an(params: &Av1anEncodeParams) -> Result<(), EncodeError>
  * (crates/daemon/src/encode/av1an.rs:126-139), called from JobExecutor::execute through
@@ -109,7 +133,9 @@ typedef struct {
   const char *output_path;  /* IVF written atomically (tmp + rename); never left zero-length */
   const char *temp_dir;     /* caller-owned scratch (job_executor.rs:275-276); only tmp files go here */
   uint32_t workers;         /* chunks in flight = contexts (one per visible GPU, round-robin) */
-  uint32_t chunk_frames;    /* frames per chunk (0 = 60) */
+  uint32_t chunk_frames;    /* frames per chunk; 0 = chunks end at detected scene cuts (av1mi_scene_cuts,
+                               min scene 12 frames) and after 240 frames at the latest (the reference's
+                               `--keyint 240`, av1an.rs:14) */
   int32_t gpu_mask;         /* bit i = may use GPU i; <= 0 = all visible */
   av1mi_params params;      /* width/height/bit_depth are taken from the Y4M header */
 } av1mi_job;

@@ -29,3 +29,17 @@ def golden_cases():
         meta["obu"] = open(os.path.join(gdir, name + ".obu"), "rb").read()
         out.append(meta)
     return out
+
+
+@pytest.fixture(scope="session")
+def av1mi():
+    """the product's Python host mirror over the C ABI (loads av1-base_amd/libav1mi.so)"""
+    import av1mi as m
+    return m
+
+
+@pytest.fixture(scope="session")
+def ctx(av1mi):
+    c = av1mi.Context(0)
+    yield c
+    c.close()

@@ -10,19 +10,6 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def av1mi():
-    import av1mi as m
-    return m
-
-
-@pytest.fixture(scope="module")
-def ctx(av1mi):
-    c = av1mi.Context(0)
-    yield c
-    c.close()
-
-
 def raw_of(planes, bd):
     dt = np.uint8 if bd == 8 else np.dtype("<u2")
     return b"".join(p.astype(dt).tobytes() for p in planes)
