@@ -54,6 +54,7 @@ typedef struct {
   int film_grain;         /* 1: film_grain_params_present + apply_grain */
   int fg_y_scaling, fg_c_scaling; /* 0..255 scaling value of both points */
   int fg_seed;            /* grain_seed of this frame (16 bits) */
+  int me_range;           /* inter frames: integer-pel full search, |dx|,|dy| <= me_range (default 8) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */
@@ -80,6 +81,8 @@ typedef struct {
   uint64_t sse[3];        /* reconstruction vs source */
   uint64_t mode_hist[13];
   uint64_t bs_hist[7];
+  uint64_t n_inter_blocks; /* blocks coded with motion compensation (inter frames) */
+  uint64_t inter_mode_hist[4]; /* NEARESTMV, NEARMV, GLOBALMV, NEWMV */
 } Av1oStats;
 
 /* Encode one key frame.  Writes a temporal unit (TD [+ sequence header] + OBU_FRAME) to out.
@@ -87,6 +90,12 @@ typedef struct {
  * Returns bytes written, or <0 on error. */
 long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq_hdr,
                        uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats);
+
+/* Same, with a reference: ref == NULL -> key frame (as av1o_encode_frame); ref != NULL -> INTER_FRAME predicted from
+ * `ref` (the previous frame's final reconstruction, the only reference: LAST_FRAME, slot 0 refreshed every frame).
+ * SURVEY.md §8a rows a13 (motion estimation) and a14 (motion compensation). */
+long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, int with_seq_hdr,
+                        uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats);
 
 /* size of the sequence header OBU etc. helpers used by the tests */
 long av1o_write_sequence_header(const Av1oConfig *cfg, uint8_t *out, size_t cap);

@@ -27,7 +27,7 @@ class Config(C.Structure):
         "width", "height", "bit_depth", "base_q_idx", "tile_w_sb", "tile_h_sb", "min_bs_log2", "max_bs_log2",
         "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping", "enable_cdef")] + [
         ("mode_mask", C.c_uint32), ("still_picture", C.c_int), ("disable_cdf_update", C.c_int),
-        ("film_grain", C.c_int), ("fg_y_scaling", C.c_int), ("fg_c_scaling", C.c_int), ("fg_seed", C.c_int), ("fuzz_coeffs", C.c_int), ("fuzz_density", C.c_int),
+        ("film_grain", C.c_int), ("fg_y_scaling", C.c_int), ("fg_c_scaling", C.c_int), ("fg_seed", C.c_int), ("me_range", C.c_int), ("fuzz_coeffs", C.c_int), ("fuzz_density", C.c_int),
         ("fuzz_maxlevel", C.c_int), ("fuzz_modes", C.c_int)]
 
 
@@ -37,7 +37,8 @@ class Frame(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_symbols", C.c_uint64), ("n_blocks", C.c_uint64), ("n_skip_blocks", C.c_uint64),
-                ("sse", C.c_uint64 * 3), ("mode_hist", C.c_uint64 * 13), ("bs_hist", C.c_uint64 * 7)]
+                ("sse", C.c_uint64 * 3), ("mode_hist", C.c_uint64 * 13), ("bs_hist", C.c_uint64 * 7),
+                ("n_inter_blocks", C.c_uint64), ("inter_mode_hist", C.c_uint64 * 4)]
 
 
 _lib = None
@@ -56,6 +57,9 @@ def lib():
         L.av1o_encode_frame.restype = C.c_long
         L.av1o_encode_frame.argtypes = [C.POINTER(Config), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_size_t,
                                         C.POINTER(Frame), C.POINTER(Stats)]
+        L.av1o_encode_frame2.restype = C.c_long
+        L.av1o_encode_frame2.argtypes = [C.POINTER(Config), C.POINTER(Frame), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_size_t,
+                                         C.POINTER(Frame), C.POINTER(Stats)]
         L.av1o_synthclip_frame.argtypes = [C.POINTER(Frame), C.c_int, C.c_uint64, C.c_int, C.c_int]
         L.av1o_fwd_txfm2d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.av1o_inv_txfm2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -112,16 +116,20 @@ def synthclip_frame(w, h, bit_depth=8, seed=1080, t=0, scene_len=0):
     return planes
 
 
-def encode_frame(cfg, planes, with_seq_hdr=True):
-    """Returns (temporal-unit bytes, [Y,U,V] reconstruction (uint16), Stats)."""
+def encode_frame(cfg, planes, with_seq_hdr=True, ref=None):
+    """Returns (temporal-unit bytes, [Y,U,V] reconstruction (uint16), Stats).  `ref`: the previous frame's
+    reconstruction -> the frame is coded as an INTER_FRAME predicted from it; None -> key frame."""
     src = _planes_to_frame(planes)
+    rf = _planes_to_frame(ref) if ref is not None else None
     rec = lib().av1o_frame_alloc(cfg.width, cfg.height)
     cap = cfg.width * cfg.height * 6 + (1 << 16)
     buf = C.create_string_buffer(cap)
     st = Stats()
-    n = lib().av1o_encode_frame(C.byref(cfg), src, 1 if with_seq_hdr else 0, buf, cap, rec, C.byref(st))
+    n = lib().av1o_encode_frame2(C.byref(cfg), src, rf, 1 if with_seq_hdr else 0, buf, cap, rec, C.byref(st))
     recon = _frame_to_planes(rec)
     lib().av1o_frame_free(src)
+    if rf is not None:
+        lib().av1o_frame_free(rf)
     lib().av1o_frame_free(rec)
     if n < 0:
         raise RuntimeError("av1o_encode_frame failed: %d" % n)

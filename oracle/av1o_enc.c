@@ -96,6 +96,7 @@ void av1o_default_config(Av1oConfig *c, int w, int h, int bit_depth) {
   c->cdef_uv_sec = 0;
   c->cdef_damping = 5;
   c->mode_mask = 0x0007; /* DC, V, H */
+  c->me_range = 8;
   c->fuzz_density = 8;
   c->fuzz_maxlevel = 40;
 }
@@ -206,23 +207,38 @@ static void make_geom(const Av1oConfig *cfg, Geom *g) {
 /* ------------------------------------------------------------------ frame header §5.9 */
 #define TILE_SIZE_BYTES 4
 
-static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, uint8_t *buf, size_t cap) {
+static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, int is_inter, uint8_t *buf, size_t cap) {
   BitW b = { buf, cap, 0 };
   int i;
   if (!cfg->still_picture) {
     bw_put(&b, 0, 1); /* show_existing_frame */
-    bw_put(&b, 0, 2); /* frame_type = KEY_FRAME */
+    bw_put(&b, is_inter ? 1 : 0, 2); /* frame_type = KEY_FRAME / INTER_FRAME */
     bw_put(&b, 1, 1); /* show_frame */
-    /* error_resilient_mode = 1 implied (key frame shown) */
+    /* error_resilient_mode = 1 implied for a shown key frame */
+    if (is_inter) bw_put(&b, 0, 1); /* error_resilient_mode */
   }
   bw_put(&b, (uint32_t)cfg->disable_cdf_update, 1); /* disable_cdf_update */
   /* allow_screen_content_tools = seq_force_screen_content_tools = 0 (still: SELECT -> coded) */
   if (cfg->still_picture) bw_put(&b, 0, 1); /* allow_screen_content_tools */
   if (!cfg->still_picture) bw_put(&b, 0, 1); /* frame_size_override_flag */
-  /* order_hint: 0 bits; primary_ref_frame = NONE (intra) ; refresh_frame_flags = 0xFF implied */
+  /* order_hint: 0 bits (enable_order_hint = 0) */
+  if (is_inter) {
+    bw_put(&b, 7, 3);    /* primary_ref_frame = PRIMARY_REF_NONE: every frame starts from the default CDFs */
+    bw_put(&b, 0x01, 8); /* refresh_frame_flags: this frame replaces slot 0 */
+    /* frame_refs_short_signaling = 0 (no order hints) */
+    for (i = 0; i < 7; i++) bw_put(&b, 0, 3); /* ref_frame_idx[i] = 0: every reference name -> the previous frame */
+  }
+  /* key frame: primary_ref_frame = NONE, refresh_frame_flags = 0xFF implied */
   /* frame_size(): from sequence; superres_params(): none */
   bw_put(&b, 0, 1); /* render_and_frame_size_different */
   /* allow_intrabc not coded (allow_screen_content_tools = 0) */
+  if (is_inter) {
+    bw_put(&b, 0, 1); /* allow_high_precision_mv */
+    bw_put(&b, 0, 1); /* is_filter_switchable */
+    bw_put(&b, 3, 2); /* interpolation_filter = BILINEAR */
+    bw_put(&b, 0, 1); /* is_motion_mode_switchable */
+    /* use_ref_frame_mvs: not coded (enable_ref_frame_mvs = 0) */
+  }
   if (!cfg->still_picture && !cfg->disable_cdf_update) bw_put(&b, 1, 1); /* disable_frame_end_update_cdf */
   /* tile_info() */
   {
@@ -283,14 +299,16 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, uint8_t *b
   }
   /* lr_params(): enable_restoration = 0 */
   bw_put(&b, 0, 1); /* tx_mode_select = 0 -> TX_MODE_LARGEST */
-  /* reference_select / skip_mode / warped motion: not coded for intra frames */
+  if (is_inter) bw_put(&b, 0, 1); /* reference_select = 0: single reference */
+  /* skip_mode_present: not coded (no order hints); allow_warped_motion: not coded (enable_warped_motion = 0) */
   bw_put(&b, 0, 1); /* reduced_tx_set */
-  /* global_motion_params: none for intra */
+  if (is_inter)
+    for (i = 0; i < 7; i++) bw_put(&b, 0, 1); /* global_motion_params: is_global = 0 for LAST..ALTREF */
   if (cfg->film_grain) { /* film_grain_params() §5.9.30 (show_frame = 1) */
     int pl;
     bw_put(&b, 1, 1);                                   /* apply_grain */
     bw_put(&b, (uint32_t)cfg->fg_seed & 0xFFFF, 16);    /* grain_seed */
-    /* key frame: update_grain = 1 implied */
+    if (is_inter) bw_put(&b, 1, 1);                     /* update_grain (implied 1 on key frames) */
     bw_put(&b, 2, 4);                                   /* num_y_points */
     bw_put(&b, 0, 8);   bw_put(&b, (uint32_t)cfg->fg_y_scaling, 8);
     bw_put(&b, 255, 8); bw_put(&b, (uint32_t)cfg->fg_y_scaling, 8);
@@ -334,6 +352,16 @@ typedef struct {
   uint16_t coeff_base_eob[5][2][4][4];
   uint16_t coeff_base[5][2][42][5];
   uint16_t coeff_br[5][2][21][5];
+  /* inter frames */
+  uint16_t y_mode[4][14];
+  uint16_t is_inter[4][3];
+  uint16_t newmv[6][3], globalmv[2][3], refmv[6][3], drl[3][3];
+  uint16_t single_ref[6][3][3]; /* [p1..p6][ctx] */
+  uint16_t inter_tx_set1[2][17], inter_tx_set2[13], inter_tx_set3[4][3];
+  uint16_t mv_joint[5];
+  struct {
+    uint16_t cls[12], class0_fp[2][5], fp[5], sign[3], class0_hp[3], hp[3], class0[3], bits[10][3];
+  } mvc[2];
 } TileCdfs;
 
 static void load_cdf(uint16_t *dst, const uint16_t *src, int nsym) {
@@ -380,6 +408,32 @@ static void init_cdfs(TileCdfs *c, int qidx) {
     }
   for (j = 0; j < 2; j++)
     for (l = 0; l < 3; l++) load_cdf(c->dc_sign[j][l], av1_default_dc_sign_cdf[q][j][l], 2);
+  /* inter frames */
+  for (i = 0; i < 4; i++) {
+    load_cdf(c->y_mode[i], av1_default_if_y_mode_cdf[i], 13);
+    load_cdf(c->is_inter[i], av1_default_is_inter_cdf[i], 2);
+    load_cdf(c->inter_tx_set3[i], av1_default_inter_tx_set3_cdf[i], 2);
+  }
+  for (i = 0; i < 6; i++) {
+    load_cdf(c->newmv[i], av1_default_newmv_cdf[i], 2);
+    load_cdf(c->refmv[i], av1_default_refmv_cdf[i], 2);
+    for (j = 0; j < 3; j++) load_cdf(c->single_ref[i][j], av1_default_single_ref_cdf[i][j], 2);
+  }
+  for (i = 0; i < 2; i++) load_cdf(c->globalmv[i], av1_default_globalmv_cdf[i], 2);
+  for (i = 0; i < 3; i++) load_cdf(c->drl[i], av1_default_drl_cdf[i], 2);
+  for (i = 0; i < 2; i++) load_cdf(c->inter_tx_set1[i], av1_default_inter_tx_set1_cdf[i], 16);
+  load_cdf(c->inter_tx_set2, av1_default_inter_tx_set2_cdf[0], 12);
+  load_cdf(c->mv_joint, av1_default_mv_joint_cdf[0], 4);
+  for (i = 0; i < 2; i++) {
+    load_cdf(c->mvc[i].cls, av1_default_mv_class_cdf[0], 11);
+    for (j = 0; j < 2; j++) load_cdf(c->mvc[i].class0_fp[j], av1_default_mv_class0_fp_cdf[j], 4);
+    load_cdf(c->mvc[i].fp, av1_default_mv_fp_cdf[0], 4);
+    load_cdf(c->mvc[i].sign, av1_default_mv_sign_cdf[0], 2);
+    load_cdf(c->mvc[i].class0_hp, av1_default_mv_class0_hp_cdf[0], 2);
+    load_cdf(c->mvc[i].hp, av1_default_mv_hp_cdf[0], 2);
+    load_cdf(c->mvc[i].class0, av1_default_mv_class0_cdf[0], 2);
+    for (j = 0; j < 10; j++) load_cdf(c->mvc[i].bits[j], av1_default_mv_bits_cdf[j], 2);
+  }
 }
 
 typedef struct Enc_ {
@@ -391,6 +445,11 @@ typedef struct Enc_ {
   uint8_t *mi_bsl;     /* log2 of block size in pixels of the block covering the mi, 0 = not coded */
   uint8_t *mi_skip;
   uint8_t *mi_ymode;
+  /* inter frames */
+  const Av1oFrame *ref; /* LAST_FRAME: the previous frame's final reconstruction; NULL on key frames */
+  uint8_t *mi_is_inter; /* 1: block predicted from LAST_FRAME */
+  uint8_t *mi_newmv;    /* 1: coded as NEWMV (counts towards NewMvCount of later blocks) */
+  int16_t *mi_mv;       /* [mi][2] = {row, col} in 1/8 luma samples */
   int8_t *cdef_idx_sb;
   /* tile state */
   int mi_row_start, mi_row_end, mi_col_start, mi_col_end;
@@ -465,7 +524,7 @@ static void write_golomb(Enc *e, unsigned x) {
   for (i = len - 1; i >= 0; i--) av1o_ec_encode_literal(&e->ec, (v >> i) & 1, 1);
 }
 
-static void write_coeffs(Enc *e, int plane, int log2n, int x4, int y4_sb, int y4_abs, const TxbCoefs *t, int ymode, int bw_eq_tx) {
+static void write_coeffs(Enc *e, int plane, int log2n, int x4, int y4_sb, int y4_abs, const TxbCoefs *t, int ymode, int bw_eq_tx, int is_inter) {
   /* x4: absolute 4x4 column (plane units); y4_sb: 4x4 row within SB (plane units) */
   const int ptype = plane > 0;
   const int txs_ctx = log2n - 2; /* square: (sqr + sqr_up + 1) >> 1 */
@@ -508,7 +567,14 @@ static void write_coeffs(Enc *e, int plane, int log2n, int x4, int y4_sb, int y4
     return;
   }
   /* --- transform_type (luma only, sets with more than one type) */
-  if (plane == 0 && log2n <= 4 && e->cfg->base_q_idx > 0) {
+  if (plane == 0 && is_inter && log2n <= 5 && e->cfg->base_q_idx > 0) {
+    /* inter_tx_type: this build codes every inter block DCT_DCT.  Symbol of DCT_DCT in the inverse maps of
+     * TX_SET_INTER_1 (16 types: 4x4, 8x8) = 7, TX_SET_INTER_2 (12 types: 16x16) = 3, TX_SET_INTER_3
+     * ({IDTX, DCT_DCT}: 32x32) = 1 (spec §5.11.47, Tx_Type_Inter_Inv_Set1/2/3) */
+    if (log2n <= 3) WRITE_SYM(e, 7, cdf->inter_tx_set1[log2n - 2], 16);
+    else if (log2n == 4) WRITE_SYM(e, 3, cdf->inter_tx_set2, 12);
+    else WRITE_SYM(e, 1, cdf->inter_tx_set3[3], 2);
+  } else if (plane == 0 && log2n <= 4 && e->cfg->base_q_idx > 0) {
     if (log2n <= 3) WRITE_SYM(e, tx_type_to_sym(1, t->tx_type), cdf->intra_tx_set1[log2n - 2][ymode], 7);
     else WRITE_SYM(e, tx_type_to_sym(2, t->tx_type), cdf->intra_tx_set2[log2n - 2][ymode], 5);
   }
@@ -710,6 +776,271 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
   return eob;
 }
 
+/* ------------------------------------------------------------------ inter prediction §7.11.3 */
+typedef struct { int row, col; } Mv; /* 1/8 luma samples */
+
+/* Block inter prediction (§7.11.3.4) for an unscaled single reference with the frame-level BILINEAR filter
+ * (Subpel_Filters[3][p] = {0,0,0,128-8p,8p,0,0,0}), rounding InterRound0 = 3, InterRound1 = 11 (8/10 bit,
+ * not compound).  Position of sample (i, j) in 1/16 plane samples: ((x0 + j) << 4) + mv_q4, mv_q4 =
+ * (2*mv) >> subsampling (§7.11.3.3 with xScale = 1 << 14).  Reference samples are clamped to the frame. */
+static void predict_inter(const Enc *e, int plane, int x0, int y0, int n, Mv mv, uint16_t *dst, int dstride) {
+  const Av1oFrame *ref = e->ref;
+  const int ss = plane > 0;
+  const int last_x = (ss ? e->cfg->width / 2 : e->cfg->width) - 1, last_y = (ss ? e->cfg->height / 2 : e->cfg->height) - 1;
+  const int mvq_r = (2 * mv.row) >> ss, mvq_c = (2 * mv.col) >> ss;
+  const int py = (y0 << 4) + mvq_r, px = (x0 << 4) + mvq_c;
+  const int iy = py >> 4, fy = py & 15, ix = px >> 4, fx = px & 15;
+  const int bd = e->cfg->bit_depth;
+  int32_t *mid = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 7) * n);
+  int r, c, t;
+  for (r = 0; r < n + 7; r++)
+    for (c = 0; c < n; c++) {
+      int yy = iy + r - 3, sum = 0;
+      yy = yy < 0 ? 0 : (yy > last_y ? last_y : yy);
+      for (t = 0; t < 8; t++) {
+        int f = t == 3 ? 128 - 8 * fx : (t == 4 ? 8 * fx : 0);
+        int xx = ix + c + t - 3;
+        xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
+        sum += f * (int)ref->p[plane][(size_t)yy * ref->stride[plane] + xx];
+      }
+      mid[r * n + c] = (sum + 4) >> 3; /* Round2(sum, InterRound0) */
+    }
+  for (r = 0; r < n; r++)
+    for (c = 0; c < n; c++) {
+      int sum = 0, v;
+      for (t = 0; t < 8; t++) {
+        int f = t == 3 ? 128 - 8 * fy : (t == 4 ? 8 * fy : 0);
+        sum += f * mid[(r + t) * n + c];
+      }
+      v = (sum + 1024) >> 11; /* Round2(sum, InterRound1) */
+      dst[r * dstride + c] = (uint16_t)(v < 0 ? 0 : (v > (1 << bd) - 1 ? (1 << bd) - 1 : v));
+    }
+  free(mid);
+}
+
+/* Integer-pel full search on luma, encoder-side: cost = SAD(source, reference) +
+ * n * (|dx| + |dy|); candidates keep the reference block within 16 samples of the frame (so no motion
+ * vector ever needs the clamping of §7.10.2.14); ties go to the first candidate in (dy, dx) raster order.
+ * Returns the SAD of the chosen vector. */
+static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
+  const int R = e->cfg->me_range, W = e->cfg->width, H = e->cfg->height;
+  const uint16_t *src = e->src->p[0] + (size_t)y * e->src->stride[0] + x;
+  const uint16_t *ref = e->ref->p[0];
+  const int rs = e->ref->stride[0], sstr = e->src->stride[0];
+  long best_cost = -1;
+  int best_sad = 0, dy, dx, i, j;
+  best->row = best->col = 0;
+  for (dy = -R; dy <= R; dy++)
+    for (dx = -R; dx <= R; dx++) {
+      int sad = 0;
+      long cost;
+      if (x + dx < -16 || x + dx + n > W + 16 || y + dy < -16 || y + dy + n > H + 16) continue;
+      for (i = 0; i < n; i++) {
+        int yy = y + dy + i;
+        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+        for (j = 0; j < n; j++) {
+          int xx = x + dx + j;
+          xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+          sad += abs((int)src[i * sstr + j] - (int)ref[(size_t)yy * rs + xx]);
+        }
+      }
+      cost = (long)sad + (long)n * (abs(dx) + abs(dy));
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_sad = sad; best->row = dy * 8; best->col = dx * 8; }
+    }
+  return best_sad;
+}
+
+/* ------------------------------------------------------------------ motion vector prediction §7.10.2 */
+#define REF_CAT_LEVEL 640
+#define MV_BORDER 128
+typedef struct {
+  Mv mv[10];
+  int weight[10];
+  int num;          /* NumMvFound */
+  int new_count;    /* NewMvCount */
+  int found_match;  /* FoundMatch */
+  int new_ctx, ref_ctx, zero_ctx;
+} MvStack;
+
+static int is_inside(const Enc *e, int r, int c);
+
+/* add_ref_mv_candidate + search_stack (§7.10.2.7/.8) for a single LAST_FRAME reference: a neighbour matches iff it
+ * is inter (every inter block of this build references LAST_FRAME; RefFrame[1] = NONE) */
+static void stack_add(const Enc *e, MvStack *s, int r, int c, int weight) {
+  const size_t idx = (size_t)r * e->g->mi_cols + c;
+  Mv m;
+  int i;
+  if (!e->mi_is_inter[idx]) return;
+  m.row = e->mi_mv[2 * idx];
+  m.col = e->mi_mv[2 * idx + 1];
+  /* lower_mv_precision with allow_high_precision_mv = 0, force_integer_mv = 0 (§7.10.2.3) */
+  if (m.row & 1) m.row += m.row > 0 ? -1 : 1;
+  if (m.col & 1) m.col += m.col > 0 ? -1 : 1;
+  if (e->mi_newmv[idx]) s->new_count++;
+  s->found_match = 1;
+  for (i = 0; i < s->num; i++)
+    if (s->mv[i].row == m.row && s->mv[i].col == m.col) break;
+  if (i < s->num) s->weight[i] += weight;
+  else if (s->num < 8) { s->mv[s->num] = m; s->weight[s->num] = weight; s->num++; }
+}
+static int cand_n4(const Enc *e, int r, int c) { return (1 << e->mi_bsl[(size_t)r * e->g->mi_cols + c]) >> 2; }
+
+static void scan_row(const Enc *e, MvStack *s, int mi_r, int mi_c, int bw4, int delta_row) {
+  int delta_col = 0, i = 0;
+  int end4 = bw4 < e->g->mi_cols - mi_c ? bw4 : e->g->mi_cols - mi_c;
+  const int use16 = bw4 >= 16;
+  if (end4 > 16) end4 = 16;
+  if (abs(delta_row) > 1) { delta_row += mi_r & 1; delta_col = 1 - (mi_c & 1); }
+  while (i < end4) {
+    int r = mi_r + delta_row, c = mi_c + delta_col + i, len;
+    if (!is_inside(e, r, c)) break;
+    len = cand_n4(e, r, c);
+    if (len > bw4) len = bw4;
+    if (abs(delta_row) > 1 && len < 2) len = 2;
+    if (use16 && len < 4) len = 4;
+    stack_add(e, s, r, c, len * 2);
+    i += len;
+  }
+}
+static void scan_col(const Enc *e, MvStack *s, int mi_r, int mi_c, int bh4, int delta_col) {
+  int delta_row = 0, i = 0;
+  int end4 = bh4 < e->g->mi_rows - mi_r ? bh4 : e->g->mi_rows - mi_r;
+  const int use16 = bh4 >= 16;
+  if (end4 > 16) end4 = 16;
+  if (abs(delta_col) > 1) { delta_row = 1 - (mi_r & 1); delta_col += mi_c & 1; }
+  while (i < end4) {
+    int r = mi_r + delta_row + i, c = mi_c + delta_col, len;
+    if (!is_inside(e, r, c)) break;
+    len = cand_n4(e, r, c);
+    if (len > bh4) len = bh4;
+    if (abs(delta_col) > 1 && len < 2) len = 2;
+    if (use16 && len < 4) len = 4;
+    stack_add(e, s, r, c, len * 2);
+    i += len;
+  }
+}
+/* scan_point (§7.10.2.4): the candidate must lie in the tile and have been decoded already */
+static void scan_point(const Enc *e, MvStack *s, int mi_r, int mi_c, int dr, int dc) {
+  int r = mi_r + dr, c = mi_c + dc;
+  if (is_inside(e, r, c) && e->mi_bsl[(size_t)r * e->g->mi_cols + c] != 0) stack_add(e, s, r, c, 4);
+}
+static void sort_stack(MvStack *s, int start, int end) {
+  while (end > start) {
+    int new_end = start, i;
+    for (i = start + 1; i < end; i++)
+      if (s->weight[i - 1] < s->weight[i]) {
+        Mv m = s->mv[i - 1]; int w = s->weight[i - 1];
+        s->mv[i - 1] = s->mv[i]; s->weight[i - 1] = s->weight[i];
+        s->mv[i] = m; s->weight[i] = w;
+        new_end = i;
+      }
+    end = new_end;
+  }
+}
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* find_mv_stack (§7.10.2) for isCompound = 0, RefFrame = {LAST_FRAME, NONE}, identity global motion,
+ * use_ref_frame_mvs = 0 */
+static void build_mv_stack(const Enc *e, int mi_r, int mi_c, int bw4, int bh4, MvStack *s) {
+  int found_above, found_left, close_matches, total_matches, num_nearest, num_new, i;
+  memset(s, 0, sizeof(*s));
+  scan_row(e, s, mi_r, mi_c, bw4, -1);
+  found_above = s->found_match; s->found_match = 0;
+  scan_col(e, s, mi_r, mi_c, bh4, -1);
+  found_left = s->found_match; s->found_match = 0;
+  if ((bw4 > bh4 ? bw4 : bh4) <= 16) scan_point(e, s, mi_r, mi_c, -1, bw4);
+  if (s->found_match) found_above = 1;
+  s->found_match = 0;
+  close_matches = found_above + found_left;
+  num_nearest = s->num;
+  num_new = s->new_count;
+  for (i = 0; i < num_nearest; i++) s->weight[i] += REF_CAT_LEVEL;
+  s->zero_ctx = 0; /* no temporal candidates */
+  scan_point(e, s, mi_r, mi_c, -1, -1);
+  if (s->found_match) found_above = 1;
+  s->found_match = 0;
+  scan_row(e, s, mi_r, mi_c, bw4, -3);
+  if (s->found_match) found_above = 1;
+  s->found_match = 0;
+  scan_col(e, s, mi_r, mi_c, bh4, -3);
+  if (s->found_match) found_left = 1;
+  s->found_match = 0;
+  scan_row(e, s, mi_r, mi_c, bw4, -5);
+  if (s->found_match) found_above = 1;
+  s->found_match = 0;
+  scan_col(e, s, mi_r, mi_c, bh4, -5);
+  if (s->found_match) found_left = 1;
+  s->found_match = 0;
+  total_matches = found_above + found_left;
+  sort_stack(s, 0, num_nearest);
+  sort_stack(s, num_nearest, s->num);
+  if (s->num < 2) {
+    /* extra search (§7.10.2.12): neighbours with any reference; with a single reference in use it can only
+     * meet vectors that are already in the list */
+    int w4 = bw4 < e->g->mi_cols - mi_c ? bw4 : e->g->mi_cols - mi_c, h4 = bh4 < e->g->mi_rows - mi_r ? bh4 : e->g->mi_rows - mi_r;
+    int num4 = w4 < h4 ? w4 : h4, pass;
+    if (num4 > 16) num4 = 16;
+    for (pass = 0; pass < 2; pass++) {
+      int idx = 0;
+      while (idx < num4 && s->num < 2) {
+        int r = pass == 0 ? mi_r - 1 : mi_r + idx, c = pass == 0 ? mi_c + idx : mi_c - 1, k;
+        size_t mi;
+        if (!is_inside(e, r, c)) break;
+        mi = (size_t)r * e->g->mi_cols + c;
+        if (e->mi_is_inter[mi]) {
+          Mv m;
+          m.row = e->mi_mv[2 * mi]; m.col = e->mi_mv[2 * mi + 1];
+          for (k = 0; k < s->num; k++)
+            if (s->mv[k].row == m.row && s->mv[k].col == m.col) break;
+          if (k == s->num) { s->mv[s->num] = m; s->weight[s->num] = 2; s->num++; }
+        }
+        idx += cand_n4(e, r, c);
+      }
+    }
+    for (i = s->num; i < 2; i++) { s->mv[i].row = 0; s->mv[i].col = 0; } /* GlobalMvs[0] */
+  }
+  /* context_and_clamping (§7.10.2.14) */
+  if (close_matches == 0) { s->new_ctx = total_matches < 1 ? total_matches : 1; s->ref_ctx = total_matches; }
+  else if (close_matches == 1) { s->new_ctx = 3 - (num_new < 1 ? num_new : 1); s->ref_ctx = 2 + total_matches; }
+  else { s->new_ctx = 5 - (num_new < 1 ? num_new : 1); s->ref_ctx = 5; }
+  for (i = 0; i < s->num; i++) {
+    int to_top = -(mi_r * 4) * 8, to_bottom = ((e->g->mi_rows - bh4 - mi_r) * 4) * 8;
+    int to_left = -(mi_c * 4) * 8, to_right = ((e->g->mi_cols - bw4 - mi_c) * 4) * 8;
+    s->mv[i].row = clampi(s->mv[i].row, to_top - (MV_BORDER + bh4 * 4 * 8), to_bottom + (MV_BORDER + bh4 * 4 * 8));
+    s->mv[i].col = clampi(s->mv[i].col, to_left - (MV_BORDER + bw4 * 4 * 8), to_right + (MV_BORDER + bw4 * 4 * 8));
+  }
+}
+
+static int drl_ctx(const MvStack *s, int idx) {
+  if (s->weight[idx] >= REF_CAT_LEVEL && s->weight[idx + 1] >= REF_CAT_LEVEL) return 0;
+  if (s->weight[idx] >= REF_CAT_LEVEL && s->weight[idx + 1] < REF_CAT_LEVEL) return 1;
+  if (s->weight[idx] < REF_CAT_LEVEL && s->weight[idx + 1] < REF_CAT_LEVEL) return 2;
+  return 0;
+}
+
+static void write_sym(struct Enc_ *e, int s, uint16_t *icdf, int n);
+/* read_mv_component mirrored (§5.11.32): d = |component difference| in 1/8 samples, > 0 */
+static void write_mv_component(struct Enc_ *e, int comp, int v) {
+  TileCdfs *cdf = &e->cdf;
+  const int sign = v < 0, mag = abs(v), z = mag - 1;
+  int cls = 0, o, d, fr, hp;
+  /* mv_class: class c > 0 covers offsets [16 << (c-1) ... ) in 1/8 units: base(c) = CLASS0_SIZE << (c + 2) */
+  while (cls < 10 && z >= (2 << (cls + 3))) cls++;
+  o = z - (cls ? (2 << (cls + 2)) : 0);
+  d = o >> 3; fr = (o >> 1) & 3; hp = o & 1;
+  write_sym(e, sign, cdf->mvc[comp].sign, 2);
+  write_sym(e, cls, cdf->mvc[comp].cls, 11);
+  if (cls == 0) {
+    write_sym(e, d, cdf->mvc[comp].class0, 2);
+    write_sym(e, fr, cdf->mvc[comp].class0_fp[d], 4);
+  } else {
+    int i;
+    for (i = 0; i < cls; i++) write_sym(e, (d >> i) & 1, cdf->mvc[comp].bits[i], 2);
+    write_sym(e, fr, cdf->mvc[comp].fp, 4);
+  }
+  (void)hp; /* allow_high_precision_mv = 0: hp = 1 is implied, every coded vector has odd offset */
+}
+
 /* ------------------------------------------------------------------ block coding §5.11.5 */
 typedef struct { int ymode, yangle, uvmode, uvangle; } ModeDec;
 
@@ -736,6 +1067,15 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
   int have_ar[2], have_bl[2];
   const int log2n_y = bsl, log2n_uv = bsl - 1 > 5 ? 5 : bsl - 1;
   int tx_y, tx_uv;
+  /* inter frames: the block is either intra (as on key frames) or predicted from LAST_FRAME with `mv` */
+  const int inter_frame = e->ref != NULL;
+  int is_inter = 0, inter_mode = 0 /* 0 NEARESTMV 1 NEARMV 2 GLOBALMV 3 NEWMV */, sad_intra = 0, sad_inter = 0;
+  Mv mv = { 0, 0 };
+  MvStack stk;
+  if (inter_frame) {
+    build_mv_stack(e, mi_r, mi_c, bw4, bw4, &stk);
+    sad_inter = motion_search(e, mi_c * 4, mi_r * 4, n, &mv);
+  }
 
   /* haveAboveRt / haveBelowLft from BlockDecoded (§5.11.35), luma and chroma */
   for (plane = 0; plane < 2; plane++) {
@@ -770,21 +1110,45 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
         if (m == DC_PRED) { sad_dc = sad; continue; }
         if (best < 0 || sad < best) { best = sad; md.ymode = m; }
       }
-      if (sad_dc >= 0 && (best < 0 || 2 * (long)best >= (long)sad_dc)) md.ymode = DC_PRED;
+      if (sad_dc >= 0 && (best < 0 || 2 * (long)best >= (long)sad_dc)) { md.ymode = DC_PRED; best = sad_dc; }
       md.uvmode = md.ymode;
+      sad_intra = best;
     }
-    av1o_predict_intra(e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0], bsl, md.ymode, md.yangle,
-                       edge_a, edge_l, avail_u, avail_l, bd);
+    /* ---- inter frames: motion-compensated prediction wins when its luma SAD is not larger */
+    if (inter_frame) {
+      if (cfg->fuzz_modes) {
+        unsigned r = fuzz_rand(e);
+        is_inter = (r & 3) != 0;
+        switch ((r >> 2) & 3) {
+          case 0: mv.row = mv.col = 0; break;
+          case 1: if (stk.num >= 1) mv = stk.mv[0]; break;
+          case 2: if (stk.num >= 2) mv = stk.mv[1]; break;
+          default: {
+            int R = cfg->me_range, dx = (int)(fuzz_rand(e) % (unsigned)(2 * R + 1)) - R, dy = (int)(fuzz_rand(e) % (unsigned)(2 * R + 1)) - R;
+            mv.row = dy * 8; mv.col = dx * 8;
+          }
+        }
+      } else {
+        is_inter = sad_inter <= sad_intra;
+      }
+    }
+    if (is_inter) predict_inter(e, 0, x, y, n, mv, e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0]);
+    else av1o_predict_intra(e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0], bsl, md.ymode, md.yangle,
+                            edge_a, edge_l, avail_u, avail_l, bd);
   }
-  tx_y = log2n_y <= 4 ? mode_to_txfm[md.ymode] : DCT_DCT;
-  tx_uv = log2n_uv <= 4 ? mode_to_txfm[md.uvmode] : DCT_DCT;
+  tx_y = (log2n_y <= 4 && !is_inter) ? mode_to_txfm[md.ymode] : DCT_DCT;
+  tx_uv = (log2n_uv <= 4 && !is_inter) ? mode_to_txfm[md.uvmode] : DCT_DCT;
   code_tx_block(e, 0, mi_c * 4, mi_r * 4, log2n_y, tx_y, ty);
   /* ---- chroma */
   for (plane = 1; plane < 3; plane++) {
     int nc = 1 << log2n_uv, x = mi_c * 2, y = mi_r * 2;
-    prepare_edges(e, plane, x, y, nc, avail_l, avail_u, have_ar[1], have_bl[1], edge_a, edge_l);
-    av1o_predict_intra(e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane], log2n_uv,
-                       md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd);
+    if (is_inter) {
+      predict_inter(e, plane, x, y, nc, mv, e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane]);
+    } else {
+      prepare_edges(e, plane, x, y, nc, avail_l, avail_u, have_ar[1], have_bl[1], edge_a, edge_l);
+      av1o_predict_intra(e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane], log2n_uv,
+                         md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd);
+    }
     code_tx_block(e, plane, x, y, log2n_uv, tx_uv, plane == 1 ? tu : tv);
   }
   skip = ty->eob == 0 && tu->eob == 0 && tv->eob == 0;
@@ -798,17 +1162,67 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
   }
   /* read_cdef: cdef_bits == 0 -> no literal, but remember that this SB has a coded cdef_idx */
   if (!skip && cfg->enable_cdef) e->cdef_idx_sb[(mi_r >> 4) * g->sb_cols + (mi_c >> 4)] = 0;
-  {
-    int am = intra_mode_context[avail_u ? e->mi_ymode[(mi_r - 1) * g->mi_cols + mi_c] : DC_PRED];
-    int lm = intra_mode_context[avail_l ? e->mi_ymode[mi_r * g->mi_cols + mi_c - 1] : DC_PRED];
-    WRITE_SYM(e, md.ymode, e->cdf.kf_y_mode[am][lm], 13);
+  if (inter_frame) {
+    /* inter_frame_mode_info (§5.11.18): is_inter, context from the neighbours' intra-ness (§8.3.2) */
+    const int a_intra = avail_u ? !e->mi_is_inter[(mi_r - 1) * g->mi_cols + mi_c] : 0;
+    const int l_intra = avail_l ? !e->mi_is_inter[mi_r * g->mi_cols + mi_c - 1] : 0;
+    int ctx;
+    if (avail_u && avail_l) ctx = (l_intra && a_intra) ? 3 : ((l_intra || a_intra) ? 1 : 0);
+    else if (avail_u || avail_l) ctx = 2 * (avail_u ? a_intra : l_intra);
+    else ctx = 0;
+    WRITE_SYM(e, is_inter, e->cdf.is_inter[ctx], 2);
   }
-  if (md.ymode >= V_PRED && md.ymode <= D67_PRED) WRITE_SYM(e, md.yangle + 3, e->cdf.angle_delta[md.ymode - V_PRED], 7);
-  {
-    int cfl_allowed = n <= 32;
-    WRITE_SYM(e, md.uvmode, e->cdf.uv_mode[cfl_allowed][md.ymode], cfl_allowed ? 14 : 13);
+  if (is_inter) {
+    /* inter_block_mode_info (§5.11.23): read_ref_frames -> LAST_FRAME = single_ref_p1 0, p3 0, p4 0.  Contexts
+     * (§8.3.2) compare counts of reference names among the above/left blocks; only LAST_FRAME is ever used. */
+    const int n_last = (avail_u ? e->mi_is_inter[(mi_r - 1) * g->mi_cols + mi_c] : 0) + (avail_l ? e->mi_is_inter[mi_r * g->mi_cols + mi_c - 1] : 0);
+    const int rctx = n_last > 0 ? 2 : 1; /* ref_count_ctx(n_last, 0) */
+    int pred_idx = 0;
+    Mv pred;
+    WRITE_SYM(e, 0, e->cdf.single_ref[0][rctx], 2); /* single_ref_p1: forward group */
+    WRITE_SYM(e, 0, e->cdf.single_ref[2][rctx], 2); /* single_ref_p3: LAST/LAST2 */
+    WRITE_SYM(e, 0, e->cdf.single_ref[3][rctx], 2); /* single_ref_p4: LAST */
+    /* mode: the cheapest name of the chosen vector */
+    if (stk.num >= 1 && mv.row == stk.mv[0].row && mv.col == stk.mv[0].col) inter_mode = 0;
+    else if (stk.num >= 2 && mv.row == stk.mv[1].row && mv.col == stk.mv[1].col) inter_mode = 1;
+    else if (mv.row == 0 && mv.col == 0) inter_mode = 2;
+    else inter_mode = 3;
+    WRITE_SYM(e, inter_mode != 3, e->cdf.newmv[stk.new_ctx], 2);                            /* new_mv: 0 = NEWMV */
+    if (inter_mode != 3) {
+      WRITE_SYM(e, inter_mode != 2, e->cdf.globalmv[stk.zero_ctx], 2);                      /* zero_mv: 0 = GLOBALMV */
+      if (inter_mode != 2) WRITE_SYM(e, inter_mode == 1, e->cdf.refmv[stk.ref_ctx], 2);      /* ref_mv: 0 = NEARESTMV */
+    }
+    if (inter_mode == 3) {        /* NEWMV, RefMvIdx = 0 */
+      if (stk.num > 1) WRITE_SYM(e, 0, e->cdf.drl[drl_ctx(&stk, 0)], 2);
+    } else if (inter_mode == 1) { /* NEARMV, RefMvIdx = 1 */
+      if (stk.num > 2) WRITE_SYM(e, 0, e->cdf.drl[drl_ctx(&stk, 1)], 2);
+    }
+    if (inter_mode == 3) {        /* read_mv: difference to RefStackMv[RefMvIdx] (GlobalMvs[0] = 0 when the list is empty) */
+      int dr, dc, joint;
+      pred = stk.mv[pred_idx];
+      dr = mv.row - pred.row; dc = mv.col - pred.col;
+      joint = (dr != 0 ? 2 : 0) | (dc != 0 ? 1 : 0); /* MV_JOINT_ZERO, HNZVZ, HZVNZ, HNZVNZ */
+      WRITE_SYM(e, joint, e->cdf.mv_joint, 4);
+      if (dr) write_mv_component(e, 0, dr);
+      if (dc) write_mv_component(e, 1, dc);
+    }
+    /* interintra, motion mode, compound type, interpolation filter: nothing coded with this frame header */
+  } else {
+    if (inter_frame) {
+      /* intra_block_mode_info (§5.11.22): y_mode by block-size group */
+      WRITE_SYM(e, md.ymode, e->cdf.y_mode[bsl <= 3 ? 1 : (bsl == 4 ? 2 : 3)], 13);
+    } else {
+      int am = intra_mode_context[avail_u ? e->mi_ymode[(mi_r - 1) * g->mi_cols + mi_c] : DC_PRED];
+      int lm = intra_mode_context[avail_l ? e->mi_ymode[mi_r * g->mi_cols + mi_c - 1] : DC_PRED];
+      WRITE_SYM(e, md.ymode, e->cdf.kf_y_mode[am][lm], 13);
+    }
+    if (md.ymode >= V_PRED && md.ymode <= D67_PRED) WRITE_SYM(e, md.yangle + 3, e->cdf.angle_delta[md.ymode - V_PRED], 7);
+    {
+      int cfl_allowed = n <= 32;
+      WRITE_SYM(e, md.uvmode, e->cdf.uv_mode[cfl_allowed][md.ymode], cfl_allowed ? 14 : 13);
+    }
+    if (md.uvmode >= V_PRED && md.uvmode <= D67_PRED) WRITE_SYM(e, md.uvangle + 3, e->cdf.angle_delta[md.uvmode - V_PRED], 7);
   }
-  if (md.uvmode >= V_PRED && md.uvmode <= D67_PRED) WRITE_SYM(e, md.uvangle + 3, e->cdf.angle_delta[md.uvmode - V_PRED], 7);
   /* (palette: allow_screen_content_tools = 0; filter intra: disabled; tx_size: TX_MODE_LARGEST) */
 
   /* ---- residual */
@@ -823,9 +1237,9 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
       }
     }
   } else {
-    write_coeffs(e, 0, log2n_y, mi_c, sb_r, mi_r, ty, md.ymode, 1);
-    write_coeffs(e, 1, log2n_uv, mi_c >> 1, sb_r >> 1, mi_r >> 1, tu, md.ymode, 1);
-    write_coeffs(e, 2, log2n_uv, mi_c >> 1, sb_r >> 1, mi_r >> 1, tv, md.ymode, 1);
+    write_coeffs(e, 0, log2n_y, mi_c, sb_r, mi_r, ty, md.ymode, 1, is_inter);
+    write_coeffs(e, 1, log2n_uv, mi_c >> 1, sb_r >> 1, mi_r >> 1, tu, md.ymode, 1, is_inter);
+    write_coeffs(e, 2, log2n_uv, mi_c >> 1, sb_r >> 1, mi_r >> 1, tv, md.ymode, 1, is_inter);
   }
   /* ---- bookkeeping */
   for (i = 0; i < bw4; i++)
@@ -835,6 +1249,10 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
         e->mi_bsl[idx] = (uint8_t)bsl;
         e->mi_skip[idx] = (uint8_t)skip;
         e->mi_ymode[idx] = (uint8_t)md.ymode;
+        e->mi_is_inter[idx] = (uint8_t)is_inter;
+        e->mi_newmv[idx] = (uint8_t)(is_inter && inter_mode == 3);
+        e->mi_mv[2 * idx] = (int16_t)(is_inter ? mv.row : 0);
+        e->mi_mv[2 * idx + 1] = (int16_t)(is_inter ? mv.col : 0);
       }
     }
   for (plane = 0; plane < 2; plane++) {
@@ -847,7 +1265,8 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
   if (e->stats) {
     e->stats->n_blocks++;
     e->stats->n_skip_blocks += (uint64_t)skip;
-    e->stats->mode_hist[md.ymode]++;
+    if (is_inter) { e->stats->n_inter_blocks++; e->stats->inter_mode_hist[inter_mode]++; }
+    else e->stats->mode_hist[md.ymode]++;
     e->stats->bs_hist[bsl]++;
   }
   free(pred);
@@ -955,6 +1374,11 @@ static size_t encode_tile(Enc *e, int tr, int tc, uint8_t *out, size_t cap) {
 /* ------------------------------------------------------------------ frame */
 long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq_hdr, uint8_t *out, size_t out_cap,
                        Av1oFrame *recon, Av1oStats *stats) {
+  return av1o_encode_frame2(cfg, src, NULL, with_seq_hdr, out, out_cap, recon, stats);
+}
+
+long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, int with_seq_hdr, uint8_t *out,
+                        size_t out_cap, Av1oFrame *recon, Av1oStats *stats) {
   Geom g;
   Enc *e;
   size_t pos = 0, payload_cap, hdr_bits, n_mi;
@@ -963,6 +1387,7 @@ long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq
   long ret = -1;
   if (cfg->width % 8 || cfg->height % 8 || cfg->width < 8 || cfg->height < 8) return -2;
   if (bd != 8 && bd != 10) return -2;
+  if (cfg->still_picture && ref) return -2;
   make_geom(cfg, &g);
   if (g.tile_cols > 64 || g.tile_rows > 64) return -3;
   e = (Enc *)calloc(1, sizeof(Enc));
@@ -974,6 +1399,10 @@ long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq
   e->mi_bsl = (uint8_t *)calloc(n_mi, 1);
   e->mi_skip = (uint8_t *)calloc(n_mi, 1);
   e->mi_ymode = (uint8_t *)calloc(n_mi, 1);
+  e->ref = ref;
+  e->mi_is_inter = (uint8_t *)calloc(n_mi, 1);
+  e->mi_newmv = (uint8_t *)calloc(n_mi, 1);
+  e->mi_mv = (int16_t *)calloc(n_mi * 2, sizeof(int16_t));
   e->cdef_idx_sb = (int8_t *)malloc((size_t)g.sb_rows * g.sb_cols);
   memset(e->cdef_idx_sb, -1, (size_t)g.sb_rows * g.sb_cols);
   for (p = 0; p < 3; p++) {
@@ -1003,7 +1432,7 @@ long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq
   {
     size_t pp;
     BitW b;
-    hdr_bits = frame_header_bits(cfg, &g, payload, payload_cap);
+    hdr_bits = frame_header_bits(cfg, &g, ref != NULL, payload, payload_cap);
     b.buf = payload; b.cap = payload_cap; b.pos = hdr_bits;
     bw_align(&b); /* byte_alignment() after the frame header inside OBU_FRAME */
     if (g.tile_cols * g.tile_rows > 1) {
@@ -1054,6 +1483,7 @@ done:
   free(tilebuf);
   for (p = 0; p < 3; p++) { free(e->above_lvl[p]); free(e->above_dc[p]); }
   free(e->mi_bsl); free(e->mi_skip); free(e->mi_ymode); free(e->cdef_idx_sb);
+  free(e->mi_is_inter); free(e->mi_newmv); free(e->mi_mv);
   av1o_frame_free(e->rec);
   free(e);
   return ret;

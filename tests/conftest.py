@@ -32,6 +32,19 @@ def golden_cases():
 
 
 @pytest.fixture(scope="session")
+def golden_sequences():
+    """inter-coded sequences: concatenated temporal units + per-frame sizes and dav1d hashes"""
+    import json
+    gdir = os.path.join(ROOT, "tests", "golden")
+    out = []
+    for name in json.load(open(os.path.join(gdir, "index_seq.json"))):
+        meta = json.load(open(os.path.join(gdir, name + ".json")))
+        meta["obu"] = open(os.path.join(gdir, name + ".obu"), "rb").read()
+        out.append(meta)
+    return out
+
+
+@pytest.fixture(scope="session")
 def av1mi():
     """the product's Python host mirror over the C ABI (loads av1-base_amd/libav1mi.so)"""
     import av1mi as m

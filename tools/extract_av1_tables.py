@@ -205,6 +205,62 @@ def main():
     o = dav([1418, 2123, 13340, 18405, 26972, 28343, 32294], "cfl_sign")
     T["cfl_sign"] = ([[int(32768 - x) for x in blob.u16(o, 7)]], (1,), 8)
 
+    # ---- inter-frame CDFs ---------------------------------------------------------------------
+    # boolean tables: dav1d's copy ({32768-p, counter} pairs, CdfModeContext order newmv, globalmv, refmv, drl,
+    # intra); multi-symbol tables: libaom's copy, cross-checked against dav1d's
+    def bool_rows(off, n):
+        raw = blob.u16(off, 2 * n).reshape(n, 2)
+        assert not raw[:, 1].any() and all(0 < x < 32768 for x in raw[:, 0]), (hex(off), raw)
+        return [[int(32768 - x)] for x in raw[:, 0]]
+    pat2 = lambda vals: b"".join(struct.pack("<HH", 32768 - v, 0) for v in vals)
+    hits = blob.find_all(pat2([24035, 16630, 15339, 8386, 12222, 4676]))
+    assert len(hits) == 1, hits
+    o = hits[0]
+    T["newmv"] = (bool_rows(o, 6), (6,), 2)
+    T["globalmv"] = (bool_rows(o + 24, 2), (2,), 2)
+    T["refmv"] = (bool_rows(o + 32, 6), (6,), 2)
+    T["drl"] = (bool_rows(o + 56, 3), (3,), 2)
+    T["is_inter"] = (bool_rows(o + 68, 4), (4,), 2)
+    assert T["globalmv"][0] == [[2175], [1054]] and T["is_inter"][0][0] == [806] and T["drl"][0][0] == [13104]
+    # single_ref: dav1d ref[6 bits p1..p6][3 contexts]; anchored on its first row
+    hits = blob.find_all(pat2([4897, 16973]))
+    assert len(hits) == 1, hits
+    T["single_ref"] = (bool_rows(hits[0], 18), (6, 3), 2)
+    for b_ in range(6):  # P(bit = 0) grows with the context
+        r = T["single_ref"][0][3 * b_:3 * b_ + 3]
+        assert r[0] < r[1] < r[2], r
+    # inter transform type sets (libaom default_inter_ext_tx_cdf[4 sets][4 sizes][17])
+    o = aom([4458, 5560, 7695, 9709], "inter_ext_tx set1")
+    T["inter_tx_set1"] = (read_cdf_table(blob, o, 2, 17, 16), (2,), 16)                  # 4x4, 8x8
+    T["inter_tx_set2"] = (read_cdf_table(blob, o + 34 * 6, 1, 17, 12), (1,), 12)          # 16x16
+    T["inter_tx_set3"] = (read_cdf_table(blob, o + 34 * 8, 4, 17, 2), (4,), 2)            # 4x4 .. 32x32
+    assert T["inter_tx_set3"][0] == [[16384], [4167], [1998], [748]]
+    d1 = [h for h in blob.find_all(icdf_pat(T["inter_tx_set1"][0][1])) if h > aom_kf + 0x10000]
+    d2 = [h for h in blob.find_all(icdf_pat(T["inter_tx_set2"][0][0])) if h > aom_kf + 0x10000]
+    d3 = blob.find_all(pat2([16384, 4167, 1998, 748]))
+    assert d1 and d2 and d3, "inter tx sets: dav1d copy not found"
+    # motion vector CDFs (libaom default_nmv_context: joints, then per component classes, class0_fp, fp, sign,
+    # class0_hp, hp, class0, bits[10]; both components carry the same defaults)
+    hits = [h for h in blob.find_all(icdf_pat([4096, 11264, 19328]) + b"\0\0\0\0" + icdf_pat([28672, 30976, 31858]))]
+    assert len(hits) == 1, hits
+    o = hits[0]
+    T["mv_joint"] = (read_cdf_table(blob, o, 1, 5, 4), (1,), 4)
+    T["mv_class"] = (read_cdf_table(blob, o + 10, 1, 12, 11), (1,), 11)
+    T["mv_class0_fp"] = (read_cdf_table(blob, o + 34, 2, 5, 4), (2,), 4)
+    T["mv_fp"] = (read_cdf_table(blob, o + 54, 1, 5, 4), (1,), 4)
+    rest = read_cdf_table(blob, o + 64, 14, 3, 2)  # sign, class0_hp, hp, class0, bits[10]
+    T["mv_sign"] = ([rest[0]], (1,), 2)
+    T["mv_class0_hp"] = ([rest[1]], (1,), 2)
+    T["mv_hp"] = ([rest[2]], (1,), 2)
+    T["mv_class0"] = ([rest[3]], (1,), 2)
+    T["mv_bits"] = (rest[4:14], (10,), 2)
+    assert T["mv_sign"][0] == [[16384]] and T["mv_class0"][0] == [[27648]] and T["mv_bits"][0][9] == [30720]
+    comp2 = read_cdf_table(blob, o + 10 + 138, 1, 12, 11)  # second component: same defaults
+    assert comp2 == T["mv_class"][0], "mv component 1 differs"
+    dj = [h for h in blob.find_all(icdf_pat([28672, 30976, 31858, 32320, 32551, 32656, 32740, 32757, 32762, 32767])) if h > aom_kf + 0x10000]
+    assert dj, "mv classes: dav1d copy not found"
+    n_inter_checked = 5
+
     # ---- cross-check the libaom mode tables against dav1d's copies ---------------------
     dk = read_cdf_table(blob, dav_kf, 25, 16, 13)
     assert dk == T["kf_y_mode"][0], "kf_y_mode: libaom and dav1d disagree"
@@ -286,7 +342,7 @@ def main():
     with open(args.out, "w") as f:
         f.write("\n".join(out) + "\n")
     print("wrote %s: %d CDF tables, %d q tables (%d cross-checked against dav1d)" % (
-        os.path.relpath(args.out), len(T), len(Q), n_checked))
+        os.path.relpath(args.out), len(T), len(Q), n_checked + n_inter_checked))
 
 
 if __name__ == "__main__":

@@ -64,6 +64,53 @@ def sha(planes):
     return h.hexdigest()
 
 
+# inter-coded sequences (key frame + P frames, each predicted from the previous reconstruction): dav1d decodes the
+# AVIF image sequence and every frame must equal the oracle's reconstruction
+SEQ_CASES = [
+    ("p200x120_bs5", 200, 120, 8, 1080, 4, dict(min_bs_log2=5, max_bs_log2=5)),
+    ("p200x120_bs4_10b", 200, 120, 10, 1080, 3, dict(min_bs_log2=4, max_bs_log2=4)),
+    ("p136_bs3", 136, 136, 8, 3, 3, dict(min_bs_log2=3, max_bs_log2=3)),
+    ("p328x248_bs5_me16", 328, 248, 8, 7, 3, dict(min_bs_log2=5, max_bs_log2=5, me_range=16)),
+    ("p200x120_static_grain", 200, 120, 10, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, disable_cdf_update=1, film_grain=1, fg_y_scaling=0,
+                                                        fg_c_scaling=0, fg_seed=99)),
+    ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
+    ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
+    ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
+    ("pfuzz_onetile_bs3", 328, 248, 8, 24, 3, dict(min_bs_log2=3, max_bs_log2=3, tile_w_sb=64, tile_h_sb=64, fuzz_modes=5)),
+    ("pfuzz_tiles2x2_me16", 328, 248, 10, 25, 3, dict(min_bs_log2=4, max_bs_log2=4, tile_w_sb=2, tile_h_sb=2, fuzz_modes=6, me_range=16)),
+]
+
+
+def make_sequences():
+    index = []
+    for name, w, h, bd, seed, n, kw in SEQ_CASES:
+        cfg = av1o.default_config(w, h, bd, **kw)
+        tus, recs, ref, modes, ninter = [], [], None, [0, 0, 0, 0], 0
+        for t in range(n):
+            src = av1o.synthclip_frame(w, h, bd, seed=seed, t=t)
+            tu, rec, st = av1o.encode_frame(cfg, src, with_seq_hdr=(t == 0), ref=ref)
+            tus.append(tu)
+            recs.append(rec)
+            ref = rec
+            ninter += int(st.n_inter_blocks)
+            modes = [a + int(b) for a, b in zip(modes, st.inter_mode_hist)]
+        dec = oracle_avif.decode_sequence(oracle_avif.wrap_avis(tus, w, h, bd), w, h)
+        if len(dec) != n:
+            raise SystemExit("%s: dav1d decoded %d of %d frames" % (name, len(dec), n))
+        for t in range(n):
+            for p in range(3):
+                if not (dec[t][p].astype(np.uint16) == recs[t][p]).all():
+                    raise SystemExit("%s: frame %d plane %d: dav1d output differs from the oracle reconstruction" % (name, t, p))
+        open(os.path.join(OUT, name + ".obu"), "wb").write(b"".join(tus))
+        meta = dict(name=name, width=w, height=h, bit_depth=bd, seed=seed, frames=n, config=kw, frame_bytes=[len(x) for x in tus],
+                    dav1d_sha256=[sha(d) for d in dec], inter_blocks=ninter, inter_modes_nearest_near_global_new=modes,
+                    decoder="dav1d 1.5.3 via libavif 1.4.1 (Pillow 12.2.0), AVIF image sequence")
+        json.dump(meta, open(os.path.join(OUT, name + ".json"), "w"), indent=1, sort_keys=True)
+        index.append(name)
+        print("%-24s %s B  inter blocks %d modes %s  dav1d == oracle recon on %d frames" % (name, meta["frame_bytes"], ninter, modes, n))
+    json.dump(index, open(os.path.join(OUT, "index_seq.json"), "w"), indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     index = []
@@ -88,6 +135,7 @@ def main():
         index.append(name)
         print("%-24s %6d B  psnr %s  dav1d == oracle recon" % (name, len(tu), meta["psnr"]))
     json.dump(index, open(os.path.join(OUT, "index.json"), "w"), indent=1)
+    make_sequences()
 
 
 if __name__ == "__main__":

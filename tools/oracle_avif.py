@@ -109,6 +109,42 @@ def wrap_avif(obus, width, height, depth=8, mono=False, seq_level_idx=31):
     return ftyp + meta + _box(b"mdat", bytes(obus))
 
 
+def wrap_avis(samples, width, height, depth=8, sync=None, seq_level_idx=31):
+    """Minimal AVIF image SEQUENCE ('avis' brand: moov/trak/stbl, one sample per temporal unit) so that
+    dav1d (through libavif) decodes inter-coded frames in order.  `sync`: 1-based numbers of key samples."""
+    n = len(samples)
+    sync = sync if sync is not None else [1]
+    ftyp = _box(b"ftyp", b"avis" + struct.pack(">I", 0) + b"avis" + b"msf1" + b"iso8" + b"mif1" + b"miaf" + b"MA1B")
+    mat = struct.pack(">9I", 0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000)
+    mvhd = _fullbox(b"mvhd", 0, 0, struct.pack(">IIII", 0, 0, 30, n) + struct.pack(">IH", 0x10000, 0x100) + b"\0" * 10 + mat + b"\0" * 24 + struct.pack(">I", 2))
+    tkhd = _fullbox(b"tkhd", 0, 3, struct.pack(">IIIII", 0, 0, 1, 0, n) + b"\0" * 8 + struct.pack(">HHHH", 0, 0, 0, 0) + mat +
+                    struct.pack(">II", width << 16, height << 16))
+    mdhd = _fullbox(b"mdhd", 0, 0, struct.pack(">IIIIHH", 0, 0, 30, n, 0x55C4, 0))
+    hdlr = _fullbox(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"pict") + b"\0" * 12 + b"\0")
+    vmhd = _fullbox(b"vmhd", 0, 1, b"\0" * 8)
+    dinf = _box(b"dinf", _fullbox(b"dref", 0, 0, struct.pack(">I", 1) + _fullbox(b"url ", 0, 1, b"")))
+    av1c = _box(b"av1C", av1c_bytes(depth, False, 0, seq_level_idx))
+    ccst = _fullbox(b"ccst", 0, 0, struct.pack(">I", 0))
+    av01 = _box(b"av01", b"\0" * 6 + struct.pack(">H", 1) + b"\0" * 16 + struct.pack(">HHIIIH", width, height, 0x480000, 0x480000, 0, 1) +
+                b"\0" * 32 + struct.pack(">Hh", 0x18, -1) + av1c + ccst)
+    stsd = _fullbox(b"stsd", 0, 0, struct.pack(">I", 1) + av01)
+    stts = _fullbox(b"stts", 0, 0, struct.pack(">III", 1, n, 1))
+    stsc = _fullbox(b"stsc", 0, 0, struct.pack(">IIII", 1, 1, n, 1))
+    stsz = _fullbox(b"stsz", 0, 0, struct.pack(">II", 0, n) + b"".join(struct.pack(">I", len(x)) for x in samples))
+    stss = _fullbox(b"stss", 0, 0, struct.pack(">I", len(sync)) + b"".join(struct.pack(">I", k) for k in sync))
+
+    def moov_with(offset):
+        stco = _fullbox(b"stco", 0, 0, struct.pack(">II", 1, offset))
+        stbl = _box(b"stbl", stsd + stts + stsc + stsz + stco + stss)
+        minf = _box(b"minf", vmhd + dinf + stbl)
+        mdia = _box(b"mdia", mdhd + hdlr + minf)
+        return _box(b"moov", mvhd + _box(b"trak", tkhd + mdia))
+
+    moov = moov_with(0)
+    moov = moov_with(len(ftyp) + len(moov) + 8)
+    return ftyp + moov + _box(b"mdat", b"".join(bytes(x) for x in samples))
+
+
 def extract_obus(avif_bytes):
     """Return the payload of the first mdat box (single-item stills only)."""
     i = 0
@@ -153,6 +189,70 @@ def decode_yuv(avif_bytes):
     finally:
         lib.avifImageDestroy(img)
         lib.avifDecoderDestroy(dec)
+
+
+def _readable_ranges():
+    out = []
+    for line in open("/proc/self/maps"):
+        a, perm = line.split()[:2]
+        if perm.startswith("r"):
+            lo, hi = (int(x, 16) for x in a.split("-"))
+            out.append((lo, hi))
+    return out
+
+
+def _image_of_decoder(dec, width, height):
+    """`avifDecoder.image`: found by probing the struct's leading pointer-sized slots for an avifImage of the
+    expected size (the struct layout differs between libavif versions; nothing is dereferenced blindly)."""
+    ranges = _readable_ranges()
+    slots = (C.c_uint64 * 32).from_address(dec)
+    for v in slots:
+        if v and any(lo <= v and v + C.sizeof(_AvifImageHead) <= hi for lo, hi in ranges):
+            h = _AvifImageHead.from_address(v)
+            if h.width == width and h.height == height and h.depth in (8, 10, 12):
+                return h
+    raise RuntimeError("avifDecoder.image not found")
+
+
+def _planes_of(h):
+    w, hh, depth = h.width, h.height, h.depth
+    out = []
+    for p in range(3):
+        pw, ph = (w, hh) if p == 0 else ((w + 1) // 2, (hh + 1) // 2)
+        rb = h.yuvRowBytes[p]
+        raw = C.string_at(h.yuvPlanes[p], rb * ph)
+        a = np.frombuffer(raw, dtype=np.uint8).reshape(ph, rb)
+        a = a[:, :pw].copy() if depth == 8 else a.view("<u2")[:, :pw].copy()
+        out.append(a)
+    return out
+
+
+def decode_sequence(avis_bytes, width, height):
+    """Decode every frame of an AVIF image sequence with dav1d (via libavif); returns [planes per frame]."""
+    lib = _load()
+    lib.avifDecoderSetIOMemory.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.avifDecoderParse.argtypes = [C.c_void_p]
+    lib.avifDecoderNextImage.argtypes = [C.c_void_p]
+    dec = lib.avifDecoderCreate()
+    frames = []
+    try:
+        buf = bytes(avis_bytes)
+        r = lib.avifDecoderSetIOMemory(dec, buf, len(buf))
+        if r == 0:
+            r = lib.avifDecoderParse(dec)
+        if r != 0:
+            raise RuntimeError("libavif parse failed: %s" % lib.avifResultToString(r).decode())
+        while True:
+            r = lib.avifDecoderNextImage(dec)
+            if r != 0:
+                msg = lib.avifResultToString(r).decode()
+                if "No images remaining" in msg or "no images" in msg.lower():
+                    break
+                raise RuntimeError("libavif/dav1d decode failed at frame %d: %s" % (len(frames), msg))
+            frames.append(_planes_of(_image_of_decoder(dec, width, height)))
+    finally:
+        lib.avifDecoderDestroy(dec)
+    return frames
 
 
 def decode_obus(obus, width, height, depth=8, mono=False):
