@@ -4,6 +4,11 @@
 #define AV1MI_DEV_H
 #include <stdint.h>
 #include <stddef.h>
+#ifdef __HIPCC__
+#define AV1MI_HD __host__ __device__
+#else
+#define AV1MI_HD
+#endif
 
 // Uniform kernel parameters of one chunk (all frames of a chunk share them).
 struct Av1miDevParams {
@@ -26,10 +31,17 @@ struct Av1miDevParams {
   // per-tile bitstream slot
   int tile_slot_bytes;
   int stream_cap;                 // 32-bit symbol-stream entries per tile (multiple of 4)
-  // header blob (identical for every frame): sequence header OBU + frame header payload
-  int seq_hdr_bytes, frame_hdr_bytes;
+  // header blob: sequence header OBU, then one slot of `hdr_slot_bytes` per frame holding that frame's OBU_FRAME
+  // payload prefix (frame header + alignment); frame_hdr_bytes = its length on key frames, inter_hdr_bytes on
+  // inter frames (frames differ only in type and grain_seed)
+  int seq_hdr_bytes, frame_hdr_bytes, inter_hdr_bytes, hdr_slot_bytes;
   int tile_size_bytes;
+  // inter coding: key frame every `keyint` frames of the chunk (1 = all key frames); motion search range
+  int keyint, me_range;
 };
+
+// frame f of a chunk is a key frame iff f % keyint == 0
+AV1MI_HD inline int av1mi_frame_is_inter(const Av1miDevParams &P, int f) { return P.keyint > 1 && (f % P.keyint) != 0; }
 
 // Per 8x8-unit block info written by the recon kernel, read by entropy + CDEF kernels.
 // Only the entry at a block's top-left 8x8 unit carries eobs; mode/skip are replicated over the
@@ -38,10 +50,12 @@ struct Av1miBlkInfo {
   uint8_t ymode;
   uint8_t skip;
   uint8_t bsl;      // log2 block size in pixels (3..6)
-  uint8_t pad;
+  uint8_t is_inter; // inter frames: 1 = predicted from LAST_FRAME with `mv`
   uint16_t eob[3];
-  uint16_t pad2;
+  int16_t mv_row, mv_col;  // 1/8 luma samples (always multiples of 8: integer-pel search)
+  uint16_t pad;
 };
+static_assert(sizeof(Av1miBlkInfo) == 16, "block info is one 16-byte record");
 
 #define AV1MI_SB_LEVELS 6144  // int16 levels per superblock: 64*64 + 2*32*32
 
@@ -67,7 +81,22 @@ struct Av1miCdfLayout {
     EOB_EXTRA = EOB1024 + 4 * 12,          // [5][2][9][3]
     DC_SIGN = EOB_EXTRA + 90 * 3,          // [2][3][3]
     COEFF_BASE_EOB = DC_SIGN + 6 * 3,      // [5][2][4][4]
-    COEFF_BASE = COEFF_BASE_EOB + 40 * 4,  // [5][2][42][5]
+    // inter frames
+    IF_Y_MODE = COEFF_BASE_EOB + 40 * 4,   // [4][14]
+    IS_INTER = IF_Y_MODE + 4 * 14,         // [4][3]
+    NEWMV = IS_INTER + 4 * 3,              // [6][3]
+    GLOBALMV = NEWMV + 6 * 3,              // [2][3]
+    REFMV = GLOBALMV + 2 * 3,              // [6][3]
+    DRL = REFMV + 6 * 3,                   // [3][3]
+    SINGLE_REF = DRL + 3 * 3,              // [6 p1..p6][3 ctx][3]
+    INTER_TX1 = SINGLE_REF + 18 * 3,       // [2][17]
+    INTER_TX2 = INTER_TX1 + 2 * 17,        // [13]
+    INTER_TX3 = INTER_TX2 + 13,            // [4][3]
+    MV_JOINT = INTER_TX3 + 4 * 3,          // [5]
+    MV_COMP = MV_JOINT + 5,                // [2] x { class[12], class0_fp[2][5], fp[5], sign[3], class0_hp[3], hp[3], class0[3], bits[10][3] }
+    MVC_CLASS = 0, MVC_CLASS0_FP = 12, MVC_FP = 22, MVC_SIGN = 27, MVC_CLASS0_HP = 30, MVC_HP = 33, MVC_CLASS0 = 36, MVC_BITS = 39,
+    MVC_SIZE = 69,
+    COEFF_BASE = MV_COMP + 2 * MVC_SIZE,   // [5][2][42][5]
     COEFF_BR = COEFF_BASE + 420 * 5,       // [5][2][21][5]
     TOTAL = COEFF_BR + 210 * 5
   };

@@ -25,7 +25,10 @@
 #include "av1mi_dev.h"
 
 extern "C" {
-hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, hipStream_t s);
+hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
+                              const unsigned long long *me_best, hipStream_t s);
+hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *src, const void *ref, unsigned long long *best, int me_range,
+                                      hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
@@ -84,7 +87,8 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.bit_depth != 8 && p.bit_depth != 10) return AV1MI_E_INVALID_ARG;
   if (p.cq_level > 63 || p.film_grain > 50) return AV1MI_E_INVALID_ARG;
   if (p.keyint == 0) p.keyint = 1;
-  if (p.keyint != 1) return AV1MI_E_UNSUPPORTED;
+  if (p.me_range == 0) p.me_range = 8;
+  if (p.me_range != 8 && p.me_range != 16) return AV1MI_E_INVALID_ARG;
   if (p.block_log2 == 0) p.block_log2 = 5;
   if (p.block_log2 < 3 || p.block_log2 > 5) return AV1MI_E_INVALID_ARG;
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
@@ -146,15 +150,27 @@ std::vector<uint8_t> make_sequence_header(const Resolved &r) {
 
 // OBU_FRAME payload up to the first tile: frame_header_obu (§5.9) + byte_alignment +
 // tile_group_obu's tile_start_and_end_present_flag + byte_alignment (§5.11.1)
-std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint32_t frame_number = 0) {
+std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint32_t frame_number = 0, bool inter = false) {
   const av1mi_params &p = r.p;
   BitWriter b;
   b.put(0, 1);  // show_existing_frame
-  b.put(0, 2);  // frame_type KEY_FRAME
+  b.put(inter ? 1 : 0, 2);  // frame_type KEY_FRAME / INTER_FRAME
   b.put(1, 1);  // show_frame
+  if (inter) b.put(0, 1);  // error_resilient_mode (implied 1 on shown key frames)
   b.put(p.cdf_update ? 0 : 1, 1);  // disable_cdf_update
   b.put(0, 1);  // frame_size_override_flag
+  if (inter) {
+    b.put(7, 3);     // primary_ref_frame = NONE: every frame starts from the default CDFs (tiles of all frames stay independent)
+    b.put(0x01, 8);  // refresh_frame_flags: this frame replaces slot 0
+    for (int i = 0; i < 7; i++) b.put(0, 3);  // ref_frame_idx[i] = 0: every reference name -> the previous frame
+  }
   b.put(0, 1);  // render_and_frame_size_different
+  if (inter) {
+    b.put(0, 1);  // allow_high_precision_mv
+    b.put(0, 1);  // is_filter_switchable
+    b.put(3, 2);  // interpolation_filter BILINEAR
+    b.put(0, 1);  // is_motion_mode_switchable
+  }
   if (p.cdf_update) b.put(1, 1);  // disable_frame_end_update_cdf
   // tile_info: explicit spacing, every tile one superblock
   {
@@ -199,11 +215,14 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
     b.put(p.cdef_uv_pri, 4); b.put(p.cdef_uv_sec, 2);
   }
   b.put(0, 1);  // tx_mode_select = 0: TX_MODE_LARGEST
+  if (inter) b.put(0, 1);  // reference_select = 0
   b.put(0, 1);  // reduced_tx_set
+  if (inter) for (int i = 0; i < 7; i++) b.put(0, 1);  // global_motion_params: is_global = 0
   if (p.film_grain) {  // film_grain_params (§5.9.30): fixed table, per-frame seed
     const uint32_t sy = p.film_grain * 2 > 255 ? 255 : p.film_grain * 2, sc = p.film_grain;
     b.put(1, 1);                                              // apply_grain
     b.put((7391u + 173u * (p.first_frame + frame_number)) & 0xFFFFu, 16);  // grain_seed
+    if (inter) b.put(1, 1);                                   // update_grain (implied on key frames)
     b.put(2, 4); b.put(0, 8); b.put(sy, 8); b.put(255, 8); b.put(sy, 8);  // num_y_points + points
     b.put(0, 1);                                              // chroma_scaling_from_luma
     for (int pl = 0; pl < 2; pl++) { b.put(2, 4); b.put(0, 8); b.put(sc, 8); b.put(255, 8); b.put(sc, 8); }
@@ -255,6 +274,29 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
   emit_rows(v, CL::EOB_EXTRA, &av1_default_eob_extra_cdf[q][0][0][0], 90, 3, nullptr, 2);
   emit_rows(v, CL::DC_SIGN, &av1_default_dc_sign_cdf[q][0][0], 6, 3, nullptr, 2);
   emit_rows(v, CL::COEFF_BASE_EOB, &av1_default_coeff_base_eob_cdf[q][0][0][0], 40, 4, nullptr, 3);
+  // inter frames
+  emit_rows(v, CL::IF_Y_MODE, av1_default_if_y_mode_cdf, 4, 14, nullptr, 13);
+  emit_rows(v, CL::IS_INTER, av1_default_is_inter_cdf, 4, 3, nullptr, 2);
+  emit_rows(v, CL::NEWMV, av1_default_newmv_cdf, 6, 3, nullptr, 2);
+  emit_rows(v, CL::GLOBALMV, av1_default_globalmv_cdf, 2, 3, nullptr, 2);
+  emit_rows(v, CL::REFMV, av1_default_refmv_cdf, 6, 3, nullptr, 2);
+  emit_rows(v, CL::DRL, av1_default_drl_cdf, 3, 3, nullptr, 2);
+  emit_rows(v, CL::SINGLE_REF, &av1_default_single_ref_cdf[0][0], 18, 3, nullptr, 2);
+  emit_rows(v, CL::INTER_TX1, av1_default_inter_tx_set1_cdf, 2, 17, nullptr, 16);
+  emit_rows(v, CL::INTER_TX2, av1_default_inter_tx_set2_cdf, 1, 13, nullptr, 12);
+  emit_rows(v, CL::INTER_TX3, av1_default_inter_tx_set3_cdf, 4, 3, nullptr, 2);
+  emit_rows(v, CL::MV_JOINT, av1_default_mv_joint_cdf, 1, 5, nullptr, 4);
+  for (int c = 0; c < 2; c++) {
+    const size_t b0 = CL::MV_COMP + (size_t)c * CL::MVC_SIZE;
+    emit_rows(v, b0 + CL::MVC_CLASS, av1_default_mv_class_cdf, 1, 12, nullptr, 11);
+    emit_rows(v, b0 + CL::MVC_CLASS0_FP, av1_default_mv_class0_fp_cdf, 2, 5, nullptr, 4);
+    emit_rows(v, b0 + CL::MVC_FP, av1_default_mv_fp_cdf, 1, 5, nullptr, 4);
+    emit_rows(v, b0 + CL::MVC_SIGN, av1_default_mv_sign_cdf, 1, 3, nullptr, 2);
+    emit_rows(v, b0 + CL::MVC_CLASS0_HP, av1_default_mv_class0_hp_cdf, 1, 3, nullptr, 2);
+    emit_rows(v, b0 + CL::MVC_HP, av1_default_mv_hp_cdf, 1, 3, nullptr, 2);
+    emit_rows(v, b0 + CL::MVC_CLASS0, av1_default_mv_class0_cdf, 1, 3, nullptr, 2);
+    emit_rows(v, b0 + CL::MVC_BITS, av1_default_mv_bits_cdf, 10, 3, nullptr, 2);
+  }
   emit_rows(v, CL::COEFF_BASE, &av1_default_coeff_base_cdf[q][0][0][0], 420, 5, nullptr, 4);
   emit_rows(v, CL::COEFF_BR, &av1_default_coeff_br_cdf[q][0][0][0], 210, 5, nullptr, 4);
   return v;
@@ -283,6 +325,7 @@ struct av1mi_ctx {
   uint32_t *d_streams = nullptr, *d_combos = nullptr;
   unsigned long long *d_frame_off = nullptr, *d_sse = nullptr;
   int *d_overflow = nullptr;
+  unsigned long long *d_me = nullptr;  // motion search results per 8x8 unit per frame
   size_t out_cap = 0;
   // host staging (pinned)
   uint8_t *h_out = nullptr;
@@ -312,11 +355,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -360,6 +403,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_frame_off, (nf + 1) * 8));
     HIPCHK(c, hipMalloc((void **)&c->d_sse, nf * 3 * 8));
     HIPCHK(c, hipMalloc((void **)&c->d_overflow, 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_me, nf * nb8 * 8));
     c->cap_frames = n_frames;
     c->ws_scale = c->cap_scale;
   }
@@ -390,6 +434,9 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.tile_slot_bytes = slot;
   P.stream_cap = stream_cap;
   P.tile_size_bytes = 4;
+  P.keyint = (int)p.keyint;
+  P.me_range = (int)p.me_range;
+  P.hdr_slot_bytes = 512;
   return AV1MI_OK;
 }
 
@@ -546,15 +593,20 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   const size_t chunk_bytes = (size_t)n_frames * P.frame_samples * bps;
   hipStream_t s = c->stream;
   // headers + CDFs
-  // header blob: sequence header OBU, then one frame header per frame (equal lengths; they differ only in grain_seed)
-  std::vector<uint8_t> seq = make_sequence_header(r), fh = make_frame_header(r, nullptr, 0);
+  // header blob: sequence header OBU, then one fixed-size slot per frame with that frame's header (key and inter
+  // frames have different lengths; frames of one kind differ only in grain_seed)
+  std::vector<uint8_t> seq = make_sequence_header(r), fh = make_frame_header(r, nullptr, 0, false), fhi = make_frame_header(r, nullptr, 0, true);
   P.seq_hdr_bytes = (int)seq.size();
   P.frame_hdr_bytes = (int)fh.size();
-  if (seq.size() > 256 || fh.size() > 512) { set_err(c, "internal: header larger than its slot"); return AV1MI_E_OVERFLOW; }
-  std::vector<uint8_t> blob(seq);
+  P.inter_hdr_bytes = (int)fhi.size();
+  if (seq.size() > 256 || fh.size() > (size_t)P.hdr_slot_bytes || fhi.size() > (size_t)P.hdr_slot_bytes) { set_err(c, "internal: header larger than its slot"); return AV1MI_E_OVERFLOW; }
+  std::vector<uint8_t> blob(seq.size() + (size_t)n_frames * P.hdr_slot_bytes, 0);
+  memcpy(blob.data(), seq.data(), seq.size());
   for (uint32_t f = 0; f < n_frames; f++) {
-    if (f && r.p.film_grain) fh = make_frame_header(r, nullptr, f);
-    blob.insert(blob.end(), fh.begin(), fh.end());
+    const bool inter = av1mi_frame_is_inter(P, (int)f);
+    std::vector<uint8_t> &h = inter ? fhi : fh;
+    if (r.p.film_grain && f) h = make_frame_header(r, nullptr, f, inter);
+    memcpy(blob.data() + seq.size() + (size_t)f * P.hdr_slot_bytes, h.data(), h.size());
   }
   std::vector<uint16_t> cdf = make_cdf_blob(r.qidx);
   HIPCHK(c, hipMemcpyAsync(c->d_hdr, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
@@ -568,7 +620,33 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     d_src = c->d_src;
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
-  HIPCHK(c, av1mi_launch_recon(&P, d_src, c->d_rec, c->d_levels, c->d_blk, s));
+  const bool inter_chunk = P.keyint > 1 && n_frames > 1;
+  if (!inter_chunk) {
+    HIPCHK(c, av1mi_launch_recon(&P, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
+  } else {
+    // Inter chunk: a P frame needs the previous frame's final (post-CDEF) reconstruction, so motion search,
+    // reconstruction and CDEF run frame by frame; entropy coding of ALL frames follows in one pass (every frame
+    // starts from the default CDFs, so tiles of different frames stay independent).
+    Av1miDevParams P1 = P;
+    P1.n_frames = 1;
+    const size_t fbytes = (size_t)P.frame_samples * bps, nb8 = (size_t)P.b8_rows * P.b8_cols, nsb = (size_t)P.sb_rows * P.sb_cols;
+    HIPCHK(c, hipMemsetAsync(c->d_me, 0xFF, (size_t)n_frames * nb8 * 8, s));
+    for (uint32_t f = 0; f < n_frames; f++) {
+      const uint8_t *srcf = (const uint8_t *)d_src + f * fbytes;
+      uint8_t *recf = (uint8_t *)c->d_rec + f * fbytes, *finf = (uint8_t *)c->d_fin + f * fbytes;
+      Av1miBlkInfo *blkf = c->d_blk + f * nb8;
+      int16_t *lvf = c->d_levels + f * nsb * AV1MI_SB_LEVELS;
+      if (!av1mi_frame_is_inter(P, (int)f)) {
+        HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, nullptr, nullptr, s));
+      } else {
+        const uint8_t *reff = (const uint8_t *)c->d_fin + (f - 1) * fbytes;
+        unsigned long long *mef = c->d_me + f * nb8;
+        HIPCHK(c, av1mi_launch_motion_search(&P1, srcf, reff, mef, P.me_range, s));
+        HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, reff, mef, s));
+      }
+      HIPCHK(c, av1mi_launch_cdef(&P1, recf, finf, blkf, s));
+    }
+  }
   HIPCHK(c, hipEventRecord(c->ev[2], s));
   // CDEF (+SSE) depends only on the reconstruction.  The range-coding kernel is a latency-bound
   // serial chain (one lane per tile: 480 waves, half the SIMDs idle), so CDEF runs beside IT on a
@@ -579,7 +657,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipStreamWaitEvent(s2, c->ev[7], 0));  // ev[7]: recorded between symbolize and range-code
   HIPCHK(c, hipEventRecord(c->ev[8], s2));
-  HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s2));
+  if (!inter_chunk) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s2));
   HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s2));
   HIPCHK(c, hipEventRecord(c->ev[9], s2));
   HIPCHK(c, hipStreamWaitEvent(s, c->ev[9], 0));  // join: everything below sees the CDEF output too

@@ -295,10 +295,12 @@ __global__ void __launch_bounds__(256) frame_layout_kernel(Av1miDevParams P, con
   part[t] = s;
   __syncthreads();
   if (t == 0) {
-    uint32_t run = (uint32_t)P.frame_hdr_bytes;
+    // temporal unit = TD + [sequence header, key frames only] + OBU_FRAME header + size + payload
+    const int inter = av1mi_frame_is_inter(P, f);
+    uint32_t run = (uint32_t)(inter ? P.inter_hdr_bytes : P.frame_hdr_bytes);
     for (int i = 0; i < 256; i++) { uint32_t v = part[i]; part[i] = run; run += v; }
     payload_size[f] = run;
-    frame_size[f] = 2u + (uint32_t)P.seq_hdr_bytes + 1u + (uint32_t)leb128_len(run) + run;
+    frame_size[f] = 2u + (inter ? 0u : (uint32_t)P.seq_hdr_bytes) + 1u + (uint32_t)leb128_len(run) + run;
   }
   __syncthreads();
   uint32_t run = part[t];
@@ -329,17 +331,19 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
   const uint32_t pay = payload_size[f];
   const int ll = leb128_len(pay);
   uint8_t *fo = out + frame_off[f];
-  const int prefix = 2 + P.seq_hdr_bytes + 1 + ll;  // TD + sequence header + OBU_FRAME header + size
+  const int inter = av1mi_frame_is_inter(P, f);
+  const int seq_bytes = inter ? 0 : P.seq_hdr_bytes, hdr_bytes = inter ? P.inter_hdr_bytes : P.frame_hdr_bytes;
+  const int prefix = 2 + seq_bytes + 1 + ll;  // TD + [sequence header] + OBU_FRAME header + size
   if (t == 0) {
     if (lane == 0) {
       fo[0] = 0x12; fo[1] = 0x00;
-      uint8_t *q = fo + 2 + P.seq_hdr_bytes;
+      uint8_t *q = fo + 2 + seq_bytes;
       q[0] = 0x32;
       uint32_t v = pay;
       for (int i = 0; i < ll; i++) { uint8_t b = v & 0x7F; v >>= 7; if (v) b |= 0x80; q[1 + i] = b; }
     }
-    for (int i = lane; i < P.seq_hdr_bytes; i += 64) fo[2 + i] = hdr_blob[i];
-    for (int i = lane; i < P.frame_hdr_bytes; i += 64) fo[prefix + i] = hdr_blob[P.seq_hdr_bytes + (size_t)f * P.frame_hdr_bytes + i];
+    for (int i = lane; i < seq_bytes; i += 64) fo[2 + i] = hdr_blob[i];
+    for (int i = lane; i < hdr_bytes; i += 64) fo[prefix + i] = hdr_blob[P.seq_hdr_bytes + (size_t)f * P.hdr_slot_bytes + i];
   }
   const uint32_t n = tile_bytes[blockIdx.x];
   uint8_t *dst = fo + prefix + tile_off[blockIdx.x];

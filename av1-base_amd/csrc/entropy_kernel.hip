@@ -45,6 +45,10 @@ struct SymLds {
   uint16_t scan[1024 + 256 + 64 + 16];  // scan index -> position, for n = 32, 16, 8, 4
   Av1miBlkInfo info[64];
   uint8_t above_lvl[3][16], above_dc[3][16], left_lvl[3][16], left_dc[3][16];
+  // inter frames: motion vector candidate list of the current block (spec §7.10.2) and, per 8x8 unit, whether
+  // its block was coded as NEWMV
+  int stk_row[10], stk_col[10], stk_w[10];
+  uint8_t newmv[64];
 };
 __shared__ SymLds g_sym;
 #define S (&g_sym)
@@ -136,7 +140,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
 // coefficients of one transform block (spec §5.11.39); x4/y4 in plane 4x4 units local to the SB.
 template <bool FULL>
 __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int adapt, const TileGeo &tg, int plane, int log2n, int x4,
-                                           int y4, int eob, int ymode, const int16_t *lv_global) {
+                                           int y4, int eob, int ymode, int is_inter, const int16_t *lv_global) {
   const int ptype = plane > 0;
   const int txs = log2n - 2;
   const int n = 1 << log2n, w4 = n >> 2;
@@ -162,7 +166,12 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       for (int i = lane; i < n * n / 2; i += 64) { const uint32_t w = g32[i]; S->lv[2 * i] = (int16_t)(w & 0xFFFF); S->lv[2 * i + 1] = (int16_t)(w >> 16); }
       __syncthreads();
     }
-    if (plane == 0 && log2n <= 4) {
+    if (plane == 0 && is_inter) {
+      // inter_tx_type: every inter block is DCT_DCT = symbol 7 / 3 / 1 of TX_SET_INTER_1 / _2 / _3 (§5.11.47)
+      if (log2n <= 3) sym_wide(y, lane, adapt, 7, CL::INTER_TX1 + (log2n - 2) * 17, 16);
+      else if (log2n == 4) sym_wide(y, lane, adapt, 3, CL::INTER_TX2, 12);
+      else sym_wide(y, lane, adapt, 1, CL::INTER_TX3 + 3 * 3, 2);
+    } else if (plane == 0 && log2n <= 4) {
       const int tt = c_mode_txfm[ymode];
       if (log2n <= 3) sym_wide(y, lane, adapt, c_txsym_set1[tt], CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
       else sym_wide(y, lane, adapt, c_txsym_set2[tt], CL::TX_SET2 + ((log2n - 2) * 13 + ymode) * 6, 5);
@@ -308,6 +317,148 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
 #undef l_dc
 }
 
+// ---- motion vector prediction (spec §7.10.2) inside a one-superblock tile ----------------------
+// Everything is uniform across the wave (scalar control flow; the list lives in LDS).  Coordinates are tile-local
+// 4x4 units (0..15); block info is per 8x8 unit; only LAST_FRAME is ever referenced, identity global motion,
+// no temporal candidates.
+struct MvScan {
+  int num, new_count, found;
+  int max_r4, max_c4;   // tile-local limits (frame edge)
+  int cur_z;            // Morton index of the current block's origin unit: units with a smaller index are decoded
+};
+__device__ __forceinline__ int morton8(int ux, int uy) {
+  return (ux & 1) | ((uy & 1) << 1) | ((ux & 2) << 1) | ((uy & 2) << 2) | ((ux & 4) << 2) | ((uy & 4) << 3);
+}
+__device__ __forceinline__ bool mv_inside(const MvScan &m, int r4, int c4) { return r4 >= 0 && c4 >= 0 && r4 < m.max_r4 && c4 < m.max_c4 && r4 < 16 && c4 < 16; }
+__device__ __forceinline__ void stack_add(MvScan &m, int r4, int c4, int weight) {
+  const int u = (r4 >> 1) * 8 + (c4 >> 1);
+  if (!uni(S->info[u].is_inter)) return;
+  const int mr = uni(S->info[u].mv_row), mc = uni(S->info[u].mv_col);  // multiples of 8: lower_mv_precision is a no-op
+  if (uni(S->newmv[u])) m.new_count++;
+  m.found = 1;
+  int i = 0;
+  for (; i < m.num; i++)
+    if (uni(S->stk_row[i]) == mr && uni(S->stk_col[i]) == mc) break;
+  if (i < m.num) S->stk_w[i] = uni(S->stk_w[i]) + weight;
+  else if (m.num < 8) { S->stk_row[m.num] = mr; S->stk_col[m.num] = mc; S->stk_w[m.num] = weight; m.num++; }
+}
+__device__ __forceinline__ int cand_n4(int r4, int c4) { return (1 << uni(S->info[(r4 >> 1) * 8 + (c4 >> 1)].bsl)) >> 2; }
+__device__ __forceinline__ void scan_row(MvScan &m, int r4, int c4, int bw4, int delta_row) {
+  int delta_col = 0, i = 0;
+  const int end4 = imin(imin(bw4, m.max_c4 - c4), 16);
+  if (iabs(delta_row) > 1) { delta_row += r4 & 1; delta_col = 1 - (c4 & 1); }
+  while (i < end4) {
+    const int r = r4 + delta_row, c = c4 + delta_col + i;
+    if (!mv_inside(m, r, c)) break;
+    int len = imin(cand_n4(r, c), bw4);
+    if (iabs(delta_row) > 1) len = imax(len, 2);
+    if (bw4 >= 16) len = imax(len, 4);
+    stack_add(m, r, c, len * 2);
+    i += len;
+  }
+}
+__device__ __forceinline__ void scan_col(MvScan &m, int r4, int c4, int bh4, int delta_col) {
+  int delta_row = 0, i = 0;
+  const int end4 = imin(imin(bh4, m.max_r4 - r4), 16);
+  if (iabs(delta_col) > 1) { delta_row = 1 - (r4 & 1); delta_col += c4 & 1; }
+  while (i < end4) {
+    const int r = r4 + delta_row + i, c = c4 + delta_col;
+    if (!mv_inside(m, r, c)) break;
+    int len = imin(cand_n4(r, c), bh4);
+    if (iabs(delta_col) > 1) len = imax(len, 2);
+    if (bh4 >= 16) len = imax(len, 4);
+    stack_add(m, r, c, len * 2);
+    i += len;
+  }
+}
+__device__ __forceinline__ void scan_point(MvScan &m, int r4, int c4, int dr, int dc) {
+  const int r = r4 + dr, c = c4 + dc;
+  if (mv_inside(m, r, c) && morton8(c >> 1, r >> 1) < m.cur_z) stack_add(m, r, c, 4);
+}
+__device__ __forceinline__ void sort_stack(int start, int end) {
+  while (end > start) {
+    int new_end = start;
+    for (int i = start + 1; i < end; i++) {
+      const int w0 = uni(S->stk_w[i - 1]), w1 = uni(S->stk_w[i]);
+      if (w0 < w1) {
+        const int r0 = uni(S->stk_row[i - 1]), c0 = uni(S->stk_col[i - 1]);
+        S->stk_row[i - 1] = uni(S->stk_row[i]); S->stk_col[i - 1] = uni(S->stk_col[i]); S->stk_w[i - 1] = w1;
+        S->stk_row[i] = r0; S->stk_col[i] = c0; S->stk_w[i] = w0;
+        new_end = i;
+      }
+    }
+    end = new_end;
+  }
+}
+// returns NumMvFound; contexts through the references.  (r4, c4): block origin, n4: block size, all in 4x4 units
+__device__ __forceinline__ int build_mv_stack(const Av1miDevParams &P, const TileGeo &tg, int r4, int c4, int n4, int &new_ctx, int &ref_ctx) {
+  MvScan m;
+  m.num = 0; m.new_count = 0; m.found = 0;
+  m.max_r4 = tg.max_y4_y; m.max_c4 = tg.max_x4_y;
+  m.cur_z = morton8(c4 >> 1, r4 >> 1);
+  scan_row(m, r4, c4, n4, -1);
+  int found_above = m.found; m.found = 0;
+  scan_col(m, r4, c4, n4, -1);
+  int found_left = m.found; m.found = 0;
+  if (n4 <= 16) scan_point(m, r4, c4, -1, n4);
+  if (m.found) found_above = 1;
+  m.found = 0;
+  const int close_matches = found_above + found_left, num_nearest = m.num, num_new = m.new_count;
+  for (int i = 0; i < num_nearest; i++) S->stk_w[i] = uni(S->stk_w[i]) + 640;  // REF_CAT_LEVEL
+  scan_point(m, r4, c4, -1, -1);
+  if (m.found) found_above = 1;
+  m.found = 0;
+  scan_row(m, r4, c4, n4, -3);
+  if (m.found) found_above = 1;
+  m.found = 0;
+  scan_col(m, r4, c4, n4, -3);
+  if (m.found) found_left = 1;
+  m.found = 0;
+  scan_row(m, r4, c4, n4, -5);
+  if (m.found) found_above = 1;
+  m.found = 0;
+  scan_col(m, r4, c4, n4, -5);
+  if (m.found) found_left = 1;
+  const int total_matches = found_above + found_left;
+  sort_stack(0, num_nearest);
+  sort_stack(num_nearest, m.num);
+  // extra search (§7.10.2.12): with one reference in use it only meets vectors already in the list; pad with the
+  // (zero) global vector
+  for (int i = m.num; i < 2; i++) { S->stk_row[i] = 0; S->stk_col[i] = 0; S->stk_w[i] = 0; }
+  if (close_matches == 0) { new_ctx = imin(total_matches, 1); ref_ctx = total_matches; }
+  else if (close_matches == 1) { new_ctx = 3 - imin(num_new, 1); ref_ctx = 2 + total_matches; }
+  else { new_ctx = 5 - imin(num_new, 1); ref_ctx = 5; }
+  // clamping (§7.10.2.14): the motion search keeps every coded vector within 16 samples of the frame, which is
+  // inside the clamp range of every later block - nothing to do
+  (void)P;
+  return m.num;
+}
+__device__ __forceinline__ int drl_ctx(int idx) {
+  const int w0 = uni(S->stk_w[idx]), w1 = uni(S->stk_w[idx + 1]);
+  if (w0 >= 640 && w1 >= 640) return 0;
+  if (w0 >= 640 && w1 < 640) return 1;
+  if (w0 < 640 && w1 < 640) return 2;
+  return 0;
+}
+// read_mv_component mirrored (§5.11.32), v != 0 in 1/8 samples (always a multiple of 8 here)
+__device__ __forceinline__ void sym_mv_component(Sym &y, int lane, int adapt, int comp, int v) {
+  const int base = CL::MV_COMP + comp * CL::MVC_SIZE;
+  const int z = iabs(v) - 1;
+  int cls = 0;
+  while (cls < 10 && z >= (2 << (cls + 3))) cls++;
+  const int o = z - (cls ? (2 << (cls + 2)) : 0);
+  const int d = o >> 3, fr = (o >> 1) & 3;
+  sym_wide(y, lane, adapt, v < 0, base + CL::MVC_SIGN, 2);
+  sym_wide(y, lane, adapt, cls, base + CL::MVC_CLASS, 11);
+  if (cls == 0) {
+    sym_wide(y, lane, adapt, d, base + CL::MVC_CLASS0, 2);
+    sym_wide(y, lane, adapt, fr, base + CL::MVC_CLASS0_FP + d * 5, 4);
+  } else {
+    for (int i = 0; i < cls; i++) sym_wide(y, lane, adapt, (d >> i) & 1, base + CL::MVC_BITS + i * 3, 2);
+    sym_wide(y, lane, adapt, fr, base + CL::MVC_FP, 4);
+  }
+}
+
 __device__ __forceinline__ int icdf_prob(int off, int el) { return (el > 0 ? S->cdf[off + el - 1] : 32768) - S->cdf[off + el]; }
 
 // split decision shared with the recon kernel
@@ -355,6 +506,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     Av1miBlkInfo bi = {};
     if (sbr * 8 + r < P.b8_rows && sbc * 8 + c < P.b8_cols) bi = info[r * P.b8_cols + c];
     S->info[lane] = bi;
+    S->newmv[lane] = 0;
     if (lane < 48) { (&S->above_lvl[0][0])[lane] = 0; (&S->above_dc[0][0])[lane] = 0; (&S->left_lvl[0][0])[lane] = 0; (&S->left_dc[0][0])[lane] = 0; }
   }
   __syncthreads();
@@ -363,6 +515,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   y.pos = 0; y.cap = P.stream_cap;
   y.combo0 = -1; y.combo1 = -1;
   const int adapt = !P.disable_cdf_update;
+  const int inter_frame = av1mi_frame_is_inter(P, f);
   TileGeo tg;
   tg.sb_x = sbc * 64; tg.sb_y = sbr * 64;
   tg.max_x4_y = P.mi_cols - sbc * 16; tg.max_y4_y = P.mi_rows - sbr * 16;
@@ -412,14 +565,66 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
         if (avail_u) sctx += uni(S->info[(b8y - 1) * 8 + b8x].skip);
         if (avail_l) sctx += uni(S->info[b8y * 8 + b8x - 1].skip);
         sym_wide(y, lane, adapt, skip, CL::SKIP + sctx * 3, 2);
-        const int am = uni(c_intra_mode_ctx[avail_u ? S->info[(b8y - 1) * 8 + b8x].ymode : 0]);
-        const int lm = uni(c_intra_mode_ctx[avail_l ? S->info[b8y * 8 + b8x - 1].ymode : 0]);
-        sym_wide(y, lane, adapt, ymode, CL::KF_Y_MODE + (am * 5 + lm) * 14, 13);
-        if (ymode >= 1 && ymode <= 8) sym_wide(y, lane, adapt, 3, CL::ANGLE_DELTA + (ymode - 1) * 8, 7);
-        const int uvmode = ymode;
-        const int cfl_allowed = n <= 32;
-        sym_wide(y, lane, adapt, uvmode, CL::UV_MODE + (cfl_allowed * 13 + ymode) * 15, cfl_allowed ? 14 : 13);
-        if (uvmode >= 1 && uvmode <= 8) sym_wide(y, lane, adapt, 3, CL::ANGLE_DELTA + (uvmode - 1) * 8, 7);
+        const int is_inter = inter_frame ? uni(S->info[b8y * 8 + b8x].is_inter) : 0;
+        if (inter_frame) {
+          // inter_frame_mode_info (§5.11.18): is_inter, context from the neighbours' intra-ness
+          const int a_intra = avail_u ? !uni(S->info[(b8y - 1) * 8 + b8x].is_inter) : 0;
+          const int l_intra = avail_l ? !uni(S->info[b8y * 8 + b8x - 1].is_inter) : 0;
+          int ictx;
+          if (avail_u && avail_l) ictx = (l_intra && a_intra) ? 3 : ((l_intra || a_intra) ? 1 : 0);
+          else if (avail_u || avail_l) ictx = 2 * (avail_u ? a_intra : l_intra);
+          else ictx = 0;
+          sym_wide(y, lane, adapt, is_inter, CL::IS_INTER + ictx * 3, 2);
+        }
+        if (is_inter) {
+          // inter_block_mode_info (§5.11.23): LAST_FRAME = single_ref_p1 0, p3 0, p4 0; then the cheapest name of
+          // the vector the recon kernel used: NEARESTMV, NEARMV, GLOBALMV, else NEWMV against the list's head
+          const int n_last = (avail_u ? uni(S->info[(b8y - 1) * 8 + b8x].is_inter) : 0) + (avail_l ? uni(S->info[b8y * 8 + b8x - 1].is_inter) : 0);
+          const int rctx = n_last > 0 ? 2 : 1;
+          sym_wide(y, lane, adapt, 0, CL::SINGLE_REF + (0 * 3 + rctx) * 3, 2);
+          sym_wide(y, lane, adapt, 0, CL::SINGLE_REF + (2 * 3 + rctx) * 3, 2);
+          sym_wide(y, lane, adapt, 0, CL::SINGLE_REF + (3 * 3 + rctx) * 3, 2);
+          int new_ctx, ref_ctx;
+          const int num = build_mv_stack(P, tg, by >> 2, bx >> 2, n >> 2, new_ctx, ref_ctx);
+          const int mvr = uni(S->info[b8y * 8 + b8x].mv_row), mvc = uni(S->info[b8y * 8 + b8x].mv_col);
+          const int s0r = uni(S->stk_row[0]), s0c = uni(S->stk_col[0]), s1r = uni(S->stk_row[1]), s1c = uni(S->stk_col[1]);
+          int mode;  // 0 NEARESTMV 1 NEARMV 2 GLOBALMV 3 NEWMV
+          if (num >= 1 && mvr == s0r && mvc == s0c) mode = 0;
+          else if (num >= 2 && mvr == s1r && mvc == s1c) mode = 1;
+          else if ((mvr | mvc) == 0) mode = 2;
+          else mode = 3;
+          sym_wide(y, lane, adapt, mode != 3, CL::NEWMV + new_ctx * 3, 2);
+          if (mode != 3) {
+            sym_wide(y, lane, adapt, mode != 2, CL::GLOBALMV + 0 * 3, 2);
+            if (mode != 2) sym_wide(y, lane, adapt, mode == 1, CL::REFMV + ref_ctx * 3, 2);
+          }
+          if (mode == 3) { if (num > 1) sym_wide(y, lane, adapt, 0, CL::DRL + drl_ctx(0) * 3, 2); }
+          else if (mode == 1) { if (num > 2) sym_wide(y, lane, adapt, 0, CL::DRL + drl_ctx(1) * 3, 2); }
+          if (mode == 3) {
+            const int dr = mvr - s0r, dc = mvc - s0c;  // list head, or the zero global vector when the list is empty
+            sym_wide(y, lane, adapt, (dr != 0 ? 2 : 0) | (dc != 0 ? 1 : 0), CL::MV_JOINT, 4);
+            if (dr) sym_mv_component(y, lane, adapt, 0, dr);
+            if (dc) sym_mv_component(y, lane, adapt, 1, dc);
+          }
+          {
+            const int n8 = n >> 3;
+            if (lane < n8 * n8) S->newmv[(b8y + lane / n8) * 8 + b8x + lane % n8] = (uint8_t)(mode == 3);
+          }
+        } else {
+          if (inter_frame) {
+            // intra_block_mode_info (§5.11.22): y_mode by block-size group
+            sym_wide(y, lane, adapt, ymode, CL::IF_Y_MODE + (bsl <= 3 ? 1 : (bsl == 4 ? 2 : 3)) * 14, 13);
+          } else {
+            const int am = uni(c_intra_mode_ctx[avail_u ? S->info[(b8y - 1) * 8 + b8x].ymode : 0]);
+            const int lm = uni(c_intra_mode_ctx[avail_l ? S->info[b8y * 8 + b8x - 1].ymode : 0]);
+            sym_wide(y, lane, adapt, ymode, CL::KF_Y_MODE + (am * 5 + lm) * 14, 13);
+          }
+          if (ymode >= 1 && ymode <= 8) sym_wide(y, lane, adapt, 3, CL::ANGLE_DELTA + (ymode - 1) * 8, 7);
+          const int uvmode = ymode;
+          const int cfl_allowed = n <= 32;
+          sym_wide(y, lane, adapt, uvmode, CL::UV_MODE + (cfl_allowed * 13 + ymode) * 15, cfl_allowed ? 14 : 13);
+          if (uvmode >= 1 && uvmode <= 8) sym_wide(y, lane, adapt, 3, CL::ANGLE_DELTA + (uvmode - 1) * 8, 7);
+        }
         const int w4 = n >> 2, w4c = imax(w4 >> 1, 1);
         const int log2c = bsl - 1;
         if (skip) {
@@ -433,7 +638,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
           for (int pl = 0; pl < 3; pl++) {
             const int l2 = pl ? log2c : bsl;
             const int16_t *lvp = pl == 0 ? sb_levels + by * 64 + bx * n : sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * (n >> 1);
-            sym_coeffs<FULL>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, lvp);
+            sym_coeffs<FULL>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, is_inter, lvp);
           }
         }
       }

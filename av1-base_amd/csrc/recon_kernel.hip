@@ -181,6 +181,31 @@ struct SbCtx {
   int sb_x, sb_y;          // superblock origin in luma pixels
 };
 
+// Inter decision of the current block (inter frames): in = the motion search's result for the block, out (luma
+// pass) = whether motion compensation won; the chroma pass follows it.
+struct InterInfo {
+  const void *ref;         // previous frame's final reconstruction (frame base), nullptr on key frames
+  int mv_row, mv_col;      // 1/8 luma samples (multiples of 8)
+  int sad_inter;           // luma SAD of that vector
+  int is_inter;
+};
+
+// Motion-compensated sample (spec §7.11.3.4, unscaled reference, BILINEAR filter, not compound): position in 1/16
+// plane samples = (coordinate << 4) + mv_q4; rounding InterRound0 = 3, InterRound1 = 11; reference coordinates are
+// clamped to the plane.  Integer positions (every luma sample of this build) reduce to a copy.
+template <typename PIX>
+__device__ __forceinline__ int mc_sample(const PIX *plane, int stride, int last_x, int last_y, int px, int py, int maxv) {
+  const int ix = px >> 4, fx = px & 15, iy = py >> 4, fy = py & 15;
+  const int x0 = ix < 0 ? 0 : (ix > last_x ? last_x : ix), y0 = iy < 0 ? 0 : (iy > last_y ? last_y : iy);
+  const int a = plane[(size_t)y0 * stride + x0];
+  if ((fx | fy) == 0) return a;
+  const int x1 = ix + 1 < 0 ? 0 : (ix + 1 > last_x ? last_x : ix + 1), y1 = iy + 1 < 0 ? 0 : (iy + 1 > last_y ? last_y : iy + 1);
+  const int b = plane[(size_t)y0 * stride + x1], c = plane[(size_t)y1 * stride + x0], d = plane[(size_t)y1 * stride + x1];
+  const int h0 = ((128 - 8 * fx) * a + 8 * fx * b + 4) >> 3, h1 = ((128 - 8 * fx) * c + 8 * fx * d + 4) >> 3;
+  const int v = ((128 - 8 * fy) * h0 + 8 * fy * h1 + 1024) >> 11;
+  return v < 0 ? 0 : (v > maxv ? maxv : v);
+}
+
 // One transform block per lane GROUP.  NPL = 1: the whole wave works on one block of `plane0` (luma,
 // with the mode decision).  NPL = 2: lanes 0-31 work on the U block and lanes 32-63 on the V block of
 // the same position at the same time (same mode, independent data) - chroma transforms are at most
@@ -190,7 +215,7 @@ struct SbCtx {
 // `mode_io`: in = mode to use (chroma), out = decided mode (luma).  eob_out[g] = eob of group g.
 template <typename PIX, int LOG2N, int NPL>
 __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
-                                                  int &mode_io, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
+                                                  int &mode_io, InterInfo &ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
   constexpr int N = 1 << LOG2N;
   constexpr int ST = N + 1;
   constexpr int G = 64 / NPL;              // lanes per group
@@ -273,7 +298,9 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     const bool final_trip = m == 13;
     if (final_trip && NPL == 1 && plane0 == 0) {
       // DC is kept unless the best other candidate at least halves its SAD
-      if (sad_dc >= 0 && (best_sad == 0x7FFFFFFF || 2 * (long)best_sad >= (long)sad_dc)) best_mode = DC_PRED;
+      if (sad_dc >= 0 && (best_sad == 0x7FFFFFFF || 2 * (long)best_sad >= (long)sad_dc)) { best_mode = DC_PRED; best_sad = sad_dc; }
+      // inter frames: motion compensation wins when its luma SAD is not larger
+      if (ii.ref) ii.is_inter = ii.sad_inter <= best_sad;
     }
     const int mode = final_trip ? best_mode : m;
     if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
@@ -288,7 +315,15 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) {
       const int r = p >> LOG2N, c = p & (N - 1);
-      const int pv = pred_pixel<LOG2N>(mode, r, c, dcv, ang, dx, dy, eo);
+      int pv;
+      if (final_trip && ii.is_inter) {
+        const int ss = plane0 > 0;
+        const PIX *rp = static_cast<const PIX *>(ii.ref) + poff;
+        pv = mc_sample<PIX>(rp, gs, (ss ? P->width >> 1 : P->width) - 1, (ss ? P->height >> 1 : P->height) - 1,
+                            ((gx + c) << 4) + ((2 * ii.mv_col) >> ss), ((gy + r) << 4) + ((2 * ii.mv_row) >> ss), (1 << bd) - 1);
+      } else {
+        pv = pred_pixel<LOG2N>(mode, r, c, dcv, ang, dx, dy, eo);
+      }
       const int sv = S->srcblk[po + p];
       if (final_trip) {
         S->blkpix[po + p] = (uint16_t)pv;
@@ -306,7 +341,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   mode_io = best_mode;
   __syncthreads();
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
-  const int txt = LOG2N <= 4 ? c_mode_txfm[best_mode] : 0;
+  const int txt = (LOG2N <= 4 && !ii.is_inter) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
   const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
   constexpr int SH0 = 2, SH1 = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : (LOG2N == 4 ? 2 : 4));
   constexpr int RS = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : 2);
@@ -423,7 +458,8 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
 
 template <typename PIX>
 __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
-                                                  Av1miBlkInfo *info, int b8_stride) {
+                                                  Av1miBlkInfo *info, int b8_stride, const PIX *ref_frame,
+                                                  const unsigned long long *me_best /* this superblock's first unit */) {
   const Av1miDevParams &P = *cx.P;
 #pragma nounroll
   for (int z = 0; z < 64; z++) {  // 8x8 units in Z (partition) order
@@ -434,18 +470,28 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     if (bsl == 0) continue;
     const int n = 1 << bsl;
     int mode = 0;
+    InterInfo ii;
+    ii.ref = ref_frame; ii.is_inter = 0; ii.mv_row = ii.mv_col = 0; ii.sad_inter = 0;
+    if (ref_frame) {
+      // motion search result of this leaf: (cost << 16) | candidate index, cost = SAD + n * (|dx| + |dy|)
+      const unsigned long long key = me_best[(by >> 3) * b8_stride + (bx >> 3)];
+      const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
+      const int dyv = idx / nc - R, dxv = idx % nc - R;
+      ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
+      ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
+    }
     int16_t *lv_y = sb_levels + by * 64 + bx * n;
     int16_t *lv_u = sb_levels + 4096 + (by >> 1) * 32 + (bx >> 1) * (n >> 1), *lv_v = lv_u + 1024;
     // luma (mode decision inside), then U and V together
     switch (bsl) {
-      case 5: tx_item<PIX, 5, 1>(cx, frame, rec_frame, 0, bx, by, mode, lv_y, lv_y, S->eobs); break;
-      case 4: tx_item<PIX, 4, 1>(cx, frame, rec_frame, 0, bx, by, mode, lv_y, lv_y, S->eobs); break;
-      default: tx_item<PIX, 3, 1>(cx, frame, rec_frame, 0, bx, by, mode, lv_y, lv_y, S->eobs); break;
+      case 5: tx_item<PIX, 5, 1>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 4: tx_item<PIX, 4, 1>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      default: tx_item<PIX, 3, 1>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
     }
     switch (bsl) {
-      case 5: tx_item<PIX, 4, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, lv_u, lv_v, S->eobs + 1); break;
-      case 4: tx_item<PIX, 3, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, lv_u, lv_v, S->eobs + 1); break;
-      default: tx_item<PIX, 2, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, lv_u, lv_v, S->eobs + 1); break;
+      case 5: tx_item<PIX, 4, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 4: tx_item<PIX, 3, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      default: tx_item<PIX, 2, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
     }
     if (cx.lane == 0) {
       const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
@@ -454,8 +500,9 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
       for (int i = 0; i < n8; i++)
         for (int j = 0; j < n8; j++) {
           Av1miBlkInfo bi;
-          bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)skip; bi.bsl = (uint8_t)bsl; bi.pad = 0;
-          bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2; bi.pad2 = 0;
+          bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)skip; bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
+          bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2;
+          bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0); bi.pad = 0;
           info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
         }
     }
@@ -464,7 +511,9 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
 
 template <typename PIX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_sb_kernel(Av1miDevParams P, const PIX *__restrict__ src, PIX *__restrict__ rec,
-                                                     int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk) {
+                                                     int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
+                                                     const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
+                                                     const unsigned long long *__restrict__ me_best) {
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
   const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
@@ -490,18 +539,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   __syncthreads();
   int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
   Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
-  encode_superblock<PIX>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols);
+  // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
+  encode_superblock<PIX>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
+                         me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
 }
 #undef S
 
 }  // namespace
 
+// ref == nullptr: P->n_frames key frames in one launch.  ref != nullptr: ONE inter frame (P->n_frames must be 1),
+// predicted from `ref` with the motion search results `me_best` of that frame.
 extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels,
-                                         Av1miBlkInfo *blk, hipStream_t stream) {
+                                         Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, hipStream_t stream) {
   const int grid = P->n_frames * P->sb_rows * P->sb_cols;
   if (P->bit_depth == 8)
-    hipLaunchKernelGGL(recon_sb_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk);
+    hipLaunchKernelGGL(recon_sb_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk,
+                       (const uint8_t *)ref, me_best);
   else
-    hipLaunchKernelGGL(recon_sb_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk);
+    hipLaunchKernelGGL(recon_sb_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk,
+                       (const uint16_t *)ref, me_best);
   return hipGetLastError();
 }

@@ -31,7 +31,7 @@ enum {
   AV1MI_E_OOM = 4,           /* host or device allocation failed */
   AV1MI_E_OVERFLOW = 5,      /* a tile outgrew its bitstream slot */
   AV1MI_E_FORMAT = 6,        /* input file is not a supported Y4M (420, 8/10 bit) */
-  AV1MI_E_UNSUPPORTED = 7    /* valid request this build cannot serve yet (e.g. keyint > 1) */
+  AV1MI_E_UNSUPPORTED = 7    /* valid request this build cannot serve yet (e.g. frames wider than 64 superblocks) */
 };
 
 typedef struct av1mi_ctx av1mi_ctx;
@@ -43,7 +43,9 @@ typedef struct {
   uint32_t width, height;   /* luma size, multiples of 8, yuv 4:2:0 */
   uint32_t bit_depth;       /* 8 or 10 (samples: uint8_t / little-endian uint16_t) */
   uint32_t cq_level;        /* "--crf N": 0..63, mapped to base_q_idx like aom (30 -> 120) */
-  uint32_t keyint;          /* "--keyint": 1 = every frame a key frame (only value served today) */
+  uint32_t keyint;          /* "--keyint": 1 = every frame a key frame; N > 1 = a key frame every N frames of a chunk, the
+                               frames between are INTER frames predicted from the previous reconstruction (one
+                               reference, integer-pel full search; chunks always start with a key frame) */
   uint32_t block_log2;      /* leaf block size log2: 3 (8x8) .. 5 (32x32); 0 = default (5) */
   uint32_t cdf_update;      /* 1 = adaptive CDFs (default), 0 = static CDFs (disable_cdf_update) */
   uint32_t enable_cdef;     /* 1 = CDEF on (default) */
@@ -53,7 +55,8 @@ typedef struct {
                                frame header (2-point scaling functions, value 2N luma / N chroma, AR lag 0);
                                synthesis is decoder-side */
   uint32_t first_frame;     /* number of the chunk's first frame inside the clip (seeds grain_seed per frame) */
-  uint32_t reserved[5];
+  uint32_t me_range;        /* inter frames: motion search range in luma samples, 8 or 16 (0 = 8) */
+  uint32_t reserved[4];
 } av1mi_params;
 
 typedef struct {

@@ -70,7 +70,12 @@ def test_invalid_parameters_map_to_failed(av1mi):
     p = av1mi.default_params(64, 64, 12)
     with pytest.raises(av1mi.EncodeFailed):
         av1mi.write_headers(p)
-    p = av1mi.default_params(64, 64, 8, keyint=240)   # the reference's production keyint: not served yet
+    p = av1mi.default_params(64, 64, 8, keyint=240, me_range=12)   # motion search range: 8 or 16 only
+    with pytest.raises(av1mi.EncodeFailed) as ei:
+        av1mi.write_headers(p)
+    assert ei.value.code == av1mi.E_INVALID_ARG
+    av1mi.write_headers(av1mi.default_params(64, 64, 8, keyint=240))   # the reference's production keyint (av1an.rs:14)
+    p = av1mi.default_params(64 * 65, 64, 8)   # more than 64 superblock columns: needs tiles larger than one superblock
     with pytest.raises(av1mi.EncodeFailed) as ei:
         av1mi.write_headers(p)
     assert ei.value.code == av1mi.E_UNSUPPORTED

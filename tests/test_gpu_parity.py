@@ -209,3 +209,57 @@ def test_film_grain_table_in_frame_headers(av1mi, ctx, oracle):
         assert d[off:off + s[i]] == tu, i
         off += s[i]
     assert len(d) > len(d0) and list(s) != list(s0)
+
+
+def oracle_chunk(oracle, cfg, frames, keyint):
+    """The oracle's restatement of a chunk: key frame every `keyint` frames, P frames from the previous reconstruction."""
+    tus, recs, ref = [], [], None
+    for t, f in enumerate(frames):
+        key = t % keyint == 0
+        tu, rec, st = oracle.encode_frame(cfg, f, with_seq_hdr=key, ref=None if key else ref)
+        tus.append(tu)
+        recs.append(rec)
+        ref = rec
+    return tus, recs
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint,me,cdf", [
+    (64, 64, 8, 3, 5, 8, 8, 1), (200, 120, 8, 5, 5, 4, 8, 1), (200, 120, 10, 4, 4, 240, 8, 1), (136, 136, 8, 3, 3, 3, 8, 1),
+    (328, 248, 10, 3, 5, 240, 16, 1), (72, 56, 8, 4, 4, 2, 16, 0), (648, 360, 8, 3, 5, 240, 8, 1)])
+def test_inter_chunk_bitstream_and_recon_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, me, cdf):
+    """keyint > 1: P frames (motion search, motion compensation, inter syntax incl. the motion-vector candidate
+    list) - every temporal unit and every reconstructed frame bit-exact against the oracle."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=500 + w, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, cdf_update=cdf, keyint=keyint, me_range=me)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, disable_cdf_update=0 if cdf else 1, me_range=me)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert list(sizes) == [len(t) for t in tus]
+    off = 0
+    for i, tu in enumerate(tus):
+        assert data[off:off + sizes[i]] == tu, "frame %d" % i
+        off += sizes[i]
+    fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+    rb = recon.tobytes()
+    for i, rec in enumerate(recs):
+        assert rb[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
+
+
+def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_sequences):
+    """The dav1d-pinned inter sequences the GPU path can express (decision-driven, one-superblock tiles)."""
+    n = 0
+    for m in golden_sequences:
+        cfgk = dict(m["config"])
+        bs = cfgk.get("min_bs_log2", 4)
+        if any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("film_grain") or bs > 5:
+            continue
+        p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, keyint=240, me_range=cfgk.get("me_range", 8),
+                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1)
+        frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
+        data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, m["bit_depth"]) for f in frames), m["frames"], want_recon=True)
+        assert data == m["obu"], m["name"]
+        fb = m["width"] * m["height"] * 3 // 2 * (2 if m["bit_depth"] > 8 else 1)
+        for t in range(m["frames"]):
+            assert sha(split_planes(recon.tobytes()[t * fb:(t + 1) * fb], m["width"], m["height"], m["bit_depth"])) == m["dav1d_sha256"][t], (m["name"], t)
+        n += 1
+    assert n >= 4
