@@ -81,8 +81,12 @@ struct Av1miCdfLayout {
     EOB_EXTRA = EOB1024 + 4 * 12,          // [5][2][9][3]
     DC_SIGN = EOB_EXTRA + 90 * 3,          // [2][3][3]
     COEFF_BASE_EOB = DC_SIGN + 6 * 3,      // [5][2][4][4]
+    COEFF_BASE = COEFF_BASE_EOB + 40 * 4,  // [5][2][42][5]
+    COEFF_BR = COEFF_BASE + 420 * 5,       // [5][2][21][5]
+    INTRA_TOTAL = COEFF_BR + 210 * 5,      // everything a key frame needs
     // inter frames
-    IF_Y_MODE = COEFF_BASE_EOB + 40 * 4,   // [4][14]
+    INTER_BASE = INTRA_TOTAL,
+    IF_Y_MODE = INTER_BASE,                // [4][14]
     IS_INTER = IF_Y_MODE + 4 * 14,         // [4][3]
     NEWMV = IS_INTER + 4 * 3,              // [6][3]
     GLOBALMV = NEWMV + 6 * 3,              // [2][3]
@@ -96,9 +100,7 @@ struct Av1miCdfLayout {
     MV_COMP = MV_JOINT + 5,                // [2] x { class[12], class0_fp[2][5], fp[5], sign[3], class0_hp[3], hp[3], class0[3], bits[10][3] }
     MVC_CLASS = 0, MVC_CLASS0_FP = 12, MVC_FP = 22, MVC_SIGN = 27, MVC_CLASS0_HP = 30, MVC_HP = 33, MVC_CLASS0 = 36, MVC_BITS = 39,
     MVC_SIZE = 69,
-    COEFF_BASE = MV_COMP + 2 * MVC_SIZE,   // [5][2][42][5]
-    COEFF_BR = COEFF_BASE + 420 * 5,       // [5][2][21][5]
-    TOTAL = COEFF_BR + 210 * 5
+    TOTAL = MV_COMP + 2 * MVC_SIZE
   };
 };
 

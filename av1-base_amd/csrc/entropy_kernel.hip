@@ -38,17 +38,20 @@ typedef Av1miCdfLayout CL;
 
 // The coefficient (narrow) rows are 57 % of the CDF set; a regular tile in adaptive mode never
 // touches them here (they adapt per lane in K4), so only the FULL kernel variant holds them in LDS.
-__shared__ uint16_t g_cdf_narrow[CL::TOTAL - CL::COEFF_BASE + 64];
+__shared__ uint16_t g_cdf_narrow[CL::INTRA_TOTAL - CL::COEFF_BASE + 64];
+// inter-frame CDFs and the motion vector candidate list: only the INTER instantiations reference (and allocate) them
+__shared__ uint16_t g_cdf_inter[CL::TOTAL - CL::INTER_BASE + 64];
+struct InterLds {
+  int stk_row[10], stk_col[10], stk_w[10];  // candidate list of the current block (spec §7.10.2)
+  uint8_t newmv[64];                         // per 8x8 unit: its block was coded as NEWMV
+};
+__shared__ InterLds g_inter;
 struct SymLds {
   uint16_t cdf[CL::COEFF_BASE + 64];   // wide rows; +64: whole-row reads by 17 lanes may run past the last row
   int16_t lv[32 * 32];
   uint16_t scan[1024 + 256 + 64 + 16];  // scan index -> position, for n = 32, 16, 8, 4
   Av1miBlkInfo info[64];
   uint8_t above_lvl[3][16], above_dc[3][16], left_lvl[3][16], left_dc[3][16];
-  // inter frames: motion vector candidate list of the current block (spec §7.10.2) and, per 8x8 unit, whether
-  // its block was coded as NEWMV
-  int stk_row[10], stk_col[10], stk_w[10];
-  uint8_t newmv[64];
 };
 __shared__ SymLds g_sym;
 #define S (&g_sym)
@@ -73,9 +76,10 @@ __device__ __forceinline__ void emit1(Sym &y, int lane, uint32_t ent) {
 
 // Wide-alphabet / rare symbol: adapt the n-symbol row at LDS offset `off` cooperatively (lane j =
 // entry j) and emit the RESOLVED entry.
+template <int ARR = 0>  // 0: S->cdf (key-frame syntax), 1: g_cdf_inter (offsets relative to CL::INTER_BASE)
 __device__ __forceinline__ void sym_wide(Sym &y, int lane, int adapt, int s, int off, int n) {
-  s = uni(s); off = uni(off); n = uni(n);
-  const int v = S->cdf[off + (lane < 17 ? lane : 16)];
+  s = uni(s); off = uni(off) - (ARR ? CL::INTER_BASE : 0); n = uni(n);
+  const int v = ARR ? g_cdf_inter[off + (lane < 17 ? lane : 16)] : S->cdf[off + (lane < 17 ? lane : 16)];
   const uint32_t fl = s > 0 ? (uint32_t)__builtin_amdgcn_readlane(v, s - 1) : 32768u;
   const uint32_t fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
   if (adapt) {
@@ -83,7 +87,7 @@ __device__ __forceinline__ void sym_wide(Sym &y, int lane, int adapt, int s, int
     const int rate = 3 + (cntr > 15) + (cntr > 31) + (n > 3 ? 2 : 1);
     int nv = lane < s ? v + ((32768 - v) >> rate) : v - (v >> rate);
     nv = lane == n ? cntr + (cntr < 32) : nv;
-    if (lane <= n) S->cdf[off + lane] = (uint16_t)nv;
+    if (lane <= n) { if (ARR) g_cdf_inter[off + lane] = (uint16_t)nv; else S->cdf[off + lane] = (uint16_t)nv; }
   }
   emit1(y, lane, ENT_RESOLVED(fl >> 6, fh >> 6, n - 1 - s));
 }
@@ -168,9 +172,9 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
     }
     if (plane == 0 && is_inter) {
       // inter_tx_type: every inter block is DCT_DCT = symbol 7 / 3 / 1 of TX_SET_INTER_1 / _2 / _3 (§5.11.47)
-      if (log2n <= 3) sym_wide(y, lane, adapt, 7, CL::INTER_TX1 + (log2n - 2) * 17, 16);
-      else if (log2n == 4) sym_wide(y, lane, adapt, 3, CL::INTER_TX2, 12);
-      else sym_wide(y, lane, adapt, 1, CL::INTER_TX3 + 3 * 3, 2);
+      if (log2n <= 3) sym_wide<1>(y, lane, adapt, 7, CL::INTER_TX1 + (log2n - 2) * 17, 16);
+      else if (log2n == 4) sym_wide<1>(y, lane, adapt, 3, CL::INTER_TX2, 12);
+      else sym_wide<1>(y, lane, adapt, 1, CL::INTER_TX3 + 3 * 3, 2);
     } else if (plane == 0 && log2n <= 4) {
       const int tt = c_mode_txfm[ymode];
       if (log2n <= 3) sym_wide(y, lane, adapt, c_txsym_set1[tt], CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
@@ -334,13 +338,13 @@ __device__ __forceinline__ void stack_add(MvScan &m, int r4, int c4, int weight)
   const int u = (r4 >> 1) * 8 + (c4 >> 1);
   if (!uni(S->info[u].is_inter)) return;
   const int mr = uni(S->info[u].mv_row), mc = uni(S->info[u].mv_col);  // multiples of 8: lower_mv_precision is a no-op
-  if (uni(S->newmv[u])) m.new_count++;
+  if (uni(g_inter.newmv[u])) m.new_count++;
   m.found = 1;
   int i = 0;
   for (; i < m.num; i++)
-    if (uni(S->stk_row[i]) == mr && uni(S->stk_col[i]) == mc) break;
-  if (i < m.num) S->stk_w[i] = uni(S->stk_w[i]) + weight;
-  else if (m.num < 8) { S->stk_row[m.num] = mr; S->stk_col[m.num] = mc; S->stk_w[m.num] = weight; m.num++; }
+    if (uni(g_inter.stk_row[i]) == mr && uni(g_inter.stk_col[i]) == mc) break;
+  if (i < m.num) g_inter.stk_w[i] = uni(g_inter.stk_w[i]) + weight;
+  else if (m.num < 8) { g_inter.stk_row[m.num] = mr; g_inter.stk_col[m.num] = mc; g_inter.stk_w[m.num] = weight; m.num++; }
 }
 __device__ __forceinline__ int cand_n4(int r4, int c4) { return (1 << uni(S->info[(r4 >> 1) * 8 + (c4 >> 1)].bsl)) >> 2; }
 __device__ __forceinline__ void scan_row(MvScan &m, int r4, int c4, int bw4, int delta_row) {
@@ -379,11 +383,11 @@ __device__ __forceinline__ void sort_stack(int start, int end) {
   while (end > start) {
     int new_end = start;
     for (int i = start + 1; i < end; i++) {
-      const int w0 = uni(S->stk_w[i - 1]), w1 = uni(S->stk_w[i]);
+      const int w0 = uni(g_inter.stk_w[i - 1]), w1 = uni(g_inter.stk_w[i]);
       if (w0 < w1) {
-        const int r0 = uni(S->stk_row[i - 1]), c0 = uni(S->stk_col[i - 1]);
-        S->stk_row[i - 1] = uni(S->stk_row[i]); S->stk_col[i - 1] = uni(S->stk_col[i]); S->stk_w[i - 1] = w1;
-        S->stk_row[i] = r0; S->stk_col[i] = c0; S->stk_w[i] = w0;
+        const int r0 = uni(g_inter.stk_row[i - 1]), c0 = uni(g_inter.stk_col[i - 1]);
+        g_inter.stk_row[i - 1] = uni(g_inter.stk_row[i]); g_inter.stk_col[i - 1] = uni(g_inter.stk_col[i]); g_inter.stk_w[i - 1] = w1;
+        g_inter.stk_row[i] = r0; g_inter.stk_col[i] = c0; g_inter.stk_w[i] = w0;
         new_end = i;
       }
     }
@@ -404,7 +408,7 @@ __device__ __forceinline__ int build_mv_stack(const Av1miDevParams &P, const Til
   if (m.found) found_above = 1;
   m.found = 0;
   const int close_matches = found_above + found_left, num_nearest = m.num, num_new = m.new_count;
-  for (int i = 0; i < num_nearest; i++) S->stk_w[i] = uni(S->stk_w[i]) + 640;  // REF_CAT_LEVEL
+  for (int i = 0; i < num_nearest; i++) g_inter.stk_w[i] = uni(g_inter.stk_w[i]) + 640;  // REF_CAT_LEVEL
   scan_point(m, r4, c4, -1, -1);
   if (m.found) found_above = 1;
   m.found = 0;
@@ -424,7 +428,7 @@ __device__ __forceinline__ int build_mv_stack(const Av1miDevParams &P, const Til
   sort_stack(num_nearest, m.num);
   // extra search (§7.10.2.12): with one reference in use it only meets vectors already in the list; pad with the
   // (zero) global vector
-  for (int i = m.num; i < 2; i++) { S->stk_row[i] = 0; S->stk_col[i] = 0; S->stk_w[i] = 0; }
+  for (int i = m.num; i < 2; i++) { g_inter.stk_row[i] = 0; g_inter.stk_col[i] = 0; g_inter.stk_w[i] = 0; }
   if (close_matches == 0) { new_ctx = imin(total_matches, 1); ref_ctx = total_matches; }
   else if (close_matches == 1) { new_ctx = 3 - imin(num_new, 1); ref_ctx = 2 + total_matches; }
   else { new_ctx = 5 - imin(num_new, 1); ref_ctx = 5; }
@@ -434,7 +438,7 @@ __device__ __forceinline__ int build_mv_stack(const Av1miDevParams &P, const Til
   return m.num;
 }
 __device__ __forceinline__ int drl_ctx(int idx) {
-  const int w0 = uni(S->stk_w[idx]), w1 = uni(S->stk_w[idx + 1]);
+  const int w0 = uni(g_inter.stk_w[idx]), w1 = uni(g_inter.stk_w[idx + 1]);
   if (w0 >= 640 && w1 >= 640) return 0;
   if (w0 >= 640 && w1 < 640) return 1;
   if (w0 < 640 && w1 < 640) return 2;
@@ -448,14 +452,14 @@ __device__ __forceinline__ void sym_mv_component(Sym &y, int lane, int adapt, in
   while (cls < 10 && z >= (2 << (cls + 3))) cls++;
   const int o = z - (cls ? (2 << (cls + 2)) : 0);
   const int d = o >> 3, fr = (o >> 1) & 3;
-  sym_wide(y, lane, adapt, v < 0, base + CL::MVC_SIGN, 2);
-  sym_wide(y, lane, adapt, cls, base + CL::MVC_CLASS, 11);
+  sym_wide<1>(y, lane, adapt, v < 0, base + CL::MVC_SIGN, 2);
+  sym_wide<1>(y, lane, adapt, cls, base + CL::MVC_CLASS, 11);
   if (cls == 0) {
-    sym_wide(y, lane, adapt, d, base + CL::MVC_CLASS0, 2);
-    sym_wide(y, lane, adapt, fr, base + CL::MVC_CLASS0_FP + d * 5, 4);
+    sym_wide<1>(y, lane, adapt, d, base + CL::MVC_CLASS0, 2);
+    sym_wide<1>(y, lane, adapt, fr, base + CL::MVC_CLASS0_FP + d * 5, 4);
   } else {
-    for (int i = 0; i < cls; i++) sym_wide(y, lane, adapt, (d >> i) & 1, base + CL::MVC_BITS + i * 3, 2);
-    sym_wide(y, lane, adapt, fr, base + CL::MVC_FP, 4);
+    for (int i = 0; i < cls; i++) sym_wide<1>(y, lane, adapt, (d >> i) & 1, base + CL::MVC_BITS + i * 3, 2);
+    sym_wide<1>(y, lane, adapt, fr, base + CL::MVC_FP, 4);
   }
 }
 
@@ -476,7 +480,7 @@ __device__ __forceinline__ bool node_split(const Av1miDevParams &P, int sb_x, in
 // FULL = false: regular tiles (superblock entirely inside the frame) in adaptive mode - exactly two
 // (tx size, plane type) classes, no narrow rows in LDS (10.4 KB -> ~4 waves per SIMD).
 // FULL = true: frame-edge tiles and static-CDF mode.  Each variant skips the other's tiles.
-template <bool FULL>
+template <bool FULL, bool INTER>
 __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, const uint16_t *__restrict__ cdf_init,
                                                            const int16_t *__restrict__ levels, const Av1miBlkInfo *__restrict__ blk,
                                                            uint32_t *__restrict__ streams, uint32_t *__restrict__ stream_len,
@@ -492,8 +496,12 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   for (int i = lane; i < CL::COEFF_BASE; i += 64) S->cdf[i] = cdf_init[i];
   S->cdf[CL::COEFF_BASE + lane] = 0;
   if (FULL) {
-    for (int i = lane; i < CL::TOTAL - CL::COEFF_BASE; i += 64) g_cdf_narrow[i] = cdf_init[CL::COEFF_BASE + i];
-    g_cdf_narrow[CL::TOTAL - CL::COEFF_BASE + lane] = 0;
+    for (int i = lane; i < CL::INTRA_TOTAL - CL::COEFF_BASE; i += 64) g_cdf_narrow[i] = cdf_init[CL::COEFF_BASE + i];
+    g_cdf_narrow[CL::INTRA_TOTAL - CL::COEFF_BASE + lane] = 0;
+  }
+  if (INTER) {
+    for (int i = lane; i < CL::TOTAL - CL::INTER_BASE; i += 64) g_cdf_inter[i] = cdf_init[CL::INTER_BASE + i];
+    g_cdf_inter[CL::TOTAL - CL::INTER_BASE + lane] = 0;
   }
   for (int l2 = 5; l2 >= 2; l2--) {
     const int n = 1 << l2;
@@ -506,7 +514,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     Av1miBlkInfo bi = {};
     if (sbr * 8 + r < P.b8_rows && sbc * 8 + c < P.b8_cols) bi = info[r * P.b8_cols + c];
     S->info[lane] = bi;
-    S->newmv[lane] = 0;
+    if (INTER) g_inter.newmv[lane] = 0;
     if (lane < 48) { (&S->above_lvl[0][0])[lane] = 0; (&S->above_dc[0][0])[lane] = 0; (&S->left_lvl[0][0])[lane] = 0; (&S->left_dc[0][0])[lane] = 0; }
   }
   __syncthreads();
@@ -515,7 +523,10 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   y.pos = 0; y.cap = P.stream_cap;
   y.combo0 = -1; y.combo1 = -1;
   const int adapt = !P.disable_cdf_update;
-  const int inter_frame = av1mi_frame_is_inter(P, f);
+  // INTER = false: key frames only (no inter syntax compiled in); INTER = true: the chunk's inter frames.  Each
+  // instantiation skips the other's frames.
+  const int inter_frame = INTER;
+  if (av1mi_frame_is_inter(P, f) != (int)INTER) return;
   TileGeo tg;
   tg.sb_x = sbc * 64; tg.sb_y = sbr * 64;
   tg.max_x4_y = P.mi_cols - sbc * 16; tg.max_y4_y = P.mi_rows - sbr * 16;
@@ -574,46 +585,46 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
           if (avail_u && avail_l) ictx = (l_intra && a_intra) ? 3 : ((l_intra || a_intra) ? 1 : 0);
           else if (avail_u || avail_l) ictx = 2 * (avail_u ? a_intra : l_intra);
           else ictx = 0;
-          sym_wide(y, lane, adapt, is_inter, CL::IS_INTER + ictx * 3, 2);
+          sym_wide<1>(y, lane, adapt, is_inter, CL::IS_INTER + ictx * 3, 2);
         }
         if (is_inter) {
           // inter_block_mode_info (§5.11.23): LAST_FRAME = single_ref_p1 0, p3 0, p4 0; then the cheapest name of
           // the vector the recon kernel used: NEARESTMV, NEARMV, GLOBALMV, else NEWMV against the list's head
           const int n_last = (avail_u ? uni(S->info[(b8y - 1) * 8 + b8x].is_inter) : 0) + (avail_l ? uni(S->info[b8y * 8 + b8x - 1].is_inter) : 0);
           const int rctx = n_last > 0 ? 2 : 1;
-          sym_wide(y, lane, adapt, 0, CL::SINGLE_REF + (0 * 3 + rctx) * 3, 2);
-          sym_wide(y, lane, adapt, 0, CL::SINGLE_REF + (2 * 3 + rctx) * 3, 2);
-          sym_wide(y, lane, adapt, 0, CL::SINGLE_REF + (3 * 3 + rctx) * 3, 2);
+          sym_wide<1>(y, lane, adapt, 0, CL::SINGLE_REF + (0 * 3 + rctx) * 3, 2);
+          sym_wide<1>(y, lane, adapt, 0, CL::SINGLE_REF + (2 * 3 + rctx) * 3, 2);
+          sym_wide<1>(y, lane, adapt, 0, CL::SINGLE_REF + (3 * 3 + rctx) * 3, 2);
           int new_ctx, ref_ctx;
           const int num = build_mv_stack(P, tg, by >> 2, bx >> 2, n >> 2, new_ctx, ref_ctx);
           const int mvr = uni(S->info[b8y * 8 + b8x].mv_row), mvc = uni(S->info[b8y * 8 + b8x].mv_col);
-          const int s0r = uni(S->stk_row[0]), s0c = uni(S->stk_col[0]), s1r = uni(S->stk_row[1]), s1c = uni(S->stk_col[1]);
+          const int s0r = uni(g_inter.stk_row[0]), s0c = uni(g_inter.stk_col[0]), s1r = uni(g_inter.stk_row[1]), s1c = uni(g_inter.stk_col[1]);
           int mode;  // 0 NEARESTMV 1 NEARMV 2 GLOBALMV 3 NEWMV
           if (num >= 1 && mvr == s0r && mvc == s0c) mode = 0;
           else if (num >= 2 && mvr == s1r && mvc == s1c) mode = 1;
           else if ((mvr | mvc) == 0) mode = 2;
           else mode = 3;
-          sym_wide(y, lane, adapt, mode != 3, CL::NEWMV + new_ctx * 3, 2);
+          sym_wide<1>(y, lane, adapt, mode != 3, CL::NEWMV + new_ctx * 3, 2);
           if (mode != 3) {
-            sym_wide(y, lane, adapt, mode != 2, CL::GLOBALMV + 0 * 3, 2);
-            if (mode != 2) sym_wide(y, lane, adapt, mode == 1, CL::REFMV + ref_ctx * 3, 2);
+            sym_wide<1>(y, lane, adapt, mode != 2, CL::GLOBALMV + 0 * 3, 2);
+            if (mode != 2) sym_wide<1>(y, lane, adapt, mode == 1, CL::REFMV + ref_ctx * 3, 2);
           }
-          if (mode == 3) { if (num > 1) sym_wide(y, lane, adapt, 0, CL::DRL + drl_ctx(0) * 3, 2); }
-          else if (mode == 1) { if (num > 2) sym_wide(y, lane, adapt, 0, CL::DRL + drl_ctx(1) * 3, 2); }
+          if (mode == 3) { if (num > 1) sym_wide<1>(y, lane, adapt, 0, CL::DRL + drl_ctx(0) * 3, 2); }
+          else if (mode == 1) { if (num > 2) sym_wide<1>(y, lane, adapt, 0, CL::DRL + drl_ctx(1) * 3, 2); }
           if (mode == 3) {
             const int dr = mvr - s0r, dc = mvc - s0c;  // list head, or the zero global vector when the list is empty
-            sym_wide(y, lane, adapt, (dr != 0 ? 2 : 0) | (dc != 0 ? 1 : 0), CL::MV_JOINT, 4);
+            sym_wide<1>(y, lane, adapt, (dr != 0 ? 2 : 0) | (dc != 0 ? 1 : 0), CL::MV_JOINT, 4);
             if (dr) sym_mv_component(y, lane, adapt, 0, dr);
             if (dc) sym_mv_component(y, lane, adapt, 1, dc);
           }
           {
             const int n8 = n >> 3;
-            if (lane < n8 * n8) S->newmv[(b8y + lane / n8) * 8 + b8x + lane % n8] = (uint8_t)(mode == 3);
+            if (lane < n8 * n8) g_inter.newmv[(b8y + lane / n8) * 8 + b8x + lane % n8] = (uint8_t)(mode == 3);
           }
         } else {
           if (inter_frame) {
             // intra_block_mode_info (§5.11.22): y_mode by block-size group
-            sym_wide(y, lane, adapt, ymode, CL::IF_Y_MODE + (bsl <= 3 ? 1 : (bsl == 4 ? 2 : 3)) * 14, 13);
+            sym_wide<1>(y, lane, adapt, ymode, CL::IF_Y_MODE + (bsl <= 3 ? 1 : (bsl == 4 ? 2 : 3)) * 14, 13);
           } else {
             const int am = uni(c_intra_mode_ctx[avail_u ? S->info[(b8y - 1) * 8 + b8x].ymode : 0]);
             const int lm = uni(c_intra_mode_ctx[avail_l ? S->info[b8y * 8 + b8x - 1].ymode : 0]);
@@ -842,8 +853,12 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
                                            const Av1miBlkInfo *blk, uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos,
                                            uint8_t *slots, uint32_t *tile_bytes, hipStream_t stream, hipEvent_t mid) {
   const int n_tiles = P->n_frames * P->sb_rows * P->sb_cols;
-  hipLaunchKernelGGL(symbolize_tile_kernel<false>, dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
-  hipLaunchKernelGGL(symbolize_tile_kernel<true>, dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+  hipLaunchKernelGGL((symbolize_tile_kernel<false, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+  hipLaunchKernelGGL((symbolize_tile_kernel<true, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+  if (P->keyint > 1 && P->n_frames > 1) {  // the chunk has inter frames
+    hipLaunchKernelGGL((symbolize_tile_kernel<false, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+    hipLaunchKernelGGL((symbolize_tile_kernel<true, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+  }
   if (mid) (void)hipEventRecord(mid, stream);
   hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
                      tile_combos, slots, tile_bytes);

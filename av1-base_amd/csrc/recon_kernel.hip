@@ -213,7 +213,7 @@ __device__ __forceinline__ int mc_sample(const PIX *plane, int stride, int last_
 // SAD, DESIGN.md §3.3] -> prediction -> forward transform -> dead-zone quantiser -> normative
 // dequantiser + inverse transform -> reconstruction (HBM + line buffers).
 // `mode_io`: in = mode to use (chroma), out = decided mode (luma).  eob_out[g] = eob of group g.
-template <typename PIX, int LOG2N, int NPL>
+template <typename PIX, int LOG2N, int NPL, bool INTER>
 __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
                                                   int &mode_io, InterInfo &ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
   constexpr int N = 1 << LOG2N;
@@ -300,7 +300,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
       // DC is kept unless the best other candidate at least halves its SAD
       if (sad_dc >= 0 && (best_sad == 0x7FFFFFFF || 2 * (long)best_sad >= (long)sad_dc)) { best_mode = DC_PRED; best_sad = sad_dc; }
       // inter frames: motion compensation wins when its luma SAD is not larger
-      if (ii.ref) ii.is_inter = ii.sad_inter <= best_sad;
+      if (INTER) ii.is_inter = ii.sad_inter <= best_sad;
     }
     const int mode = final_trip ? best_mode : m;
     if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
@@ -316,7 +316,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     for (int p = sl; p < N * N; p += G) {
       const int r = p >> LOG2N, c = p & (N - 1);
       int pv;
-      if (final_trip && ii.is_inter) {
+      if (INTER && final_trip && ii.is_inter) {
         const int ss = plane0 > 0;
         const PIX *rp = static_cast<const PIX *>(ii.ref) + poff;
         pv = mc_sample<PIX>(rp, gs, (ss ? P->width >> 1 : P->width) - 1, (ss ? P->height >> 1 : P->height) - 1,
@@ -341,7 +341,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   mode_io = best_mode;
   __syncthreads();
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
-  const int txt = (LOG2N <= 4 && !ii.is_inter) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
+  const int txt = (LOG2N <= 4 && !(INTER && ii.is_inter)) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
   const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
   constexpr int SH0 = 2, SH1 = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : (LOG2N == 4 ? 2 : 4));
   constexpr int RS = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : 2);
@@ -456,7 +456,7 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
   return 0;
 }
 
-template <typename PIX>
+template <typename PIX, bool INTER>
 __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
                                                   Av1miBlkInfo *info, int b8_stride, const PIX *ref_frame,
                                                   const unsigned long long *me_best /* this superblock's first unit */) {
@@ -472,7 +472,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     int mode = 0;
     InterInfo ii;
     ii.ref = ref_frame; ii.is_inter = 0; ii.mv_row = ii.mv_col = 0; ii.sad_inter = 0;
-    if (ref_frame) {
+    if (INTER) {
       // motion search result of this leaf: (cost << 16) | candidate index, cost = SAD + n * (|dx| + |dy|)
       const unsigned long long key = me_best[(by >> 3) * b8_stride + (bx >> 3)];
       const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
@@ -484,14 +484,14 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     int16_t *lv_u = sb_levels + 4096 + (by >> 1) * 32 + (bx >> 1) * (n >> 1), *lv_v = lv_u + 1024;
     // luma (mode decision inside), then U and V together
     switch (bsl) {
-      case 5: tx_item<PIX, 5, 1>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      case 4: tx_item<PIX, 4, 1>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      default: tx_item<PIX, 3, 1>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 5: tx_item<PIX, 5, 1, INTER>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 4: tx_item<PIX, 4, 1, INTER>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      default: tx_item<PIX, 3, 1, INTER>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
     }
     switch (bsl) {
-      case 5: tx_item<PIX, 4, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      case 4: tx_item<PIX, 3, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      default: tx_item<PIX, 2, 2>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 5: tx_item<PIX, 4, 2, INTER>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 4: tx_item<PIX, 3, 2, INTER>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      default: tx_item<PIX, 2, 2, INTER>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
     }
     if (cx.lane == 0) {
       const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
@@ -509,7 +509,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
   }
 }
 
-template <typename PIX>
+template <typename PIX, bool INTER>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_sb_kernel(Av1miDevParams P, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
   Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
   // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
-  encode_superblock<PIX>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
+  encode_superblock<PIX, INTER>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
                          me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
 }
 #undef S
@@ -552,11 +552,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels,
                                          Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, hipStream_t stream) {
   const int grid = P->n_frames * P->sb_rows * P->sb_cols;
-  if (P->bit_depth == 8)
-    hipLaunchKernelGGL(recon_sb_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk,
-                       (const uint8_t *)ref, me_best);
-  else
-    hipLaunchKernelGGL(recon_sb_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk,
-                       (const uint16_t *)ref, me_best);
+  const bool inter = ref != nullptr;
+  if (P->bit_depth == 8) {
+    if (inter) hipLaunchKernelGGL((recon_sb_kernel<uint8_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk, (const uint8_t *)ref, me_best);
+    else hipLaunchKernelGGL((recon_sb_kernel<uint8_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk, (const uint8_t *)ref, me_best);
+  } else {
+    if (inter) hipLaunchKernelGGL((recon_sb_kernel<uint16_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk, (const uint16_t *)ref, me_best);
+    else hipLaunchKernelGGL((recon_sb_kernel<uint16_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk, (const uint16_t *)ref, me_best);
+  }
   return hipGetLastError();
 }
