@@ -4,8 +4,8 @@
 // around the codec: splitting the clip into independent chunks (each starts with a key frame +
 // sequence header; `--workers`/`--temp`, av1an.rs:100-104), running `workers` chunks in flight
 // (here: one context per visible GPU, round-robin) and concatenating chunk streams in order
-// (§8e).  Input is Y4M, output is IVF (container demux/mux via ffmpeg
-// is out of scope).  Output is written to a temporary name and renamed, so the
+// (§8e).  Input is Y4M; output is Matroska (.mkv/.webm, the reference's job output,
+// jobs.rs:187-188), IVF or a bare OBU stream by extension (input demux/decode via ffmpeg is out of scope, §8b).  Output is written to a temporary name and renamed, so the
 // caller's `exists && len > 0` validation (job_executor.rs:296-317) never sees a partial file.
 #include <errno.h>
 #include <stdio.h>
@@ -76,6 +76,134 @@ int y4m_read_frame(Y4m *y, uint8_t *dst) {
 
 void put_le(uint8_t *p, uint64_t v, int n) { for (int i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * i)); }
 
+// ---- output containers --------------------------------------------------------------------
+// The reference's job output is `{temp_output_dir}/{uuid}.mkv` (crates/daemon/src/jobs.rs:187-188), muxed by
+// av1an/mkvmerge.  The container is chosen by the extension of output_path: .mkv/.webm -> Matroska (EBML header,
+// Segment{Info, Tracks{V_AV1 + av1C CodecPrivate}, one Cluster of SimpleBlocks per chunk}), .obu -> bare Section-5
+// OBU stream, anything else -> IVF.  Video only: the Y4M input has no audio to pass through.
+struct Muxer {
+  FILE *fo = nullptr;
+  enum Kind { IVF, MKV, OBU } kind = IVF;
+  uint32_t w = 0, h = 0, fps_n = 30, fps_d = 1;
+  uint64_t frames = 0, bytes = 0;
+  long seg_size_pos = 0, seg_data_pos = 0, dur_pos = 0;
+  std::vector<uint8_t> cluster;     // SimpleBlocks of the open cluster
+  uint64_t cluster_t0 = 0;          // its timestamp, ms
+  bool cluster_open = false;
+
+  static void ebml_id(std::vector<uint8_t> &v, uint32_t id) { for (int sh = 24; sh >= 0; sh -= 8) if (id >> sh) v.push_back((uint8_t)(id >> sh)); }
+  static void ebml_size(std::vector<uint8_t> &v, uint64_t n) {  // 8-byte form: 0x01 + 56 bits
+    v.push_back(0x01);
+    for (int sh = 48; sh >= 0; sh -= 8) v.push_back((uint8_t)(n >> sh));
+  }
+  static void ebml_elem(std::vector<uint8_t> &v, uint32_t id, const std::vector<uint8_t> &payload) { ebml_id(v, id); ebml_size(v, payload.size()); v.insert(v.end(), payload.begin(), payload.end()); }
+  static std::vector<uint8_t> be(uint64_t x, int n) { std::vector<uint8_t> v; for (int i = n - 1; i >= 0; i--) v.push_back((uint8_t)(x >> (8 * i))); return v; }
+  static std::vector<uint8_t> str(const char *s) { return std::vector<uint8_t>(s, s + strlen(s)); }
+  uint64_t ts_ms(uint64_t frame) const { return frame * 1000ull * fps_d / (fps_n ? fps_n : 30); }
+
+  void begin(const char *path, const std::vector<uint8_t> &seq_hdr_obu) {
+    const char *dot = strrchr(path, '.');
+    kind = (dot && (!strcmp(dot, ".mkv") || !strcmp(dot, ".webm"))) ? MKV : ((dot && !strcmp(dot, ".obu")) ? OBU : IVF);
+    if (kind == IVF) {
+      uint8_t ivf[32] = { 'D', 'K', 'I', 'F', 0, 0, 32, 0, 'A', 'V', '0', '1' };
+      put_le(ivf + 12, w, 2); put_le(ivf + 14, h, 2); put_le(ivf + 16, fps_n, 4); put_le(ivf + 20, fps_d, 4);
+      fwrite(ivf, 1, 32, fo);
+      bytes = 32;
+    } else if (kind == MKV) {
+      std::vector<uint8_t> hdr, e;
+      ebml_elem(e, 0x4286, be(1, 1)); ebml_elem(e, 0x42F7, be(1, 1)); ebml_elem(e, 0x42F2, be(4, 1)); ebml_elem(e, 0x42F3, be(8, 1));
+      ebml_elem(e, 0x4282, str(dot && !strcmp(dot, ".webm") ? "webm" : "matroska")); ebml_elem(e, 0x4287, be(4, 1)); ebml_elem(e, 0x4285, be(2, 1));
+      ebml_elem(hdr, 0x1A45DFA3, e);
+      ebml_id(hdr, 0x18538067);  // Segment, size patched at the end
+      fwrite(hdr.data(), 1, hdr.size(), fo);
+      seg_size_pos = ftell(fo);
+      uint8_t unk[8] = { 0x01, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF };
+      fwrite(unk, 1, 8, fo);
+      seg_data_pos = ftell(fo);
+      std::vector<uint8_t> info, ib;
+      ebml_elem(ib, 0x2AD7B1, be(1000000, 4));              // TimestampScale: 1 ms
+      ebml_elem(ib, 0x4D80, str("libav1mi")); ebml_elem(ib, 0x5741, str("libav1mi"));
+      ebml_id(ib, 0x4489); ebml_size(ib, 8);                 // Duration (float64 ms), patched at the end
+      const size_t dur_off = ib.size();
+      for (int i = 0; i < 8; i++) ib.push_back(0);
+      ebml_elem(info, 0x1549A966, ib);
+      const long info_pos = ftell(fo);
+      fwrite(info.data(), 1, info.size(), fo);
+      dur_pos = info_pos + (long)(info.size() - ib.size() + dur_off);
+      // Tracks: one video track, CodecPrivate = AV1CodecConfigurationRecord (marker/version, profile/level, flags) + configOBUs
+      std::vector<uint8_t> tracks, te, vid, priv;
+      priv.push_back(0x81); priv.push_back((uint8_t)((0 << 5) | 31));  // seq_profile 0, seq_level_idx 31 (as in the sequence header)
+      priv.push_back((uint8_t)(((bit_depth > 8) << 6) | (1 << 3) | (1 << 2)));  // high_bitdepth, 4:2:0
+      priv.push_back(0);
+      priv.insert(priv.end(), seq_hdr_obu.begin(), seq_hdr_obu.end());
+      ebml_elem(vid, 0xB0, be(w, 2)); ebml_elem(vid, 0xBA, be(h, 2));
+      ebml_elem(te, 0xD7, be(1, 1)); ebml_elem(te, 0x73C5, be(1, 1)); ebml_elem(te, 0x83, be(1, 1)); ebml_elem(te, 0x9C, be(0, 1));
+      ebml_elem(te, 0x86, str("V_AV1")); ebml_elem(te, 0x63A2, priv);
+      ebml_elem(te, 0x23E383, be(1000000000ull * fps_d / (fps_n ? fps_n : 30), 4));  // DefaultDuration, ns
+      ebml_elem(te, 0xE0, vid);
+      std::vector<uint8_t> tentry;
+      ebml_elem(tentry, 0xAE, te);
+      ebml_elem(tracks, 0x1654AE6B, tentry);
+      fwrite(tracks.data(), 1, tracks.size(), fo);
+      bytes = (uint64_t)ftell(fo);
+    }
+  }
+  void flush_cluster() {
+    if (!cluster_open) return;
+    std::vector<uint8_t> c, body;
+    ebml_elem(body, 0xE7, be(cluster_t0, 4));
+    body.insert(body.end(), cluster.begin(), cluster.end());
+    ebml_elem(c, 0x1F43B675, body);
+    fwrite(c.data(), 1, c.size(), fo);
+    bytes += c.size();
+    cluster.clear();
+    cluster_open = false;
+  }
+  // one temporal unit (TD + [sequence header] + frame); `key`: starts a new cluster in Matroska
+  void write_frame(const uint8_t *tu, uint32_t size, bool key) {
+    if (kind == IVF) {
+      uint8_t fh[12];
+      put_le(fh, size, 4); put_le(fh + 4, frames, 8);
+      fwrite(fh, 1, 12, fo); fwrite(tu, 1, size, fo);
+      bytes += 12 + size;
+    } else if (kind == OBU) {
+      fwrite(tu, 1, size, fo);
+      bytes += size;
+    } else {
+      const uint64_t t = ts_ms(frames);
+      if (key || !cluster_open || t - cluster_t0 > 30000) { flush_cluster(); cluster_open = true; cluster_t0 = t; }
+      // SimpleBlock: track 1, int16 relative timestamp, flags (0x80 = key frame); the temporal delimiter is dropped
+      const uint8_t *p = tu; uint32_t n = size;
+      if (n >= 2 && p[0] == 0x12 && p[1] == 0x00) { p += 2; n -= 2; }
+      ebml_id(cluster, 0xA3); ebml_size(cluster, 4 + (uint64_t)n);
+      cluster.push_back(0x81);
+      const int16_t rel = (int16_t)(t - cluster_t0);
+      cluster.push_back((uint8_t)(rel >> 8)); cluster.push_back((uint8_t)rel);
+      cluster.push_back(key ? 0x80 : 0x00);
+      cluster.insert(cluster.end(), p, p + n);
+    }
+    frames++;
+  }
+  void end() {
+    if (kind == IVF) {
+      if (fseek(fo, 24, SEEK_SET) == 0) { uint8_t cnt[4]; put_le(cnt, frames, 4); fwrite(cnt, 1, 4, fo); }
+    } else if (kind == MKV) {
+      flush_cluster();
+      const long endpos = ftell(fo);
+      std::vector<uint8_t> sz;
+      ebml_size(sz, (uint64_t)(endpos - seg_data_pos));
+      if (fseek(fo, seg_size_pos, SEEK_SET) == 0) fwrite(sz.data(), 1, 8, fo);
+      const double dur = (double)ts_ms(frames);
+      uint64_t bits;
+      memcpy(&bits, &dur, 8);
+      std::vector<uint8_t> d = be(bits, 8);
+      if (fseek(fo, dur_pos, SEEK_SET) == 0) fwrite(d.data(), 1, 8, fo);
+      fseek(fo, endpos, SEEK_SET);
+    }
+  }
+  uint32_t bit_depth = 8;
+};
+
 struct Chunk {
   uint32_t index = 0, n_frames = 0, first_frame = 0;
   std::vector<uint8_t> frames;
@@ -118,9 +246,14 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   std::string tmp = std::string(job->output_path) + ".tmp." + std::to_string((long)getpid());
   FILE *fo = fopen(tmp.c_str(), "wb");
   if (!fo) { int e = -errno; for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return e; }
-  uint8_t ivf[32] = { 'D', 'K', 'I', 'F', 0, 0, 32, 0, 'A', 'V', '0', '1' };
-  put_le(ivf + 12, y.w, 2); put_le(ivf + 14, y.h, 2); put_le(ivf + 16, y.fps_n, 4); put_le(ivf + 20, y.fps_d, 4);
-  fwrite(ivf, 1, 32, fo);
+  Muxer mux;
+  mux.fo = fo; mux.w = y.w; mux.h = y.h; mux.fps_n = y.fps_n; mux.fps_d = y.fps_d; mux.bit_depth = y.bd;
+  {
+    uint8_t sh[64]; size_t shn = sizeof(sh);
+    rc = av1mi_write_headers(&prm, sh, &shn, nullptr, nullptr);
+    if (rc) { fclose(fo); unlink(tmp.c_str()); for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
+    mux.begin(job->output_path, std::vector<uint8_t>(sh, sh + shn));
+  }
 
   std::mutex mu;
   std::condition_variable cv_work, cv_done;
@@ -155,7 +288,8 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
 
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t n_chunks = 0, next_write = 0, frames_done = 0, frames_read = 0;
-  uint64_t bytes_out = 32, pts = 0;
+  uint64_t bytes_out = mux.bytes;
+  const uint32_t keyint = prm.keyint ? prm.keyint : 1;
   av1mi_report tot = {};
   auto drain = [&](bool all) {
     for (;;) {
@@ -171,13 +305,10 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
       if (!ck->rc && !first_err) {
         size_t off = 0;
         for (uint32_t f = 0; f < ck->n_frames; f++) {
-          uint8_t fh[12];
-          put_le(fh, ck->sizes[f], 4); put_le(fh + 4, pts++, 8);
-          fwrite(fh, 1, 12, fo);
-          fwrite(ck->out.data + off, 1, ck->sizes[f], fo);
+          mux.write_frame(ck->out.data + off, ck->sizes[f], f % keyint == 0);
           off += ck->sizes[f];
-          bytes_out += 12 + ck->sizes[f];
         }
+        bytes_out = mux.bytes;
         frames_done += ck->n_frames;
         tot.frames += ck->n_frames; tot.bytes += ck->rep.bytes; tot.n_symbols += ck->rep.n_symbols;
         for (int p = 0; p < 3; p++) tot.sse[p] += ck->rep.sse[p];
@@ -260,7 +391,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   fclose(y.f);
   // patch frame count, finish atomically
   int io_err = 0;
-  if (fseek(fo, 24, SEEK_SET) == 0) { uint8_t cnt[4]; put_le(cnt, frames_done, 4); fwrite(cnt, 1, 4, fo); }
+  mux.end();
   if (fflush(fo) != 0 || ferror(fo)) io_err = -EIO;
   fclose(fo);
   if (!first_err && !io_err && frames_done == 0) first_err = AV1MI_E_FORMAT;

@@ -263,3 +263,87 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
             assert sha(split_planes(recon.tobytes()[t * fb:(t + 1) * fb], m["width"], m["height"], m["bit_depth"])) == m["dav1d_sha256"][t], (m["name"], t)
         n += 1
     assert n >= 4
+
+
+def test_4k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):
+    """BASELINE config 4's frame size (3840x2160, 10-bit: 60 x 34 one-superblock tiles, the bottom row 48 samples
+    tall): one key frame and one P frame, bit-exact against the oracle."""
+    w, h, bd, n = 3840, 2160, 10, 2
+    frames = [oracle.synthclip_frame(w, h, bd, seed=2160, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, keyint=2)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5)
+    tus, recs = oracle_chunk(oracle, cfg, frames, 2)
+    assert data == b"".join(tus)
+    fb = w * h * 3
+    assert recon.tobytes()[fb:2 * fb] == raw_of(recs[1], bd)
+
+
+def _ebml(buf, pos, end):
+    """yield (id, payload_start, payload_end) of the EBML elements in buf[pos:end]"""
+    while pos < end:
+        b = buf[pos]
+        n = 1 + (8 - b.bit_length())
+        eid = int.from_bytes(buf[pos:pos + n], "big")
+        pos += n
+        b = buf[pos]
+        n = 1 + (8 - b.bit_length())
+        size = int.from_bytes(buf[pos:pos + n], "big") & ((1 << (7 * n)) - 1)
+        pos += n
+        yield eid, pos, pos + size
+        pos += size
+
+
+def test_encode_file_matroska_and_obu_outputs(av1mi, oracle, tmp_path):
+    """output_path ending in .mkv (the reference's job output, jobs.rs:187-188): EBML header, Segment with Info,
+    one V_AV1 track whose CodecPrivate is the av1C record + sequence header, one Cluster per key frame with a
+    SimpleBlock per frame (temporal delimiters dropped).  .obu: the bare stream.  Payloads equal the IVF path's."""
+    w, h, n = 136, 72, 7
+    frames = [oracle.synthclip_frame(w, h, 8, seed=78, t=t) for t in range(n)]
+    y4m = tmp_path / "clip.y4m"
+    with open(y4m, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C420jpeg\n" % (w, h))
+        for fr in frames:
+            f.write(b"FRAME\n" + raw_of(fr, 8))
+    outs = {}
+    for ext in ("ivf", "mkv", "obu"):
+        out = tmp_path / ("clip." + ext)
+        rep = av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, tmp_path, av1mi.derive_plan(8), chunk_frames=4, keyint=2))
+        assert rep.frames == n
+        outs[ext] = out.read_bytes()
+    tus, pos = [], 32
+    while pos < len(outs["ivf"]):
+        sz = int.from_bytes(outs["ivf"][pos:pos + 4], "little")
+        tus.append(outs["ivf"][pos + 12:pos + 12 + sz])
+        pos += 12 + sz
+    assert len(tus) == n and outs["obu"] == b"".join(tus)
+    mkv = outs["mkv"]
+    top = list(_ebml(mkv, 0, len(mkv)))
+    assert [e[0] for e in top] == [0x1A45DFA3, 0x18538067] and top[1][2] == len(mkv)
+    hdr = {e[0]: mkv[e[1]:e[2]] for e in _ebml(mkv, top[0][1], top[0][2])}
+    assert hdr[0x4282] == b"matroska"
+    seg = list(_ebml(mkv, top[1][1], top[1][2]))
+    assert [e[0] for e in seg][:2] == [0x1549A966, 0x1654AE6B] and all(e[0] == 0x1F43B675 for e in seg[2:])
+    info = {e[0]: mkv[e[1]:e[2]] for e in _ebml(mkv, seg[0][1], seg[0][2])}
+    import struct
+    assert int.from_bytes(info[0x2AD7B1], "big") == 1000000 and struct.unpack(">d", info[0x4489])[0] == n * 1000 // 25
+    entry = next(_ebml(mkv, seg[1][1], seg[1][2]))
+    te = {e[0]: (e[1], e[2]) for e in _ebml(mkv, entry[1], entry[2])}
+    assert mkv[te[0x86][0]:te[0x86][1]] == b"V_AV1"
+    priv = mkv[te[0x63A2][0]:te[0x63A2][1]]
+    seq_obu = tus[0][2:2 + 2 + tus[0][3]]
+    assert priv[:4] == bytes([0x81, 31, 0x0C, 0]) and priv[4:] == seq_obu
+    vid = {e[0]: int.from_bytes(mkv[e[1]:e[2]], "big") for e in _ebml(mkv, te[0xE0][0], te[0xE0][1])}
+    assert vid == {0xB0: w, 0xBA: h}
+    blocks = []
+    for c in seg[2:]:
+        els = list(_ebml(mkv, c[1], c[2]))
+        t0 = int.from_bytes(mkv[els[0][1]:els[0][2]], "big")
+        assert els[0][0] == 0xE7
+        for e in els[1:]:
+            assert e[0] == 0xA3 and mkv[e[1]] == 0x81
+            blocks.append((t0 + int.from_bytes(mkv[e[1] + 1:e[1] + 3], "big", signed=True), mkv[e[1] + 3], mkv[e[1] + 4:e[2]]))
+    assert [b[0] for b in blocks] == [i * 1000 // 25 for i in range(n)]
+    # chunks of 4 frames, key frame every 2 frames inside a chunk: frames 0, 2, 4, 6 are key frames
+    assert [b[1] for b in blocks] == [0x80, 0, 0x80, 0, 0x80, 0, 0x80]
+    assert [b[2] for b in blocks] == [t[2:] for t in tus]
