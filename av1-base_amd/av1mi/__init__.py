@@ -36,7 +36,7 @@ E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_OOM, E_OVERFLOW, E_FORMAT, E_UNSUPPORTED = 
 
 # every symbol include/av1mi.h declares
 ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", "av1mi_last_error", "av1mi_encode_chunk",
-               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts"]
+               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute"]
 
 
 class Params(C.Structure):
@@ -66,6 +66,20 @@ class SceneState(C.Structure):
     _fields_ = [("frames_since_cut", C.c_uint32), ("hist_n", C.c_uint32), ("hist_q8", C.c_uint32 * 8)]
 
 
+class ExecJob(C.Structure):
+    """include/av1mi.h: av1mi_exec_job"""
+    _fields_ = [("id", C.c_char_p), ("input_path", C.c_char_p), ("output_path", C.c_char_p), ("temp_base_dir", C.c_char_p),
+                ("workers", C.c_uint32), ("params", Params)]
+
+
+class JobMetrics(C.Structure):
+    """include/av1mi.h: av1mi_job_metrics (the reference's JobMetrics fields this path fills, metrics.rs:12-30)"""
+    _fields_ = [("stage", C.c_char * 16), ("progress", C.c_float), ("fps", C.c_float), ("bitrate_kbps", C.c_float), ("psnr", C.c_float),
+                ("crf", C.c_uint32), ("workers", C.c_uint32), ("frames_encoded", C.c_uint64), ("total_frames", C.c_uint64),
+                ("size_in_bytes_after", C.c_uint64)]
+
+
+STATE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.POINTER(JobMetrics))
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64)
 
 _lib.av1mi_default_params.argtypes = [C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32]
@@ -79,6 +93,7 @@ _lib.av1mi_free.argtypes = [C.c_void_p]
 _lib.av1mi_scene_cuts.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(SceneState),
                                   C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
 _lib.av1mi_encode_file.argtypes = [C.POINTER(Job), PROGRESS_CB, C.c_void_p, C.POINTER(Report)]
+_lib.av1mi_job_execute.argtypes = [C.POINTER(ExecJob), STATE_CB, C.c_void_p, C.POINTER(JobMetrics), C.c_char_p, C.c_size_t]
 _lib.av1mi_cq_to_qindex.argtypes = [C.c_uint32]
 _lib.av1mi_cq_to_qindex.restype = C.c_uint32
 _lib.av1mi_abi_version.restype = C.c_uint32
@@ -262,3 +277,21 @@ def run_mi355x(params, progress=None):
     rc = _lib.av1mi_encode_file(C.byref(job), cb, None, C.byref(rep))
     _raise_for(rc)
     return rep
+
+
+def job_execute(job_id, input_path, output_path, temp_base_dir, workers=0, cq_level=30, **enc):
+    """The encode segment of JobExecutor::execute (job_executor.rs:266-317, 413-436) around the in-process encoder.
+    Returns (rc, [stage strings seen], JobMetrics, error text)."""
+    j = ExecJob()
+    j.id = os.fspath(job_id).encode()
+    j.input_path = os.fspath(input_path).encode()
+    j.output_path = os.fspath(output_path).encode()
+    j.temp_base_dir = os.fspath(temp_base_dir).encode()
+    j.workers = workers
+    j.params = default_params(8, 8, 8, cq_level=cq_level, **enc)
+    stages = []
+    cb = STATE_CB(lambda u, s, m: stages.append(s.decode()) if not stages or stages[-1] != s.decode() else None)
+    m = JobMetrics()
+    err = C.create_string_buffer(256)
+    rc = _lib.av1mi_job_execute(C.byref(j), cb, None, C.byref(m), err, 256)
+    return rc, stages, m, err.value.decode()

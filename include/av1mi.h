@@ -148,6 +148,35 @@ typedef void (*av1mi_progress_cb)(void *user, uint32_t frames_done, uint32_t fra
 
 int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total);
 
+/* ---- the caller's encode segment ---------------------------------------------------------------
+ * Mirror of the part of JobExecutor::execute that surrounds the encode call (crates/daemon/src/job_executor.rs:
+ * 266-317 and 413-436): state -> "encoding", create `{temp_base_dir}/chunks_{id}`, run the encode, on success state ->
+ * "validating" and require the output to exist and be non-empty, remove the chunks directory on every path, and fill the
+ * JobMetrics fields the reference leaves at zero (metrics.rs:12-30; job_executor.rs:117-137).  Size gate, atomic
+ * replacement and skip markers (job_executor.rs:319-411) stay with the caller: control plane, out of scope.
+ * `state_cb` is called with the reference's stage strings ("encoding", "validating", then "size_gating" when the segment
+ * hands back to the caller, or "failed"); `error` receives the reference's failure text ("Output file not found: ...",
+ * "Output file is empty", "MI355X encoder failed with exit code: N", "IO error: ...").  Returns 0, or the failing code. */
+typedef struct {
+  const char *id;              /* Job.id */
+  const char *input_path, *output_path;
+  const char *temp_base_dir;   /* JobExecutor.temp_base_dir */
+  uint32_t workers;            /* ConcurrencyPlan.av1an_workers */
+  av1mi_params params;
+} av1mi_exec_job;
+
+typedef struct {               /* JobMetrics (metrics.rs:12-30), the fields this path can fill */
+  char stage[16];
+  float progress, fps, bitrate_kbps, psnr;
+  uint32_t crf, workers;
+  uint64_t frames_encoded, total_frames, size_in_bytes_after;
+} av1mi_job_metrics;
+
+typedef void (*av1mi_state_cb)(void *user, const char *stage, const av1mi_job_metrics *m);
+
+int av1mi_job_execute(const av1mi_exec_job *job, av1mi_state_cb state_cb, void *user, av1mi_job_metrics *metrics,
+                      char *error, size_t error_cap);
+
 /* helpers shared with the host mirror / tests */
 uint32_t av1mi_cq_to_qindex(uint32_t cq_level);
 uint32_t av1mi_abi_version(void);

@@ -1,0 +1,58 @@
+// integration/mi355x.rs - the file a maintainer adds as crates/daemon/src/encode/mi355x.rs.
+// SOURCE ONLY: the build image has no cargo/rustc, so this has not been compiled; INTEGRATION.md explains every line.
+//! MI355X in-process encoder: drop-in for `run_av1an` (same params, same error type).
+use super::av1an::{Av1anEncodeParams, EncodeError};
+use std::ffi::CString;
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct Av1miParams {            // include/av1mi.h: av1mi_params
+    pub width: u32, pub height: u32, pub bit_depth: u32,
+    pub cq_level: u32, pub keyint: u32, pub block_log2: u32, pub cdf_update: u32, pub enable_cdef: u32,
+    pub cdef_y_pri: u32, pub cdef_y_sec: u32, pub cdef_uv_pri: u32, pub cdef_uv_sec: u32, pub cdef_damping: u32,
+    pub intra_mode_mask: u32, pub film_grain: u32, pub first_frame: u32, pub me_range: u32,
+    pub reserved: [u32; 4],
+}
+#[repr(C)]
+pub struct Av1miJob {               // include/av1mi.h: av1mi_job  <->  Av1anEncodeParams (av1an.rs:36-45)
+    pub input_path: *const c_char,  // params.input_path
+    pub output_path: *const c_char, // params.output_path
+    pub temp_dir: *const c_char,    // params.temp_chunks_dir (caller-owned, job_executor.rs:275-276)
+    pub workers: u32,               // params.concurrency.av1an_workers (`--workers`, av1an.rs:100-101)
+    pub chunk_frames: u32,
+    pub gpu_mask: i32,
+    pub params: Av1miParams,
+}
+#[repr(C)]
+#[derive(Default)]
+pub struct Av1miReport {            // fills JobMetrics.{fps, frames_encoded, psnr} (metrics.rs:12-30)
+    pub frames: u32, pub bytes: u64, pub sse: [f64; 3], pub psnr: [f64; 3],
+    pub ms_h2d: f32, pub ms_recon: f32, pub ms_cdef: f32, pub ms_entropy: f32, pub ms_pack: f32,
+    pub ms_d2h: f32, pub ms_total: f32, pub ms_symbolize: f32, pub n_symbols: u64,
+    pub max_tile_symbols: u32, pub cap_scale: u32, pub chunks: u32, pub reserved1: u32,
+}
+type ProgressCb = Option<extern "C" fn(user: *mut c_void, done: u32, total: u32, fps: f64, bytes: u64)>;
+
+#[link(name = "av1mi")]
+extern "C" {
+    fn av1mi_default_params(p: *mut Av1miParams, w: u32, h: u32, bit_depth: u32);
+    fn av1mi_encode_file(job: *const Av1miJob, cb: ProgressCb, user: *mut c_void, total: *mut Av1miReport) -> c_int;
+}
+
+/// Same contract as `run_av1an` (av1an.rs:126-139): blocks until `output_path` is complete.
+pub fn run_mi355x(params: &Av1anEncodeParams, cq_level: u32) -> Result<(), EncodeError> {
+    let c = |p: &std::path::Path| CString::new(p.as_os_str().as_encoded_bytes()).map_err(|e| EncodeError::Io(std::io::Error::other(e)));
+    let (i, o, t) = (c(&params.input_path)?, c(&params.output_path)?, c(&params.temp_chunks_dir)?);
+    let mut p = Av1miParams::default();
+    unsafe { av1mi_default_params(&mut p, 8, 8, 8) };   // geometry comes from the Y4M header
+    p.cq_level = cq_level;                               // the reference's "--crf" (av1an.rs:14)
+    let job = Av1miJob { input_path: i.as_ptr(), output_path: o.as_ptr(), temp_dir: t.as_ptr(),
+                         workers: params.concurrency.av1an_workers, chunk_frames: 0 /* scene-cut chunks */, gpu_mask: 0, params: p };
+    let mut rep = Av1miReport::default();
+    match unsafe { av1mi_encode_file(&job, None, std::ptr::null_mut(), &mut rep) } {
+        0 => Ok(()),
+        rc if rc > 0 => Err(EncodeError::Av1anFailed(rc)),                                   // av1an.rs:21
+        rc => Err(EncodeError::Io(std::io::Error::from_raw_os_error(-rc))),                   // av1an.rs:29
+    }
+}

@@ -146,3 +146,18 @@ def test_product_never_references_the_oracle():
                 if re.search(r'#include\s*"[^"]*oracle|import\s+av1o|from\s+av1o|libav1o|oracle/_', txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_job_execute_failure_paths_without_gpu(av1mi, tmp_path):
+    """The caller's encode segment (job_executor.rs:266-317, 413-436): the stage sequence and failure strings of the
+    reference, and its temp-dir lifecycle, on the paths that need no GPU."""
+    # missing input: the encoder reports an I/O error -> state failed, "IO error: ...", chunks dir removed
+    rc, stages, m, err = av1mi.job_execute("j1", tmp_path / "nope.y4m", tmp_path / "o.ivf", tmp_path / "tmp")
+    assert rc == -2 and stages == ["encoding", "failed"] and err.startswith("IO error: ")
+    assert not (tmp_path / "tmp" / "chunks_j1").exists() and not (tmp_path / "o.ivf").exists()
+    # not a Y4M: encoder failure code -> "MI355X encoder failed with exit code: N"
+    bad = tmp_path / "bad.y4m"
+    bad.write_bytes(b"RIFF....")
+    rc, stages, m, err = av1mi.job_execute("j2", bad, tmp_path / "o.ivf", tmp_path / "tmp")
+    assert rc == av1mi.E_FORMAT and stages == ["encoding", "failed"] and err == "MI355X encoder failed with exit code: %d" % av1mi.E_FORMAT
+    assert m.stage == b"failed" and not (tmp_path / "tmp" / "chunks_j2").exists()

@@ -347,3 +347,20 @@ def test_encode_file_matroska_and_obu_outputs(av1mi, oracle, tmp_path):
     # chunks of 4 frames, key frame every 2 frames inside a chunk: frames 0, 2, 4, 6 are key frames
     assert [b[1] for b in blocks] == [0x80, 0, 0x80, 0, 0x80, 0, 0x80]
     assert [b[2] for b in blocks] == [t[2:] for t in tus]
+
+
+def test_job_execute_segment_states_and_metrics(av1mi, oracle, tmp_path):
+    """Success path of the caller's encode segment: encoding -> validating -> (hands back at) size_gating, chunks
+    directory created and removed, JobMetrics fields filled from the progress callback."""
+    w, h, n = 136, 72, 9
+    y4m = tmp_path / "clip.y4m"
+    with open(y4m, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h))
+        for t in range(n):
+            f.write(b"FRAME\n" + raw_of(oracle.synthclip_frame(w, h, 8, seed=79, t=t), 8))
+    out = tmp_path / "out.mkv"
+    rc, stages, m, err = av1mi.job_execute("abc", y4m, out, tmp_path / "work", workers=2, keyint=4)
+    assert rc == 0 and err == "" and stages == ["encoding", "validating", "size_gating"]
+    assert m.frames_encoded == n and m.total_frames == n and m.progress == 1.0 and m.fps > 0 and m.bitrate_kbps > 0
+    assert m.size_in_bytes_after == out.stat().st_size > 0 and 25 < m.psnr < 60 and m.crf == 30 and m.workers == 2
+    assert (tmp_path / "work").exists() and not (tmp_path / "work" / "chunks_abc").exists()
