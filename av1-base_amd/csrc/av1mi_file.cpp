@@ -325,15 +325,23 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
     }
   };
   auto enqueue = [&](Chunk *ck) {
-    ck->index = n_chunks;
-    ck->first_frame = (uint32_t)frames_read;
-    frames_read += ck->n_frames;
-    n_chunks++;
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      // bound the number of chunks held in memory
-      cv_done.wait(lk, [&] { return queue.size() + done.size() < (size_t)workers * 2; });
-      queue.push_back(ck);
+    // Bound the chunks held in memory: at most 2 * workers read but not yet written.  Finished chunks are written
+    // by THIS thread, so while waiting it must keep draining - waiting only for "fewer outstanding" would deadlock
+    // once every outstanding chunk is finished and parked in `done`.
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return n_chunks - next_write < workers * 2 || done.count(next_write); });
+        if (n_chunks - next_write < workers * 2) {
+          ck->index = n_chunks;
+          ck->first_frame = (uint32_t)frames_read;
+          frames_read += ck->n_frames;
+          n_chunks++;
+          queue.push_back(ck);
+          break;
+        }
+      }
+      drain(false);
     }
     cv_work.notify_one();
     drain(false);

@@ -316,7 +316,12 @@ def test_encode_file_matroska_and_obu_outputs(av1mi, oracle, tmp_path):
         sz = int.from_bytes(outs["ivf"][pos:pos + 4], "little")
         tus.append(outs["ivf"][pos + 12:pos + 12 + sz])
         pos += 12 + sz
-    assert len(tus) == n and outs["obu"] == b"".join(tus)
+    assert len(tus) == n
+    if outs["obu"] != b"".join(tus):   # diagnostic for a rare flake: which frames differ between two runs of the same encode
+        pos, sizes = 0, []
+        cfg = oracle.default_config(w, h, 8, min_bs_log2=5, max_bs_log2=5)
+        ref_tus = oracle_chunk(oracle, cfg, frames[:4], 2)[0] + oracle_chunk(oracle, cfg, frames[4:], 2)[0]
+        raise AssertionError("ivf run vs oracle: %s; obu bytes %d vs %d" % ([i for i in range(n) if tus[i] != ref_tus[i]], len(outs["obu"]), len(b"".join(tus))))
     mkv = outs["mkv"]
     top = list(_ebml(mkv, 0, len(mkv)))
     assert [e[0] for e in top] == [0x1A45DFA3, 0x18538067] and top[1][2] == len(mkv)
@@ -364,3 +369,21 @@ def test_job_execute_segment_states_and_metrics(av1mi, oracle, tmp_path):
     assert m.frames_encoded == n and m.total_frames == n and m.progress == 1.0 and m.fps > 0 and m.bitrate_kbps > 0
     assert m.size_in_bytes_after == out.stat().st_size > 0 and 25 < m.psnr < 60 and m.crf == 30 and m.workers == 2
     assert (tmp_path / "work").exists() and not (tmp_path / "work" / "chunks_abc").exists()
+
+
+def test_encode_file_many_chunks_few_workers(av1mi, oracle, tmp_path):
+    """More chunks than 2 x workers: the reader must keep writing finished chunks while it waits for room
+    (regression: it used to wait for room only, and deadlocked once every outstanding chunk was finished)."""
+    w, h, n = 72, 56, 12
+    y4m = tmp_path / "clip.y4m"
+    with open(y4m, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h))
+        for t in range(n):
+            f.write(b"FRAME\n" + raw_of(oracle.synthclip_frame(w, h, 8, seed=80, t=t), 8))
+    outs = []
+    for workers in (1, 3):
+        out = tmp_path / ("o%d.obu" % workers)
+        rep = av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, tmp_path, av1mi.derive_plan(8, workers_override=workers), chunk_frames=1))
+        assert rep.frames == n and rep.chunks == n
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1]
