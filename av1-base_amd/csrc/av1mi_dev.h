@@ -38,6 +38,11 @@ struct Av1miDevParams {
   int tile_size_bytes;
   // inter coding: key frame every `keyint` frames of the chunk (1 = all key frames); motion search range
   int keyint, me_range;
+  // loop restoration (luma Wiener, 64x64 units): literal bits that code candidate k's coefficients against the
+  // tile-start reference Wiener_Taps_Mid (both passes), MSB first in the low `lr_code_len[k]` bits
+  int enable_lr;
+  int lr_code_len[3];
+  unsigned long long lr_code_bits[3];
 };
 
 // frame f of a chunk is a key frame iff f % keyint == 0
@@ -81,7 +86,8 @@ struct Av1miCdfLayout {
     EOB_EXTRA = EOB1024 + 4 * 12,          // [5][2][9][3]
     DC_SIGN = EOB_EXTRA + 90 * 3,          // [2][3][3]
     COEFF_BASE_EOB = DC_SIGN + 6 * 3,      // [5][2][4][4]
-    COEFF_BASE = COEFF_BASE_EOB + 40 * 4,  // [5][2][42][5]
+    USE_WIENER = COEFF_BASE_EOB + 40 * 4,  // [3]
+    COEFF_BASE = USE_WIENER + 3,           // [5][2][42][5]
     COEFF_BR = COEFF_BASE + 420 * 5,       // [5][2][21][5]
     INTRA_TOTAL = COEFF_BR + 210 * 5,      // everything a key frame needs
     // inter frames

@@ -30,8 +30,10 @@ hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *re
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *src, const void *ref, unsigned long long *best, int me_range,
                                       hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
+hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
+                                const uint8_t *lr_choice,
                                 hipStream_t s, hipEvent_t mid);
 hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t s);
 hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
@@ -131,7 +133,7 @@ std::vector<uint8_t> make_sequence_header(const Resolved &r) {
   b.put(0, 1);  // seq_force_screen_content_tools
   b.put(0, 1);  // enable_superres
   b.put(p.enable_cdef ? 1 : 0, 1);
-  b.put(0, 1);  // enable_restoration
+  b.put(p.enable_lr ? 1 : 0, 1);  // enable_restoration
   // color_config
   b.put(p.bit_depth > 8, 1);  // high_bitdepth
   b.put(0, 1);                // mono_chrome
@@ -214,6 +216,10 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
     b.put(p.cdef_y_pri, 4); b.put(p.cdef_y_sec, 2);
     b.put(p.cdef_uv_pri, 4); b.put(p.cdef_uv_sec, 2);
   }
+  if (p.enable_lr) {  // lr_params (§5.9.20): luma RESTORE_WIENER (lr_type 2), chroma none, lr_unit_shift 0 = 64x64 units
+    b.put(2, 2); b.put(0, 2); b.put(0, 2);
+    b.put(0, 1);
+  }
   b.put(0, 1);  // tx_mode_select = 0: TX_MODE_LARGEST
   if (inter) b.put(0, 1);  // reference_select = 0
   b.put(0, 1);  // reduced_tx_set
@@ -239,6 +245,41 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
   b.align();
   if (r.sb_cols * r.sb_rows > 1) { b.put(0, 1); b.align(); }  // tile_start_and_end_present_flag
   return b.buf;
+}
+
+// ---- loop restoration unit syntax (§5.11.58): the literal bits that code a Wiener coefficient set against the
+// tile-start reference Wiener_Taps_Mid = {3, -7, 15} (tiles are one superblock = one unit, so that is always the
+// reference).  Mirrors decode_signed_subexp_with_ref_bool / decode_subexp_bool / NS / inverse_recenter.
+struct BitString { unsigned long long bits = 0; int len = 0; void put(unsigned v, int n) { for (int i = n - 1; i >= 0; i--) { bits = (bits << 1) | ((v >> i) & 1); len++; } } };
+void lr_put_ns(BitString &b, int n, int v) {
+  int w = 0, x = n;
+  while (x) { w++; x >>= 1; }
+  const int m = (1 << w) - n;
+  if (v < m) b.put((unsigned)v, w - 1);
+  else { const int extra = v + m; b.put((unsigned)(extra >> 1), w - 1); b.put((unsigned)(extra & 1), 1); }
+}
+void lr_put_subexp(BitString &b, int num_syms, int k, int v) {
+  int i = 0, mk = 0;
+  for (;;) {
+    const int b2 = i ? k + i - 1 : k, a = 1 << b2;
+    if (num_syms <= mk + 3 * a) { lr_put_ns(b, num_syms - mk, v - mk); return; }
+    if (v >= mk + a) { b.put(1, 1); i++; mk += a; }
+    else { b.put(0, 1); b.put((unsigned)(v - mk), b2); return; }
+  }
+}
+int lr_recenter(int r, int v) { return v > 2 * r ? v : (v >= r ? (v - r) << 1 : ((r - v) << 1) - 1); }
+void lr_put_signed_ref(BitString &b, int low, int high, int k, int r, int v) {
+  const int mx = high - low, x = v - low, rr = r - low;
+  if ((rr << 1) <= mx) lr_put_subexp(b, mx, k, lr_recenter(rr, x));
+  else lr_put_subexp(b, mx, k, lr_recenter(mx - 1 - rr, mx - 1 - x));
+}
+const int8_t kWienerCand[3][3] = { { 0, 0, -4 }, { 1, -3, -6 }, { 3, -7, 15 } };  // == lr_kernel.hip, oracle/av1o_lr.c
+BitString lr_code_of(int cand) {
+  static const int tmin[3] = { -5, -23, -17 }, tmax[3] = { 10, 8, 46 }, tk[3] = { 1, 2, 3 }, mid[3] = { 3, -7, 15 };
+  BitString b;
+  for (int pass = 0; pass < 2; pass++)
+    for (int j = 0; j < 3; j++) lr_put_signed_ref(b, tmin[j], tmax[j] + 1, tk[j], mid[j], kWienerCand[cand][j]);
+  return b;
 }
 
 // default CDF blob for one q context in the layout of Av1miCdfLayout (inverted, 0, counter)
@@ -274,6 +315,7 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
   emit_rows(v, CL::EOB_EXTRA, &av1_default_eob_extra_cdf[q][0][0][0], 90, 3, nullptr, 2);
   emit_rows(v, CL::DC_SIGN, &av1_default_dc_sign_cdf[q][0][0], 6, 3, nullptr, 2);
   emit_rows(v, CL::COEFF_BASE_EOB, &av1_default_coeff_base_eob_cdf[q][0][0][0], 40, 4, nullptr, 3);
+  emit_rows(v, CL::USE_WIENER, av1_default_use_wiener_cdf, 1, 3, nullptr, 2);
   // inter frames
   emit_rows(v, CL::IF_Y_MODE, av1_default_if_y_mode_cdf, 4, 14, nullptr, 13);
   emit_rows(v, CL::IS_INTER, av1_default_is_inter_cdf, 4, 3, nullptr, 2);
@@ -326,6 +368,8 @@ struct av1mi_ctx {
   unsigned long long *d_frame_off = nullptr, *d_sse = nullptr;
   int *d_overflow = nullptr;
   unsigned long long *d_me = nullptr;  // motion search results per 8x8 unit per frame
+  void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
+  uint8_t *d_lrc = nullptr;            // per restoration unit: 0 = off, k = candidate k-1
   size_t out_cap = 0;
   // host staging (pinned)
   uint8_t *h_out = nullptr;
@@ -355,11 +399,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -407,6 +451,11 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     c->cap_frames = n_frames;
     c->ws_scale = c->cap_scale;
   }
+  if (p.enable_lr && !c->d_cd) {
+    const size_t nf = c->cap_frames;
+    HIPCHK(c, hipMalloc(&c->d_cd, nf * frame_samples * bps));
+    HIPCHK(c, hipMalloc((void **)&c->d_lrc, nf * nsb + 64));
+  }
   c->res = r;
   Av1miDevParams &P = c->P;
   memset(&P, 0, sizeof(P));
@@ -437,6 +486,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.keyint = (int)p.keyint;
   P.me_range = (int)p.me_range;
   P.hdr_slot_bytes = 512;
+  P.enable_lr = p.enable_lr ? 1 : 0;
+  for (int k = 0; k < 3; k++) { const BitString b = lr_code_of(k); P.lr_code_len[k] = b.len; P.lr_code_bits[k] = b.bits; }
   return AV1MI_OK;
 }
 
@@ -621,8 +672,14 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   const bool inter_chunk = P.keyint > 1 && n_frames > 1;
+  const bool lr = P.enable_lr != 0;
+  void *cdef_out = lr ? c->d_cd : c->d_fin;   // with loop restoration CDEF writes d_cd and the restored frame goes to d_fin
   if (!inter_chunk) {
     HIPCHK(c, av1mi_launch_recon(&P, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
+    if (lr) {  // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
+      HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, s));
+      HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, s));
+    }
   } else {
     // Inter chunk: a P frame needs the previous frame's final (post-CDEF) reconstruction, so motion search,
     // reconstruction and CDEF run frame by frame; entropy coding of ALL frames follows in one pass (every frame
@@ -633,7 +690,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     HIPCHK(c, hipMemsetAsync(c->d_me, 0xFF, (size_t)n_frames * nb8 * 8, s));
     for (uint32_t f = 0; f < n_frames; f++) {
       const uint8_t *srcf = (const uint8_t *)d_src + f * fbytes;
-      uint8_t *recf = (uint8_t *)c->d_rec + f * fbytes, *finf = (uint8_t *)c->d_fin + f * fbytes;
+      uint8_t *recf = (uint8_t *)c->d_rec + f * fbytes, *finf = (uint8_t *)c->d_fin + f * fbytes, *cdf_ = (uint8_t *)cdef_out + f * fbytes;
       Av1miBlkInfo *blkf = c->d_blk + f * nb8;
       int16_t *lvf = c->d_levels + f * nsb * AV1MI_SB_LEVELS;
       if (!av1mi_frame_is_inter(P, (int)f)) {
@@ -644,7 +701,11 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         HIPCHK(c, av1mi_launch_motion_search(&P1, srcf, reff, mef, P.me_range, s));
         HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, reff, mef, s));
       }
-      HIPCHK(c, av1mi_launch_cdef(&P1, recf, finf, blkf, s));
+      HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, s));
+      if (lr) {
+        const int upf = ((P.height + 32) / 64 > 0 ? (P.height + 32) / 64 : 1) * ((P.width + 32) / 64 > 0 ? (P.width + 32) / 64 : 1);
+        HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, s));
+      }
     }
   }
   HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -653,11 +714,11 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   // second stream; symbolize and CDEF are both throughput-bound and would only slow each other.
   hipStream_t s2 = getenv("AV1MI_SERIAL") ? c->stream : c->stream2;  // AV1MI_SERIAL: single-stream timing experiments
   HIPCHK(c, hipEventRecord(c->ev[3], s));
-  HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, s, c->ev[7]));
+  HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc, s, c->ev[7]));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipStreamWaitEvent(s2, c->ev[7], 0));  // ev[7]: recorded between symbolize and range-code
   HIPCHK(c, hipEventRecord(c->ev[8], s2));
-  if (!inter_chunk) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s2));
+  if (!inter_chunk && !lr) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s2));
   HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s2));
   HIPCHK(c, hipEventRecord(c->ev[9], s2));
   HIPCHK(c, hipStreamWaitEvent(s, c->ev[9], 0));  // join: everything below sees the CDEF output too

@@ -484,7 +484,7 @@ template <bool FULL, bool INTER>
 __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, const uint16_t *__restrict__ cdf_init,
                                                            const int16_t *__restrict__ levels, const Av1miBlkInfo *__restrict__ blk,
                                                            uint32_t *__restrict__ streams, uint32_t *__restrict__ stream_len,
-                                                           uint32_t *__restrict__ tile_combos) {
+                                                           uint32_t *__restrict__ tile_combos, const uint8_t *__restrict__ lr_choice) {
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
   const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
@@ -533,6 +533,20 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   tg.max_x4_c = (P.mi_cols >> 1) - sbc * 8; tg.max_y4_c = (P.mi_rows >> 1) - sbr * 8;
   const int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
 
+  if (P.enable_lr) {
+    // read_lr (§5.11.57): the luma restoration unit whose origin lies in this superblock (units = 64x64, offset by 8
+    // rows, so unit (r, c) starts in superblock (r, c)); RefLrWiener is at its tile-start value in every tile
+    const int urows = imax((P.height + 32) / 64, 1), ucols = imax((P.width + 32) / 64, 1);
+    if (sbr < urows && sbc < ucols) {
+      const int ch = uni(lr_choice[(size_t)f * urows * ucols + sbr * ucols + sbc]);
+      sym_wide(y, lane, adapt, ch != 0, CL::USE_WIENER, 2);
+      if (ch) {
+        const int len = P.lr_code_len[ch - 1];
+        const unsigned long long bits = P.lr_code_bits[ch - 1];
+        for (int i = len - 1; i >= 0; i--) emit1(y, lane, ENT_LITERAL((int)((bits >> i) & 1)));
+      }
+    }
+  }
 #pragma nounroll
   for (int z = 0; z < 64; z++) {
     const int bx = (((z >> 0) & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) << 3;
@@ -851,13 +865,13 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
 
 extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels,
                                            const Av1miBlkInfo *blk, uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos,
-                                           uint8_t *slots, uint32_t *tile_bytes, hipStream_t stream, hipEvent_t mid) {
+                                           uint8_t *slots, uint32_t *tile_bytes, const uint8_t *lr_choice, hipStream_t stream, hipEvent_t mid) {
   const int n_tiles = P->n_frames * P->sb_rows * P->sb_cols;
-  hipLaunchKernelGGL((symbolize_tile_kernel<false, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
-  hipLaunchKernelGGL((symbolize_tile_kernel<true, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+  hipLaunchKernelGGL((symbolize_tile_kernel<false, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
+  hipLaunchKernelGGL((symbolize_tile_kernel<true, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
   if (P->keyint > 1 && P->n_frames > 1) {  // the chunk has inter frames
-    hipLaunchKernelGGL((symbolize_tile_kernel<false, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
-    hipLaunchKernelGGL((symbolize_tile_kernel<true, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos);
+    hipLaunchKernelGGL((symbolize_tile_kernel<false, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
+    hipLaunchKernelGGL((symbolize_tile_kernel<true, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
   }
   if (mid) (void)hipEventRecord(mid, stream);
   hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,

@@ -1,0 +1,150 @@
+// lr_kernel.hip - loop restoration: per-unit Wiener decision and filter on luma.
+//
+// Replaces the restoration-filter search and application inside the SVT-AV1 worker behind `run_av1an`
+// (/root/reference/crates/daemon/src/encode/av1an.rs:126-139).  Normative part: AV1 spec §7.17.3 (units offset by 8 luma
+// rows), §7.17.4 (separable 7-tap Wiener filter, Round2 by 3 then 11, intermediate clamp) and §7.17.6 (rows outside the
+// 64-row stripe come from the pre-CDEF frame, at most 2 rows away).  Encoder part: a unit takes the
+// candidate filter with the smallest SSE against the source, or none; restated in oracle/av1o_lr.c.
+//
+// MI355X mapping: one wave per 64x64 unit (lane = column).  Per stripe of the unit the horizontal pass of 70 rows goes to
+// LDS as int16 (the spec's clamp keeps it in 16 bits for 8/10 bit), the vertical pass reads 7 LDS rows per sample.  The
+// three candidates are evaluated for their SSE only; the winner is applied in a last pass that writes the final
+// reconstruction (chroma is copied: FrameRestorationType = NONE).  Algorithmic HBM bytes: CDEF frame read + pre-CDEF rows
+// at stripe edges + source read + final write = ~3*L*b + N*b per frame.
+#include <hip/hip_runtime.h>
+#include "av1mi_dev.h"
+
+namespace {
+
+__constant__ int8_t c_wiener_cand[3][3] = { { 0, 0, -4 }, { 1, -3, -6 }, { 3, -7, 15 } };
+
+__shared__ int16_t g_mid[70][64];
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// horizontal pass of rows [ya - 3, yb + 3) of one stripe for column x into g_mid[row - (ya - 3)][lane]
+template <typename PIX>
+__device__ __forceinline__ void wiener_h(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int x, int ya, int yb, int s0, int s1,
+                                         const int *f, bool active, int lane) {
+  const int W = P.width, H = P.height, bd = P.bit_depth;
+  const int offset = 1 << (bd + 7 - 3 - 1), limit = (1 << (bd + 1 + 7 - 3)) - 1;
+  for (int r = ya - 3; r < yb + 3; r++) {
+    int yy = clampi(r, 0, H - 1);
+    const PIX *fr = cdef;
+    if (yy < s0) { yy = yy > s0 - 2 ? yy : s0 - 2; fr = pre; }
+    else if (yy > s1) { yy = yy < s1 + 2 ? yy : s1 + 2; fr = pre; }
+    int s = 0;
+    if (active) {
+      const PIX *row = fr + (size_t)yy * P.stride_y;
+#pragma unroll
+      for (int t = 0; t < 7; t++) s += f[t] * (int)row[clampi(x + t - 3, 0, W - 1)];
+      s = clampi((s + 4) >> 3, -offset, limit - offset);
+    }
+    g_mid[r - (ya - 3)][lane] = (int16_t)s;
+  }
+}
+__device__ __forceinline__ int wiener_v(int row_in_mid, int lane, const int *f, int maxv) {
+  int s = 0;
+#pragma unroll
+  for (int t = 0; t < 7; t++) s += f[t] * (int)g_mid[row_in_mid + t][lane];
+  return clampi((s + 1024) >> 11, 0, maxv);
+}
+__device__ __forceinline__ void taps_of(int k, int *f) {
+  const int c0 = c_wiener_cand[k][0], c1 = c_wiener_cand[k][1], c2 = c_wiener_cand[k][2];
+  f[0] = f[6] = c0; f[1] = f[5] = c1; f[2] = f[4] = c2; f[3] = 128 - 2 * (c0 + c1 + c2);
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename PIX>
+__global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX *__restrict__ pre, const PIX *__restrict__ cdef,
+                                                    const PIX *__restrict__ src, PIX *__restrict__ out, uint8_t *__restrict__ choice) {
+  const int urows = (P.height + 32) / 64 > 0 ? (P.height + 32) / 64 : 1, ucols = (P.width + 32) / 64 > 0 ? (P.width + 32) / 64 : 1;
+  const int per_frame = urows * ucols;
+  const int f = blockIdx.x / per_frame, u = blockIdx.x % per_frame, ur = u / ucols, uc = u % ucols;
+  const int lane = threadIdx.x;
+  const size_t fo = (size_t)f * P.frame_samples;
+  pre += fo; cdef += fo; src += fo; out += fo;
+  const int y0 = ur ? ur * 64 - 8 : 0, y1 = ur == urows - 1 ? P.height : ur * 64 + 56;
+  const int x0 = uc * 64, x1 = uc == ucols - 1 ? P.width : x0 + 64;
+  const int maxv = (1 << P.bit_depth) - 1;
+  // ---- SSE without restoration and with each candidate
+  unsigned long long sse[4] = { 0, 0, 0, 0 };
+  for (int xs = x0; xs < x1; xs += 64) {
+    const int x = xs + lane;
+    const bool active = x < x1;
+    for (int st = (y0 + 8) / 64; st * 64 - 8 < y1; st++) {
+      const int s0 = st * 64 - 8, s1 = s0 + 63;
+      const int ya = y0 > s0 ? y0 : s0, yb = y1 < s1 + 1 ? y1 : s1 + 1;
+      if (active)
+        for (int y = ya; y < yb; y++) {
+          const int d = (int)cdef[(size_t)y * P.stride_y + x] - (int)src[(size_t)y * P.stride_y + x];
+          sse[0] += (unsigned long long)(d * d);
+        }
+      for (int k = 0; k < 3; k++) {
+        int tf[7];
+        taps_of(k, tf);
+        __syncthreads();
+        wiener_h<PIX>(P, cdef, pre, x, ya, yb, s0, s1, tf, active, lane);
+        __syncthreads();
+        if (active)
+          for (int y = ya; y < yb; y++) {
+            const int d = wiener_v(y - ya, lane, tf, maxv) - (int)src[(size_t)y * P.stride_y + x];
+            sse[k + 1] += (unsigned long long)(d * d);
+          }
+      }
+    }
+  }
+  int best = 0;
+  {
+    unsigned long long bs = wave_sum64(sse[0]);
+    for (int k = 0; k < 3; k++) {
+      const unsigned long long s = wave_sum64(sse[k + 1]);
+      if (s < bs) { bs = s; best = k + 1; }
+    }
+  }
+  if (lane == 0) choice[blockIdx.x] = (uint8_t)best;
+  // ---- apply: luma of the unit, and the co-located chroma (copied)
+  for (int xs = x0; xs < x1; xs += 64) {
+    const int x = xs + lane;
+    const bool active = x < x1;
+    for (int st = (y0 + 8) / 64; st * 64 - 8 < y1; st++) {
+      const int s0 = st * 64 - 8, s1 = s0 + 63;
+      const int ya = y0 > s0 ? y0 : s0, yb = y1 < s1 + 1 ? y1 : s1 + 1;
+      if (best) {
+        int tf[7];
+        taps_of(best - 1, tf);
+        __syncthreads();
+        wiener_h<PIX>(P, cdef, pre, x, ya, yb, s0, s1, tf, active, lane);
+        __syncthreads();
+        if (active)
+          for (int y = ya; y < yb; y++) out[(size_t)y * P.stride_y + x] = (PIX)wiener_v(y - ya, lane, tf, maxv);
+      } else if (active) {
+        for (int y = ya; y < yb; y++) out[(size_t)y * P.stride_y + x] = cdef[(size_t)y * P.stride_y + x];
+      }
+    }
+  }
+  {
+    const int cy0 = y0 >> 1, cy1 = y1 >> 1, cx0 = x0 >> 1, cx1 = x1 >> 1;
+    for (int pl = 0; pl < 2; pl++) {
+      const size_t po = pl ? P.plane_off_v : P.plane_off_u;
+      for (int y = cy0; y < cy1; y++)
+        for (int x = cx0 + lane; x < cx1; x += 64) out[po + (size_t)y * P.stride_c + x] = cdef[po + (size_t)y * P.stride_c + x];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice,
+                                      hipStream_t stream) {
+  const int urows = (P->height + 32) / 64 > 0 ? (P->height + 32) / 64 : 1, ucols = (P->width + 32) / 64 > 0 ? (P->width + 32) / 64 : 1;
+  const int grid = P->n_frames * urows * ucols;
+  if (P->bit_depth == 8)
+    hipLaunchKernelGGL(lr_unit_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice);
+  else
+    hipLaunchKernelGGL(lr_unit_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice);
+  return hipGetLastError();
+}

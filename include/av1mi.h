@@ -56,7 +56,9 @@ typedef struct {
                                synthesis is decoder-side */
   uint32_t first_frame;     /* number of the chunk's first frame inside the clip (seeds grain_seed per frame) */
   uint32_t me_range;        /* inter frames: motion search range in luma samples, 8 or 16 (0 = 8) */
-  uint32_t reserved[4];
+  uint32_t enable_lr;       /* 1 = loop restoration on luma (Wiener, 64x64 units, each unit off or one of 3 filters by SSE);
+                               default 0: the decision needs the CDEF output, which serialises CDEF before entropy coding */
+  uint32_t reserved[3];
 } av1mi_params;
 
 typedef struct {

@@ -54,6 +54,7 @@ typedef struct {
   int film_grain;         /* 1: film_grain_params_present + apply_grain */
   int fg_y_scaling, fg_c_scaling; /* 0..255 scaling value of both points */
   int fg_seed;            /* grain_seed of this frame (16 bits) */
+  int enable_lr;          /* 1: loop restoration on luma: Wiener, 64x64 units, per-unit choice among {off, 3 filters} */
   int me_range;           /* inter frames: integer-pel full search, |dx|,|dy| <= me_range (default 8) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
@@ -114,6 +115,16 @@ void av1o_predict_intra(uint16_t *dst, int stride, int log2n, int mode, int angl
 
 void av1o_cdef_frame(const Av1oConfig *cfg, const Av1oFrame *in, Av1oFrame *out,
                      const uint8_t *skip_mi, int mi_stride, const int8_t *cdef_idx_sb);
+
+/* ---- loop restoration (av1o_lr.c) */
+typedef struct {
+  int8_t type;            /* 0 RESTORE_NONE, 1 RESTORE_WIENER */
+  int8_t coef[2][3];      /* [pass: 0 vertical, 1 horizontal][tap 0..2] */
+} Av1oLrUnit;
+extern const int8_t av1o_wiener_candidates[3][3];
+int av1o_lr_units(int size);
+void av1o_lr_frame(const Av1oConfig *cfg, const Av1oFrame *pre, const Av1oFrame *cdef, const Av1oFrame *src, Av1oFrame *out,
+                   Av1oLrUnit *units, unsigned fuzz);
 
 /* ---- synthclip v1: deterministic integer-only synthetic clip ------------ */
 void av1o_synthclip_frame(Av1oFrame *f, int bit_depth, uint64_t seed, int t, int scene_len);

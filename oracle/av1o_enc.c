@@ -166,7 +166,7 @@ static size_t seq_header_payload(const Av1oConfig *cfg, uint8_t *buf, size_t cap
   }
   bw_put(&b, 0, 1);               /* enable_superres */
   bw_put(&b, cfg->enable_cdef, 1); /* enable_cdef */
-  bw_put(&b, 0, 1);               /* enable_restoration */
+  bw_put(&b, (uint32_t)(cfg->enable_lr != 0), 1); /* enable_restoration */
   write_color_config(&b, cfg);
   bw_put(&b, (uint32_t)(cfg->film_grain != 0), 1); /* film_grain_params_present */
   bw_trailing(&b);
@@ -297,7 +297,12 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, int is_int
     bw_put(&b, (uint32_t)cfg->cdef_uv_pri, 4);
     bw_put(&b, (uint32_t)cfg->cdef_uv_sec, 2);
   }
-  /* lr_params(): enable_restoration = 0 */
+  if (cfg->enable_lr) { /* lr_params() §5.9.20: luma RESTORE_WIENER (lr_type 2), chroma RESTORE_NONE, 64x64 units */
+    bw_put(&b, 2, 2);
+    bw_put(&b, 0, 2);
+    bw_put(&b, 0, 2);
+    bw_put(&b, 0, 1); /* lr_unit_shift = 0: LoopRestorationSize = 256 >> 2 = 64 (no lr_uv_shift: chroma unused) */
+  }
   bw_put(&b, 0, 1); /* tx_mode_select = 0 -> TX_MODE_LARGEST */
   if (is_inter) bw_put(&b, 0, 1); /* reference_select = 0: single reference */
   /* skip_mode_present: not coded (no order hints); allow_warped_motion: not coded (enable_warped_motion = 0) */
@@ -359,6 +364,7 @@ typedef struct {
   uint16_t single_ref[6][3][3]; /* [p1..p6][ctx] */
   uint16_t inter_tx_set1[2][17], inter_tx_set2[13], inter_tx_set3[4][3];
   uint16_t mv_joint[5];
+  uint16_t use_wiener[3];
   struct {
     uint16_t cls[12], class0_fp[2][5], fp[5], sign[3], class0_hp[3], hp[3], class0[3], bits[10][3];
   } mvc[2];
@@ -424,6 +430,7 @@ static void init_cdfs(TileCdfs *c, int qidx) {
   for (i = 0; i < 2; i++) load_cdf(c->inter_tx_set1[i], av1_default_inter_tx_set1_cdf[i], 16);
   load_cdf(c->inter_tx_set2, av1_default_inter_tx_set2_cdf[0], 12);
   load_cdf(c->mv_joint, av1_default_mv_joint_cdf[0], 4);
+  load_cdf(c->use_wiener, av1_default_use_wiener_cdf[0], 2);
   for (i = 0; i < 2; i++) {
     load_cdf(c->mvc[i].cls, av1_default_mv_class_cdf[0], 11);
     for (j = 0; j < 2; j++) load_cdf(c->mvc[i].class0_fp[j], av1_default_mv_class0_fp_cdf[j], 4);
@@ -450,6 +457,9 @@ typedef struct Enc_ {
   uint8_t *mi_is_inter; /* 1: block predicted from LAST_FRAME */
   uint8_t *mi_newmv;    /* 1: coded as NEWMV (counts towards NewMvCount of later blocks) */
   int16_t *mi_mv;       /* [mi][2] = {row, col} in 1/8 luma samples */
+  /* loop restoration: unit decisions of this frame (NULL while they are not known yet: first pass) */
+  const Av1oLrUnit *lr_units;
+  int ref_lr[2][3];     /* RefLrWiener[0][pass][tap], reset per tile */
   int8_t *cdef_idx_sb;
   /* tile state */
   int mi_row_start, mi_row_end, mi_col_start, mi_col_end;
@@ -1273,6 +1283,59 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
   free(ty);
 }
 
+/* ------------------------------------------------------------------ loop restoration syntax §5.11.57/58 */
+static void write_lit_bits(Enc *e, unsigned v, int n) { if (n > 0) av1o_ec_encode_literal(&e->ec, v, n); }
+/* NS(n) with literal bools (§4.10.10 mirrored) */
+static void write_ns_bools(Enc *e, int n, int v) {
+  int w = 0, x = n, m;
+  while (x) { w++; x >>= 1; }
+  m = (1 << w) - n;
+  if (v < m) write_lit_bits(e, (unsigned)v, w - 1);
+  else { int extra = v + m; write_lit_bits(e, (unsigned)(extra >> 1), w - 1); write_lit_bits(e, (unsigned)(extra & 1), 1); }
+}
+/* decode_subexp_bool mirrored: numSyms, k, value v in [0, numSyms) */
+static void write_subexp_bools(Enc *e, int num_syms, int k, int v) {
+  int i = 0, mk = 0;
+  for (;;) {
+    int b2 = i ? k + i - 1 : k, a = 1 << b2;
+    if (num_syms <= mk + 3 * a) { write_ns_bools(e, num_syms - mk, v - mk); return; }
+    if (v >= mk + a) { write_lit_bits(e, 1, 1); i++; mk += a; }   /* subexp_more_bools = 1 */
+    else { write_lit_bits(e, 0, 1); write_lit_bits(e, (unsigned)(v - mk), b2); return; }
+  }
+}
+static int recenter(int r, int v) { /* inverse of inverse_recenter */
+  if (v > 2 * r) return v;
+  if (v >= r) return (v - r) << 1;
+  return ((r - v) << 1) - 1;
+}
+/* decode_signed_subexp_with_ref_bool mirrored: value v in [low, high), reference r */
+static void write_signed_subexp_ref(Enc *e, int low, int high, int k, int r, int v) {
+  const int mx = high - low;
+  int x = v - low, rr = r - low;
+  if ((rr << 1) <= mx) write_subexp_bools(e, mx, k, recenter(rr, x));
+  else write_subexp_bools(e, mx, k, recenter(mx - 1 - rr, mx - 1 - x));
+}
+/* read_lr (§5.11.57) for the 64x64 superblock at (mi_r, mi_c): luma units whose origin lies in it */
+static void write_lr(Enc *e, int mi_r, int mi_c) {
+  static const int tmin[3] = { -5, -23, -17 }, tmax[3] = { 10, 8, 46 }, tk[3] = { 1, 2, 3 };
+  const int urows = av1o_lr_units(e->cfg->height), ucols = av1o_lr_units(e->cfg->width);
+  int r0 = (mi_r * 4 + 63) / 64, r1 = ((mi_r + 16) * 4 + 63) / 64, c0 = (mi_c * 4 + 63) / 64, c1 = ((mi_c + 16) * 4 + 63) / 64, ur, uc, pass, j;
+  if (!e->cfg->enable_lr || !e->lr_units) return;
+  if (r1 > urows) r1 = urows;
+  if (c1 > ucols) c1 = ucols;
+  for (ur = r0; ur < r1; ur++)
+    for (uc = c0; uc < c1; uc++) {
+      const Av1oLrUnit *u = &e->lr_units[ur * ucols + uc];
+      WRITE_SYM(e, u->type, e->cdf.use_wiener, 2);
+      if (!u->type) continue;
+      for (pass = 0; pass < 2; pass++)
+        for (j = 0; j < 3; j++) {
+          write_signed_subexp_ref(e, tmin[j], tmax[j] + 1, tk[j], e->ref_lr[pass][j], u->coef[pass][j]);
+          e->ref_lr[pass][j] = u->coef[pass][j];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ partition §5.11.4 */
 static int icdf_prob(const uint16_t *icdf, int el) { return (el > 0 ? icdf[el - 1] : 32768) - icdf[el]; }
 
@@ -1351,6 +1414,7 @@ static size_t encode_tile(Enc *e, int tr, int tc, uint8_t *out, size_t cap) {
   e->mi_col_start = g->col_start_sb[tc] * 16;
   e->mi_col_end = g->col_start_sb[tc + 1] * 16 < g->mi_cols ? g->col_start_sb[tc + 1] * 16 : g->mi_cols;
   init_cdfs(&e->cdf, e->cfg->base_q_idx);
+  for (p = 0; p < 2; p++) { e->ref_lr[p][0] = 3; e->ref_lr[p][1] = -7; e->ref_lr[p][2] = 15; } /* Wiener_Taps_Mid */
   av1o_ec_init(&e->ec, out, cap);
   for (p = 0; p < 3; p++) {
     memset(e->above_lvl[p], 0, (size_t)g->mi_cols + 16);
@@ -1361,6 +1425,7 @@ static size_t encode_tile(Enc *e, int tr, int tc, uint8_t *out, size_t cap) {
     memset(e->left_dc, 0, sizeof(e->left_dc));
     for (c = e->mi_col_start; c < e->mi_col_end; c += 16) {
       clear_block_decoded(e, r, c);
+      write_lr(e, r, c);
       encode_partition(e, r, c, 6);
     }
   }
@@ -1381,6 +1446,8 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
                         size_t out_cap, Av1oFrame *recon, Av1oStats *stats) {
   Geom g;
   Enc *e;
+  Av1oLrUnit *lr_units = NULL;
+  Av1oFrame *lr_out = NULL;
   size_t pos = 0, payload_cap, hdr_bits, n_mi;
   uint8_t *payload, *tilebuf;
   int tr, tc, p, bd = cfg->bit_depth;
@@ -1428,6 +1495,25 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
     if (k < 0) goto done;
     pos += (size_t)k;
   }
+  /* Loop restoration: the unit decisions are coded at the head of each superblock but depend on the CDEF output of
+   * the whole frame, so the tiles are run once to reconstruct (bits discarded), the units decided, then run again. */
+  if (cfg->enable_lr) {
+    Av1oFrame *cd = av1o_frame_alloc(cfg->width, cfg->height);
+    for (tr = 0; tr < g.tile_rows; tr++)
+      for (tc = 0; tc < g.tile_cols; tc++)
+        if (encode_tile(e, tr, tc, tilebuf, payload_cap) == (size_t)-1) { av1o_frame_free(cd); goto done; }
+    av1o_cdef_frame(cfg, e->rec, cd, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
+    lr_units = (Av1oLrUnit *)calloc((size_t)av1o_lr_units(cfg->width) * av1o_lr_units(cfg->height), sizeof(Av1oLrUnit));
+    lr_out = av1o_frame_alloc(cfg->width, cfg->height);
+    av1o_lr_frame(cfg, e->rec, cd, src, lr_out, lr_units, cfg->fuzz_modes ? (unsigned)cfg->fuzz_modes + 77u : 0u);
+    av1o_frame_free(cd);
+    e->lr_units = lr_units;
+    memset(e->mi_bsl, 0, n_mi); memset(e->mi_skip, 0, n_mi); memset(e->mi_ymode, 0, n_mi);
+    memset(e->mi_is_inter, 0, n_mi); memset(e->mi_newmv, 0, n_mi); memset(e->mi_mv, 0, n_mi * 2 * sizeof(int16_t));
+    memset(e->cdef_idx_sb, -1, (size_t)g.sb_rows * g.sb_cols);
+    e->rng_state = (uint32_t)(cfg->fuzz_coeffs ? cfg->fuzz_coeffs : (cfg->fuzz_modes ? cfg->fuzz_modes : 1)) * 2654435761u + 1u;
+    if (stats) memset(stats, 0, sizeof(*stats));
+  }
   /* OBU_FRAME payload = frame_header_obu + byte_alignment + tile_group_obu */
   {
     size_t pp;
@@ -1462,7 +1548,12 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   /* CDEF -> final reconstruction */
   if (recon || stats) {
     Av1oFrame *fin = recon ? recon : av1o_frame_alloc(cfg->width, cfg->height);
-    av1o_cdef_frame(cfg, e->rec, fin, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
+    if (lr_out) { /* final reconstruction = loop-restored frame (decided in the first pass; the second is identical) */
+      for (p = 0; p < 3; p++) {
+        int pw = p ? cfg->width / 2 : cfg->width, ph = p ? cfg->height / 2 : cfg->height, y;
+        for (y = 0; y < ph; y++) memcpy(fin->p[p] + (size_t)y * fin->stride[p], lr_out->p[p] + (size_t)y * lr_out->stride[p], sizeof(uint16_t) * (size_t)pw);
+      }
+    } else av1o_cdef_frame(cfg, e->rec, fin, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
     if (stats) {
       for (p = 0; p < 3; p++) {
         int pw = p ? cfg->width / 2 : cfg->width, ph = p ? cfg->height / 2 : cfg->height, x, y;
@@ -1484,6 +1575,7 @@ done:
   for (p = 0; p < 3; p++) { free(e->above_lvl[p]); free(e->above_dc[p]); }
   free(e->mi_bsl); free(e->mi_skip); free(e->mi_ymode); free(e->cdef_idx_sb);
   free(e->mi_is_inter); free(e->mi_newmv); free(e->mi_mv);
+  free(lr_units); av1o_frame_free(lr_out);
   av1o_frame_free(e->rec);
   free(e);
   return ret;

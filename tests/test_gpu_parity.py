@@ -51,6 +51,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_cdef=cfgk.get("enable_cdef", 1))
         p.intra_mode_mask = cfgk.get("mode_mask", 0)
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
+        p.enable_lr = cfgk.get("enable_lr", 0)
         for k in ("cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping"):
             if k in cfgk:
                 setattr(p, k, cfgk[k])
@@ -254,7 +255,7 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
         if any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("film_grain") or bs > 5:
             continue
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, keyint=240, me_range=cfgk.get("me_range", 8),
-                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1)
+                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0))
         frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, m["bit_depth"]) for f in frames), m["frames"], want_recon=True)
         assert data == m["obu"], m["name"]
@@ -387,3 +388,20 @@ def test_encode_file_many_chunks_few_workers(av1mi, oracle, tmp_path):
         assert rep.frames == n and rep.chunks == n
         outs.append(out.read_bytes())
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint", [(200, 120, 8, 2, 5, 1), (328, 248, 10, 2, 4, 1), (72, 104, 8, 2, 5, 1), (648, 360, 8, 3, 5, 240),
+                                               (200, 120, 10, 3, 4, 2)])
+def test_loop_restoration_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint):
+    """enable_lr: per-unit Wiener decision + filter on key and inter frames (the restored frame is the
+    next frame's reference); streams and reconstructions bit-exact against the oracle.  72x104: the last unit holds
+    two stripes."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=900 + w, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, enable_lr=1)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, enable_lr=1)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert data == b"".join(tus)
+    fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+    for i, rec in enumerate(recs):
+        assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i

@@ -50,6 +50,11 @@ CASES = [
     # syntax); scaling 40/20 -> dav1d synthesises grain on top (bounded difference, its hash recorded separately)
     ("k200x120_grain_tab0_10b", 200, 120, 10, 1080, 2, dict(film_grain=1, fg_y_scaling=0, fg_c_scaling=0, fg_seed=1234)),
     ("k200x120_grain20_10b", 200, 120, 10, 1080, 2, dict(film_grain=1, fg_y_scaling=40, fg_c_scaling=20, fg_seed=7391)),
+    # loop restoration (luma Wiener, 64x64 units): decision-driven, and fuzzed unit types / coefficients
+    ("k200x120_lr", 200, 120, 8, 1080, 1, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=1)),
+    ("k328x248_lr_10b", 328, 248, 10, 7, 1, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
+    ("fuzz_lr", 200, 120, 8, 31, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1, fuzz_modes=3)),
+    ("fuzz_lr_10b_onetile", 264, 200, 10, 32, 0, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=1, fuzz_modes=5, tile_w_sb=64, tile_h_sb=64)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -73,6 +78,8 @@ SEQ_CASES = [
     ("p328x248_bs5_me16", 328, 248, 8, 7, 3, dict(min_bs_log2=5, max_bs_log2=5, me_range=16)),
     ("p200x120_static_grain", 200, 120, 10, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, disable_cdf_update=1, film_grain=1, fg_y_scaling=0,
                                                         fg_c_scaling=0, fg_seed=99)),
+    ("p200x120_lr", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=1)),
+    ("pfuzz_lr_10b", 200, 120, 10, 26, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1, fuzz_modes=12)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
