@@ -251,17 +251,43 @@ __global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX
 }
 
 // ------------------------------------------------------------------------------ SSE (PSNR)
-template <typename PIX>
+// 16 bytes per lane per load (8 or 16 samples); plane sizes are multiples of 16 samples (width, height multiples of 8),
+// so a vector never straddles two planes.  VEC = false: sample-wise fallback for frame pointers that are not 16-byte aligned.
+template <typename PIX, bool VEC>
 __global__ void __launch_bounds__(256) sse_kernel(Av1miDevParams P, const PIX *__restrict__ a, const PIX *__restrict__ b,
                                                  unsigned long long *__restrict__ sse /* [n_frames][3] */) {
   const int f = blockIdx.y;
   const PIX *pa = a + (size_t)f * P.frame_samples, *pb = b + (size_t)f * P.frame_samples;
   const long ny = (long)P.width * P.height, nc = ny >> 2;
   unsigned long long acc[3] = { 0, 0, 0 };
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P.frame_samples; i += (long)gridDim.x * 256) {
-    const int d = (int)pa[i] - (int)pb[i];
-    const int pl = i < ny ? 0 : (i < ny + nc ? 1 : 2);
-    acc[pl] += (unsigned long long)(d * d);
+  if (VEC) {
+    constexpr int SPV = 16 / (int)sizeof(PIX);  // samples per vector
+    const uint4 *va = reinterpret_cast<const uint4 *>(pa), *vb = reinterpret_cast<const uint4 *>(pb);
+    const long nvec = P.frame_samples / SPV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+      const uint4 x = va[i], y = vb[i];
+      const uint32_t xs[4] = { x.x, x.y, x.z, x.w }, ys[4] = { y.x, y.y, y.z, y.w };
+      unsigned s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (sizeof(PIX) == 2) {
+          const int d0 = (int)(xs[k] & 0xFFFF) - (int)(ys[k] & 0xFFFF), d1 = (int)(xs[k] >> 16) - (int)(ys[k] >> 16);
+          s += (unsigned)(d0 * d0) + (unsigned)(d1 * d1);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) { const int d = (int)((xs[k] >> (8 * q)) & 0xFF) - (int)((ys[k] >> (8 * q)) & 0xFF); s += (unsigned)(d * d); }
+        }
+      }
+      const long i0 = i * SPV;
+      const int pl = i0 < ny ? 0 : (i0 < ny + nc ? 1 : 2);
+      acc[pl] += s;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P.frame_samples; i += (long)gridDim.x * 256) {
+      const int d = (int)pa[i] - (int)pb[i];
+      const int pl = i < ny ? 0 : (i < ny + nc ? 1 : 2);
+      acc[pl] += (unsigned long long)(d * d);
+    }
   }
   for (int pl = 0; pl < 3; pl++) {
     unsigned long long v = acc[pl];
@@ -368,10 +394,14 @@ extern "C" hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec
 
 extern "C" hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t stream) {
   dim3 grid(64, P->n_frames);
-  if (P->bit_depth == 8)
-    hipLaunchKernelGGL(sse_kernel<uint8_t>, grid, dim3(256), 0, stream, *P, (const uint8_t *)a, (const uint8_t *)b, sse);
-  else
-    hipLaunchKernelGGL(sse_kernel<uint16_t>, grid, dim3(256), 0, stream, *P, (const uint16_t *)a, (const uint16_t *)b, sse);
+  const bool vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;  // frame size in bytes is a multiple of 16 (1.5 * w * h, w and h multiples of 8)
+  if (P->bit_depth == 8) {
+    if (vec) hipLaunchKernelGGL((sse_kernel<uint8_t, true>), grid, dim3(256), 0, stream, *P, (const uint8_t *)a, (const uint8_t *)b, sse);
+    else hipLaunchKernelGGL((sse_kernel<uint8_t, false>), grid, dim3(256), 0, stream, *P, (const uint8_t *)a, (const uint8_t *)b, sse);
+  } else {
+    if (vec) hipLaunchKernelGGL((sse_kernel<uint16_t, true>), grid, dim3(256), 0, stream, *P, (const uint16_t *)a, (const uint16_t *)b, sse);
+    else hipLaunchKernelGGL((sse_kernel<uint16_t, false>), grid, dim3(256), 0, stream, *P, (const uint16_t *)a, (const uint16_t *)b, sse);
+  }
   return hipGetLastError();
 }
 
