@@ -431,7 +431,9 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_levels, nf * nsb * AV1MI_SB_LEVELS * sizeof(int16_t)));
     const size_t nb8 = (size_t)(p.width / 8) * (p.height / 8);
     HIPCHK(c, hipMalloc((void **)&c->d_blk, nf * nb8 * sizeof(Av1miBlkInfo)));
-    HIPCHK(c, hipMemset(c->d_blk, 0, nf * nb8 * sizeof(Av1miBlkInfo)));
+    // on the context's own stream: hipMemset would run on the null stream, which a non-blocking stream does not wait
+    // for - the fill could land after the first reconstruction kernel had written its block info
+    HIPCHK(c, hipMemsetAsync(c->d_blk, 0, nf * nb8 * sizeof(Av1miBlkInfo), c->stream));
     HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * nsb * slot));
     c->out_cap = nf * (nsb * (size_t)(slot + 4) + 256);
     HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));
