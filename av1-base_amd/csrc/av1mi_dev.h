@@ -14,7 +14,9 @@
 struct Av1miDevParams {
   int width, height, bit_depth;
   int mi_rows, mi_cols;     // 4x4 units
-  int sb_rows, sb_cols;     // 64x64 superblocks == tiles (tile = 1 SB)
+  int sb_rows, sb_cols;     // 64x64 superblocks
+  int tile_sb;              // tile size in superblocks, both ways: 1, or 2 when the frame has more than 64 superblock rows/columns
+  int tile_rows, tile_cols; // tile grid (the last row/column of tiles may be one superblock short)
   int b8_rows, b8_cols;     // 8x8 units (block-info granularity)
   int n_frames;
   int base_q_idx, qctx;
@@ -39,10 +41,10 @@ struct Av1miDevParams {
   // inter coding: key frame every `keyint` frames of the chunk (1 = all key frames); motion search range
   int keyint, me_range;
   // loop restoration (luma Wiener, 64x64 units): literal bits that code candidate k's coefficients against the
-  // tile-start reference Wiener_Taps_Mid (both passes), MSB first in the low `lr_code_len[k]` bits
+  // reference RefLrWiener (both passes), MSB first in the low `lr_code_len[r][k]` bits
   int enable_lr;
-  int lr_code_len[3];
-  unsigned long long lr_code_bits[3];
+  int lr_code_len[4][3];                 // [reference: 0 = Wiener_Taps_Mid, r = candidate r-1][candidate]
+  unsigned long long lr_code_bits[4][3];
 };
 
 // frame f of a chunk is a key frame iff f % keyint == 0

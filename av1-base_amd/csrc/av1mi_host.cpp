@@ -74,6 +74,7 @@ struct Resolved {
   av1mi_params p;
   int qidx;
   int sb_cols, sb_rows;
+  int tile_sb, tile_cols, tile_rows;  // tiles of tile_sb x tile_sb superblocks (1, or 2 beyond 64 superblocks either way)
 };
 
 // aom's quantizer_to_qindex[] (CQ level -> base_q_idx); 30 -> 120
@@ -98,7 +99,12 @@ int resolve(const av1mi_params *in, Resolved *r) {
   r->qidx = kQuantizerToQindex[p.cq_level];
   r->sb_cols = (p.width + 63) / 64;
   r->sb_rows = (p.height + 63) / 64;
-  if (r->sb_cols > 64 || r->sb_rows > 64) return AV1MI_E_UNSUPPORTED;  // needs tiles larger than one superblock
+  // AV1 allows at most 64 x 64 tiles: frames beyond 64 superblocks either way (8K) use tiles of 2 x 2 superblocks
+  if (p.tile_sb > 2) return AV1MI_E_INVALID_ARG;
+  r->tile_sb = p.tile_sb ? (int)p.tile_sb : ((r->sb_cols > 64 || r->sb_rows > 64) ? 2 : 1);
+  r->tile_cols = (r->sb_cols + r->tile_sb - 1) / r->tile_sb;
+  r->tile_rows = (r->sb_rows + r->tile_sb - 1) / r->tile_sb;
+  if (r->tile_cols > 64 || r->tile_rows > 64) return AV1MI_E_UNSUPPORTED;
   return AV1MI_OK;
 }
 
@@ -174,27 +180,31 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
     b.put(0, 1);  // is_motion_mode_switchable
   }
   if (p.cdf_update) b.put(1, 1);  // disable_frame_end_update_cdf
-  // tile_info: explicit spacing, every tile one superblock
+  // tile_info (§5.9.15): explicit spacing, tiles of tile_sb x tile_sb superblocks (the last row/column may be short)
   {
-    const int sb_cols = r.sb_cols, sb_rows = r.sb_rows;
+    const int sb_cols = r.sb_cols, sb_rows = r.sb_rows, ts = r.tile_sb;
     const int max_tile_width_sb = 4096 >> 6, max_tile_area_sb = (4096 * 2304) >> 12;
     int min_log2_tile_cols = tile_log2(max_tile_width_sb, sb_cols);
     int min_log2_tiles = tile_log2(max_tile_area_sb, sb_rows * sb_cols);
     if (min_log2_tiles < min_log2_tile_cols) min_log2_tiles = min_log2_tile_cols;
     b.put(0, 1);  // uniform_tile_spacing_flag
-    for (int start = 0; start < sb_cols; start++) {
-      int max_w = sb_cols - start < max_tile_width_sb ? sb_cols - start : max_tile_width_sb;
-      b.put_ns(max_w, 0);
+    int widest = 0;
+    for (int start = 0; start < sb_cols; start += ts) {
+      const int max_w = sb_cols - start < max_tile_width_sb ? sb_cols - start : max_tile_width_sb;
+      const int sz = sb_cols - start < ts ? sb_cols - start : ts;
+      b.put_ns(max_w, sz - 1);  // width_in_sbs_minus_1
+      if (sz > widest) widest = sz;
     }
     int area = sb_rows * sb_cols;
     if (min_log2_tiles > 0) area >>= (min_log2_tiles + 1);
-    int max_tile_height_sb = area / 1;
+    int max_tile_height_sb = area / widest;
     if (max_tile_height_sb < 1) max_tile_height_sb = 1;
-    for (int start = 0; start < sb_rows; start++) {
-      int max_h = sb_rows - start < max_tile_height_sb ? sb_rows - start : max_tile_height_sb;
-      b.put_ns(max_h, 0);
+    for (int start = 0; start < sb_rows; start += ts) {
+      const int max_h = sb_rows - start < max_tile_height_sb ? sb_rows - start : max_tile_height_sb;
+      const int sz = sb_rows - start < ts ? sb_rows - start : ts;
+      b.put_ns(max_h, sz - 1);  // height_in_sbs_minus_1
     }
-    const int cl = tile_log2(1, sb_cols), rl = tile_log2(1, sb_rows);
+    const int cl = tile_log2(1, r.tile_cols), rl = tile_log2(1, r.tile_rows);
     if (cl > 0 || rl > 0) {
       b.put(0, cl + rl);  // context_update_tile_id
       b.put(3, 2);        // tile_size_bytes_minus_1
@@ -243,7 +253,7 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
   }
   if (hdr_bits) *hdr_bits = b.bits;
   b.align();
-  if (r.sb_cols * r.sb_rows > 1) { b.put(0, 1); b.align(); }  // tile_start_and_end_present_flag
+  if (r.tile_cols * r.tile_rows > 1) { b.put(0, 1); b.align(); }  // tile_start_and_end_present_flag
   return b.buf;
 }
 
@@ -274,11 +284,12 @@ void lr_put_signed_ref(BitString &b, int low, int high, int k, int r, int v) {
   else lr_put_subexp(b, mx, k, lr_recenter(mx - 1 - rr, mx - 1 - x));
 }
 const int8_t kWienerCand[3][3] = { { 0, 0, -4 }, { 1, -3, -6 }, { 3, -7, 15 } };  // == lr_kernel.hip, oracle/av1o_lr.c
-BitString lr_code_of(int cand) {
+// ref: 0 = Wiener_Taps_Mid (tile start), r = candidate r-1 (the previous unit of the tile that was coded with a filter)
+BitString lr_code_of(int ref, int cand) {
   static const int tmin[3] = { -5, -23, -17 }, tmax[3] = { 10, 8, 46 }, tk[3] = { 1, 2, 3 }, mid[3] = { 3, -7, 15 };
   BitString b;
   for (int pass = 0; pass < 2; pass++)
-    for (int j = 0; j < 3; j++) lr_put_signed_ref(b, tmin[j], tmax[j] + 1, tk[j], mid[j], kWienerCand[cand][j]);
+    for (int j = 0; j < 3; j++) lr_put_signed_ref(b, tmin[j], tmax[j] + 1, tk[j], ref ? kWienerCand[ref - 1][j] : mid[j], kWienerCand[cand][j]);
   return b;
 }
 
@@ -416,12 +427,13 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   const int bps = p.bit_depth > 8 ? 2 : 1;
   const size_t frame_samples = (size_t)p.width * p.height * 3 / 2;
   const size_t nsb = (size_t)r.sb_cols * r.sb_rows;
+  const size_t ntile = (size_t)r.tile_cols * r.tile_rows;
   // Per-tile capacities.  The x1 sizes hold any tile of ordinary content at the supported CQ range; a
   // tile that outgrows them is detected on the device and the chunk is re-run at the next multiplier.
   // x16 is the true worst case of a 64x64 4:2:0 tile (6144 coefficients x <= 37 stream entries:
   // base + 4 range + sign + 31 Golomb bits; <= 10 output bytes per coefficient), so the retry ends.
-  const int slot = (bps == 1 ? 8192 : 16384) * c->cap_scale;
-  const int stream_cap = 16384 * c->cap_scale;
+  const int slot = (bps == 1 ? 8192 : 16384) * c->cap_scale * r.tile_sb * r.tile_sb;
+  const int stream_cap = 16384 * c->cap_scale * r.tile_sb * r.tile_sb;
   if (!same) {
     free_workspace(c);
     const size_t nf = n_frames;
@@ -434,8 +446,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     // on the context's own stream: hipMemset would run on the null stream, which a non-blocking stream does not wait
     // for - the fill could land after the first reconstruction kernel had written its block info
     HIPCHK(c, hipMemsetAsync(c->d_blk, 0, nf * nb8 * sizeof(Av1miBlkInfo), c->stream));
-    HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * nsb * slot));
-    c->out_cap = nf * (nsb * (size_t)(slot + 4) + 256);
+    HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * ntile * slot));
+    c->out_cap = nf * (ntile * (size_t)(slot + 4) + 256);
     HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));
     HIPCHK(c, hipMalloc((void **)&c->d_hdr, 256 + nf * 512));
     HIPCHK(c, hipMalloc((void **)&c->d_cdf, Av1miCdfLayout::TOTAL * sizeof(uint16_t)));
@@ -443,7 +455,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_tile_off, nf * nsb * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_sym, nf * nsb * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_combos, nf * nsb * 4));
-    HIPCHK(c, hipMalloc((void **)&c->d_streams, nf * nsb * (size_t)stream_cap * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_streams, nf * ntile * (size_t)stream_cap * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_frame_size, nf * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_payload, nf * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_frame_off, (nf + 1) * 8));
@@ -464,6 +476,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.width = p.width; P.height = p.height; P.bit_depth = p.bit_depth;
   P.mi_rows = p.height / 4; P.mi_cols = p.width / 4;
   P.sb_rows = r.sb_rows; P.sb_cols = r.sb_cols;
+  P.tile_sb = r.tile_sb; P.tile_rows = r.tile_rows; P.tile_cols = r.tile_cols;
   P.b8_rows = p.height / 8; P.b8_cols = p.width / 8;
   P.n_frames = (int)n_frames;
   P.base_q_idx = r.qidx;
@@ -489,7 +502,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.me_range = (int)p.me_range;
   P.hdr_slot_bytes = 512;
   P.enable_lr = p.enable_lr ? 1 : 0;
-  for (int k = 0; k < 3; k++) { const BitString b = lr_code_of(k); P.lr_code_len[k] = b.len; P.lr_code_bits[k] = b.bits; }
+  for (int rf = 0; rf < 4; rf++)
+    for (int k = 0; k < 3; k++) { const BitString b = lr_code_of(rf, k); P.lr_code_len[rf][k] = b.len; P.lr_code_bits[rf][k] = b.bits; }
   return AV1MI_OK;
 }
 
@@ -758,7 +772,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   std::vector<uint32_t> syms;
   if (e1 == hipSuccess) e1 = hipMemcpyAsync(sse.data(), c->d_sse, (size_t)n_frames * 24, hipMemcpyDeviceToHost, s);
   if (e1 == hipSuccess && report) {
-    syms.resize((size_t)n_frames * P.sb_rows * P.sb_cols);
+    syms.resize((size_t)n_frames * P.tile_rows * P.tile_cols);
     e1 = hipMemcpyAsync(syms.data(), c->d_sym, syms.size() * 4, hipMemcpyDeviceToHost, s);
   }
   if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);

@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256) frame_layout_kernel(Av1miDevParams P, con
                                                           uint32_t *__restrict__ tile_off, uint32_t *__restrict__ frame_size,
                                                           uint32_t *__restrict__ payload_size, int *__restrict__ overflow) {
   __shared__ uint32_t part[256];
-  const int f = blockIdx.x, nt = P.sb_rows * P.sb_cols, t = threadIdx.x;
+  const int f = blockIdx.x, nt = P.tile_rows * P.tile_cols, t = threadIdx.x;
   const uint32_t *tb = tile_bytes + (size_t)f * nt;
   const int per = (nt + 255) / 256;
   uint32_t s = 0;
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
                                                        const uint8_t *__restrict__ hdr_blob, uint8_t *__restrict__ out,
                                                        const int *__restrict__ overflow) {
   if (*overflow) return;  // sizes and offsets are meaningless: nothing may be written
-  const int nt = P.sb_rows * P.sb_cols;
+  const int nt = P.tile_rows * P.tile_cols;
   const int f = blockIdx.x / nt, t = blockIdx.x % nt, lane = threadIdx.x;
   const uint32_t pay = payload_size[f];
   const int ll = leb128_len(pay);
@@ -408,7 +408,7 @@ extern "C" hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, c
 extern "C" hipError_t av1mi_launch_pack(const Av1miDevParams *P, const uint8_t *slots, const uint32_t *tile_bytes, uint32_t *tile_off,
                                         uint32_t *frame_size, uint32_t *payload_size, unsigned long long *frame_off,
                                         const uint8_t *hdr_blob, uint8_t *out, int *overflow, int stage, hipStream_t stream) {
-  const int nt = P->sb_rows * P->sb_cols;
+  const int nt = P->tile_rows * P->tile_cols;
   if (stage == 0) {
     hipLaunchKernelGGL(frame_layout_kernel, dim3(P->n_frames), dim3(256), 0, stream, *P, tile_bytes, tile_off, frame_size, payload_size, overflow);
     hipLaunchKernelGGL(chunk_layout_kernel, dim3(1), dim3(64), 0, stream, P->n_frames, frame_size, frame_off);

@@ -43,18 +43,31 @@ __shared__ uint16_t g_cdf_narrow[CL::INTRA_TOTAL - CL::COEFF_BASE + 64];
 __shared__ uint16_t g_cdf_inter[CL::TOTAL - CL::INTER_BASE + 64];
 struct InterLds {
   int stk_row[10], stk_col[10], stk_w[10];  // candidate list of the current block (spec §7.10.2)
-  uint8_t newmv[64];                         // per 8x8 unit: its block was coded as NEWMV
+  uint8_t newmv[256];                        // per 8x8 unit of the tile: its block was coded as NEWMV
 };
 __shared__ InterLds g_inter;
 struct SymLds {
   uint16_t cdf[CL::COEFF_BASE + 64];   // wide rows; +64: whole-row reads by 17 lanes may run past the last row
   int16_t lv[32 * 32];
   uint16_t scan[1024 + 256 + 64 + 16];  // scan index -> position, for n = 32, 16, 8, 4
-  Av1miBlkInfo info[64];
-  uint8_t above_lvl[3][16], above_dc[3][16], left_lvl[3][16], left_dc[3][16];
+  uint8_t left_lvl[3][16], left_dc[3][16];   // per superblock row of the tile
 };
 __shared__ SymLds g_sym;
 #define S (&g_sym)
+// per-tile state whose size depends on the tile size (TSB x TSB superblocks): block info of the tile's 8x8 units and the
+// above contexts; only the two-superblock instantiations reference (and allocate) the larger object
+template <int TSB>
+struct TileLds {
+  Av1miBlkInfo info[64 * TSB * TSB];
+  uint8_t above_lvl[3][16 * TSB], above_dc[3][16 * TSB];
+};
+__shared__ TileLds<1> g_tile1;
+__shared__ TileLds<2> g_tile2;
+template <int TSB> struct TileSel;
+template <> struct TileSel<1> { static __device__ __forceinline__ TileLds<1> &get() { return g_tile1; } };
+template <> struct TileSel<2> { static __device__ __forceinline__ TileLds<2> &get() { return g_tile2; } };
+#define TI (TileSel<TSB>::get())
+#define TW (8 * TSB)   // tile width in 8x8 units
 
 struct Sym {
   uint32_t *out;     // this tile's stream (global)
@@ -127,6 +140,7 @@ __constant__ uint8_t c_txsym_set1[4] = { 1, 5, 6, 4 };
 __constant__ uint8_t c_txsym_set2[4] = { 1, 3, 4, 2 };
 
 struct TileGeo {
+  int tox, toy;     // origin of the current superblock inside the tile, luma pixels (0 or 64)
   int sb_x, sb_y;   // luma pixel origin
   int max_x4_y, max_y4_y, max_x4_c, max_y4_c;  // frame limits in 4x4 units, superblock-local
 };
@@ -142,15 +156,16 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
 }
 
 // coefficients of one transform block (spec §5.11.39); x4/y4 in plane 4x4 units local to the SB.
-template <bool FULL>
+template <bool FULL, int TSB>
 __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int adapt, const TileGeo &tg, int plane, int log2n, int x4,
                                            int y4, int eob, int ymode, int is_inter, const int16_t *lv_global) {
   const int ptype = plane > 0;
   const int txs = log2n - 2;
   const int n = 1 << log2n, w4 = n >> 2;
   const int max_x4 = plane ? tg.max_x4_c : tg.max_x4_y, max_y4 = plane ? tg.max_y4_c : tg.max_y4_y;
-#define a_lvl S->above_lvl[plane]
-#define a_dc S->above_dc[plane]
+  const int aoff = (plane ? tg.tox >> 3 : tg.tox >> 2);  // above contexts are indexed by tile-local 4x4 column
+#define a_lvl (TI.above_lvl[plane] + aoff)
+#define a_dc (TI.above_dc[plane] + aoff)
 #define l_lvl S->left_lvl[plane]
 #define l_dc S->left_dc[plane]
   int nb_or = 0, dsum = 0;
@@ -333,11 +348,15 @@ struct MvScan {
 __device__ __forceinline__ int morton8(int ux, int uy) {
   return (ux & 1) | ((uy & 1) << 1) | ((ux & 2) << 1) | ((uy & 2) << 2) | ((ux & 4) << 2) | ((uy & 4) << 3);
 }
-__device__ __forceinline__ bool mv_inside(const MvScan &m, int r4, int c4) { return r4 >= 0 && c4 >= 0 && r4 < m.max_r4 && c4 < m.max_c4 && r4 < 16 && c4 < 16; }
+// coding order of a tile-local 8x8 unit: superblocks in raster order, Morton order inside
+template <int TSB>
+__device__ __forceinline__ int unit_order(int ux, int uy) { return (((uy >> 3) * TSB + (ux >> 3)) << 6) | morton8(ux & 7, uy & 7); }
+__device__ __forceinline__ bool mv_inside(const MvScan &m, int r4, int c4) { return r4 >= 0 && c4 >= 0 && r4 < m.max_r4 && c4 < m.max_c4; }
+template <int TSB>
 __device__ __forceinline__ void stack_add(MvScan &m, int r4, int c4, int weight) {
-  const int u = (r4 >> 1) * 8 + (c4 >> 1);
-  if (!uni(S->info[u].is_inter)) return;
-  const int mr = uni(S->info[u].mv_row), mc = uni(S->info[u].mv_col);  // multiples of 8: lower_mv_precision is a no-op
+  const int u = (r4 >> 1) * TW + (c4 >> 1);
+  if (!uni(TI.info[u].is_inter)) return;
+  const int mr = uni(TI.info[u].mv_row), mc = uni(TI.info[u].mv_col);  // multiples of 8: lower_mv_precision is a no-op
   if (uni(g_inter.newmv[u])) m.new_count++;
   m.found = 1;
   int i = 0;
@@ -346,7 +365,9 @@ __device__ __forceinline__ void stack_add(MvScan &m, int r4, int c4, int weight)
   if (i < m.num) g_inter.stk_w[i] = uni(g_inter.stk_w[i]) + weight;
   else if (m.num < 8) { g_inter.stk_row[m.num] = mr; g_inter.stk_col[m.num] = mc; g_inter.stk_w[m.num] = weight; m.num++; }
 }
-__device__ __forceinline__ int cand_n4(int r4, int c4) { return (1 << uni(S->info[(r4 >> 1) * 8 + (c4 >> 1)].bsl)) >> 2; }
+template <int TSB>
+__device__ __forceinline__ int cand_n4(int r4, int c4) { return (1 << uni(TI.info[(r4 >> 1) * TW + (c4 >> 1)].bsl)) >> 2; }
+template <int TSB>
 __device__ __forceinline__ void scan_row(MvScan &m, int r4, int c4, int bw4, int delta_row) {
   int delta_col = 0, i = 0;
   const int end4 = imin(imin(bw4, m.max_c4 - c4), 16);
@@ -354,13 +375,14 @@ __device__ __forceinline__ void scan_row(MvScan &m, int r4, int c4, int bw4, int
   while (i < end4) {
     const int r = r4 + delta_row, c = c4 + delta_col + i;
     if (!mv_inside(m, r, c)) break;
-    int len = imin(cand_n4(r, c), bw4);
+    int len = imin(cand_n4<TSB>(r, c), bw4);
     if (iabs(delta_row) > 1) len = imax(len, 2);
     if (bw4 >= 16) len = imax(len, 4);
-    stack_add(m, r, c, len * 2);
+    stack_add<TSB>(m, r, c, len * 2);
     i += len;
   }
 }
+template <int TSB>
 __device__ __forceinline__ void scan_col(MvScan &m, int r4, int c4, int bh4, int delta_col) {
   int delta_row = 0, i = 0;
   const int end4 = imin(imin(bh4, m.max_r4 - r4), 16);
@@ -368,16 +390,17 @@ __device__ __forceinline__ void scan_col(MvScan &m, int r4, int c4, int bh4, int
   while (i < end4) {
     const int r = r4 + delta_row + i, c = c4 + delta_col;
     if (!mv_inside(m, r, c)) break;
-    int len = imin(cand_n4(r, c), bh4);
+    int len = imin(cand_n4<TSB>(r, c), bh4);
     if (iabs(delta_col) > 1) len = imax(len, 2);
     if (bh4 >= 16) len = imax(len, 4);
-    stack_add(m, r, c, len * 2);
+    stack_add<TSB>(m, r, c, len * 2);
     i += len;
   }
 }
+template <int TSB>
 __device__ __forceinline__ void scan_point(MvScan &m, int r4, int c4, int dr, int dc) {
   const int r = r4 + dr, c = c4 + dc;
-  if (mv_inside(m, r, c) && morton8(c >> 1, r >> 1) < m.cur_z) stack_add(m, r, c, 4);
+  if (mv_inside(m, r, c) && unit_order<TSB>(c >> 1, r >> 1) < m.cur_z) stack_add<TSB>(m, r, c, 4);
 }
 __device__ __forceinline__ void sort_stack(int start, int end) {
   while (end > start) {
@@ -395,33 +418,35 @@ __device__ __forceinline__ void sort_stack(int start, int end) {
   }
 }
 // returns NumMvFound; contexts through the references.  (r4, c4): block origin, n4: block size, all in 4x4 units
+template <int TSB>
 __device__ __forceinline__ int build_mv_stack(const Av1miDevParams &P, const TileGeo &tg, int r4, int c4, int n4, int &new_ctx, int &ref_ctx) {
   MvScan m;
   m.num = 0; m.new_count = 0; m.found = 0;
-  m.max_r4 = tg.max_y4_y; m.max_c4 = tg.max_x4_y;
-  m.cur_z = morton8(c4 >> 1, r4 >> 1);
-  scan_row(m, r4, c4, n4, -1);
+  // limits: the tile (TSB superblocks) clipped to the frame, in tile-local 4x4 units
+  m.max_r4 = imin(16 * TSB, tg.max_y4_y + (tg.toy >> 2)); m.max_c4 = imin(16 * TSB, tg.max_x4_y + (tg.tox >> 2));
+  m.cur_z = unit_order<TSB>(c4 >> 1, r4 >> 1);
+  scan_row<TSB>(m, r4, c4, n4, -1);
   int found_above = m.found; m.found = 0;
-  scan_col(m, r4, c4, n4, -1);
+  scan_col<TSB>(m, r4, c4, n4, -1);
   int found_left = m.found; m.found = 0;
-  if (n4 <= 16) scan_point(m, r4, c4, -1, n4);
+  if (n4 <= 16) scan_point<TSB>(m, r4, c4, -1, n4);
   if (m.found) found_above = 1;
   m.found = 0;
   const int close_matches = found_above + found_left, num_nearest = m.num, num_new = m.new_count;
   for (int i = 0; i < num_nearest; i++) g_inter.stk_w[i] = uni(g_inter.stk_w[i]) + 640;  // REF_CAT_LEVEL
-  scan_point(m, r4, c4, -1, -1);
+  scan_point<TSB>(m, r4, c4, -1, -1);
   if (m.found) found_above = 1;
   m.found = 0;
-  scan_row(m, r4, c4, n4, -3);
+  scan_row<TSB>(m, r4, c4, n4, -3);
   if (m.found) found_above = 1;
   m.found = 0;
-  scan_col(m, r4, c4, n4, -3);
+  scan_col<TSB>(m, r4, c4, n4, -3);
   if (m.found) found_left = 1;
   m.found = 0;
-  scan_row(m, r4, c4, n4, -5);
+  scan_row<TSB>(m, r4, c4, n4, -5);
   if (m.found) found_above = 1;
   m.found = 0;
-  scan_col(m, r4, c4, n4, -5);
+  scan_col<TSB>(m, r4, c4, n4, -5);
   if (m.found) found_left = 1;
   const int total_matches = found_above + found_left;
   sort_stack(0, num_nearest);
@@ -480,17 +505,18 @@ __device__ __forceinline__ bool node_split(const Av1miDevParams &P, int sb_x, in
 // FULL = false: regular tiles (superblock entirely inside the frame) in adaptive mode - exactly two
 // (tx size, plane type) classes, no narrow rows in LDS (10.4 KB -> ~4 waves per SIMD).
 // FULL = true: frame-edge tiles and static-CDF mode.  Each variant skips the other's tiles.
-template <bool FULL, bool INTER>
+template <bool FULL, bool INTER, int TSB>
 __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, const uint16_t *__restrict__ cdf_init,
                                                            const int16_t *__restrict__ levels, const Av1miBlkInfo *__restrict__ blk,
                                                            uint32_t *__restrict__ streams, uint32_t *__restrict__ stream_len,
                                                            uint32_t *__restrict__ tile_combos, const uint8_t *__restrict__ lr_choice) {
-  const int sbs_per_frame = P.sb_rows * P.sb_cols;
-  const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
-  const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
+  // one wave per TILE of TSB x TSB superblocks (raster order inside the tile)
+  const int tiles_per_frame = P.tile_rows * P.tile_cols, sbs_per_frame = P.sb_rows * P.sb_cols;
+  const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
+  const int tr = tile / P.tile_cols, tc = tile % P.tile_cols;
   const int lane = threadIdx.x;
   {
-    const bool regular = !P.disable_cdf_update && (sbc + 1) * 64 <= P.width && (sbr + 1) * 64 <= P.height;
+    const bool regular = !P.disable_cdf_update && (tc + 1) * 64 * TSB <= P.width && (tr + 1) * 64 * TSB <= P.height;
     if (regular == FULL) return;
   }
   for (int i = lane; i < CL::COEFF_BASE; i += 64) S->cdf[i] = cdf_init[i];
@@ -509,13 +535,16 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     for (int p = lane; p < n * n; p += 64) S->scan[to + scan_index(p >> l2, p & (n - 1), n)] = (uint16_t)p;
   }
   {
-    const Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
-    const int r = lane >> 3, c = lane & 7;
-    Av1miBlkInfo bi = {};
-    if (sbr * 8 + r < P.b8_rows && sbc * 8 + c < P.b8_cols) bi = info[r * P.b8_cols + c];
-    S->info[lane] = bi;
-    if (INTER) g_inter.newmv[lane] = 0;
-    if (lane < 48) { (&S->above_lvl[0][0])[lane] = 0; (&S->above_dc[0][0])[lane] = 0; (&S->left_lvl[0][0])[lane] = 0; (&S->left_dc[0][0])[lane] = 0; }
+    // block info of the whole tile (zero outside the frame), above contexts cleared (clear_above_context)
+    const Av1miBlkInfo *finfo = blk + (size_t)f * P.b8_rows * P.b8_cols;
+    for (int u = lane; u < 64 * TSB * TSB; u += 64) {
+      const int r = tr * TW + u / TW, c = tc * TW + u % TW;
+      Av1miBlkInfo bi = {};
+      if (r < P.b8_rows && c < P.b8_cols) bi = finfo[(size_t)r * P.b8_cols + c];
+      TI.info[u] = bi;
+      if (INTER) g_inter.newmv[u] = 0;
+    }
+    for (int i = lane; i < 3 * 16 * TSB; i += 64) { (&TI.above_lvl[0][0])[i] = 0; (&TI.above_dc[0][0])[i] = 0; }
   }
   __syncthreads();
   Sym y;
@@ -527,23 +556,39 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   // instantiation skips the other's frames.
   const int inter_frame = INTER;
   if (av1mi_frame_is_inter(P, f) != (int)INTER) return;
+  int lr_prev = 0;  // RefLrWiener of the tile: 0 = Wiener_Taps_Mid, k = candidate k-1 (the last unit coded with a filter)
+#pragma nounroll
+  for (int si = 0; si < TSB * TSB; si++) {
+  const int sbr = tr * TSB + si / TSB, sbc = tc * TSB + si % TSB;
+  if (sbr >= P.sb_rows || sbc >= P.sb_cols) continue;
+  const int sb = sbr * P.sb_cols + sbc;
   TileGeo tg;
+  tg.tox = (si % TSB) * 64; tg.toy = (si / TSB) * 64;
   tg.sb_x = sbc * 64; tg.sb_y = sbr * 64;
   tg.max_x4_y = P.mi_cols - sbc * 16; tg.max_y4_y = P.mi_rows - sbr * 16;
   tg.max_x4_c = (P.mi_cols >> 1) - sbc * 8; tg.max_y4_c = (P.mi_rows >> 1) - sbr * 8;
+  const int tox = tg.tox, toy = tg.toy, tox8 = tox >> 3, toy8 = toy >> 3;
+#define INFO(ux_, uy_) TI.info[((uy_) + toy8) * TW + (ux_) + tox8]
   const int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
+  if (si % TSB == 0) {  // clear_left_context at the start of every superblock row of the tile
+    __syncthreads();
+    if (lane < 48) { (&S->left_lvl[0][0])[lane] = 0; (&S->left_dc[0][0])[lane] = 0; }
+    __syncthreads();
+  }
 
   if (P.enable_lr) {
     // read_lr (§5.11.57): the luma restoration unit whose origin lies in this superblock (units = 64x64, offset by 8
-    // rows, so unit (r, c) starts in superblock (r, c)); RefLrWiener is at its tile-start value in every tile
+    // rows, so unit (r, c) starts in superblock (r, c)); its coefficients are coded against RefLrWiener, which starts
+    // every tile at Wiener_Taps_Mid and follows the units coded with a filter
     const int urows = imax((P.height + 32) / 64, 1), ucols = imax((P.width + 32) / 64, 1);
     if (sbr < urows && sbc < ucols) {
       const int ch = uni(lr_choice[(size_t)f * urows * ucols + sbr * ucols + sbc]);
       sym_wide(y, lane, adapt, ch != 0, CL::USE_WIENER, 2);
       if (ch) {
-        const int len = P.lr_code_len[ch - 1];
-        const unsigned long long bits = P.lr_code_bits[ch - 1];
+        const int len = P.lr_code_len[lr_prev][ch - 1];
+        const unsigned long long bits = P.lr_code_bits[lr_prev][ch - 1];
         for (int i = len - 1; i >= 0; i--) emit1(y, lane, ENT_LITERAL((int)((bits >> i) & 1)));
+        lr_prev = ch;
       }
     }
   }
@@ -554,7 +599,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     if (tg.sb_y + by >= P.height || tg.sb_x + bx >= P.width) continue;
     const int b8x = bx >> 3, b8y = by >> 3;
     // leaf containing this 8x8 unit (written by the recon kernel); it is coded at its origin only
-    const int leaf = uni(S->info[b8y * 8 + b8x].bsl);
+    const int leaf = uni(INFO(b8x, b8y).bsl);
     if ((bx | by) & ((1 << leaf) - 1)) continue;
     // nodes whose origin is (bx, by): every level above the leaf down to the leaf, largest first.
     // A node at level l > leaf with this origin contains a smaller leaf, so it is a SPLIT node.
@@ -566,8 +611,8 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
       {
         const int half = n >> 1;
         const bool has_rows = tg.sb_y + by + half < P.height, has_cols = tg.sb_x + bx + half < P.width;
-        const int above = by > 0 && uni(S->info[(b8y - 1) * 8 + b8x].bsl) < bsl;
-        const int left = bx > 0 && uni(S->info[b8y * 8 + b8x - 1].bsl) < bsl;
+        const int above = by + toy > 0 && uni(INFO(b8x, b8y - 1).bsl) < bsl;
+        const int left = bx + tox > 0 && uni(INFO(b8x - 1, b8y).bsl) < bsl;
         const int off = CL::PARTITION + ((bsl - 3) * 4 + left * 2 + above) * 11;
         if (has_rows && has_cols) {
           sym_wide(y, lane, adapt, split ? 3 : 0, off, bsl == 3 ? 4 : 10);
@@ -583,18 +628,18 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
       }
       if (split) continue;
       {
-        const int ymode = uni(S->info[b8y * 8 + b8x].ymode), skip = uni(S->info[b8y * 8 + b8x].skip);
-        const int eob0 = uni(S->info[b8y * 8 + b8x].eob[0]), eob1 = uni(S->info[b8y * 8 + b8x].eob[1]), eob2 = uni(S->info[b8y * 8 + b8x].eob[2]);
-        const int avail_u = by > 0, avail_l = bx > 0;
+        const int ymode = uni(INFO(b8x, b8y).ymode), skip = uni(INFO(b8x, b8y).skip);
+        const int eob0 = uni(INFO(b8x, b8y).eob[0]), eob1 = uni(INFO(b8x, b8y).eob[1]), eob2 = uni(INFO(b8x, b8y).eob[2]);
+        const int avail_u = by + toy > 0, avail_l = bx + tox > 0;  // inside the tile
         int sctx = 0;
-        if (avail_u) sctx += uni(S->info[(b8y - 1) * 8 + b8x].skip);
-        if (avail_l) sctx += uni(S->info[b8y * 8 + b8x - 1].skip);
+        if (avail_u) sctx += uni(INFO(b8x, b8y - 1).skip);
+        if (avail_l) sctx += uni(INFO(b8x - 1, b8y).skip);
         sym_wide(y, lane, adapt, skip, CL::SKIP + sctx * 3, 2);
-        const int is_inter = inter_frame ? uni(S->info[b8y * 8 + b8x].is_inter) : 0;
+        const int is_inter = inter_frame ? uni(INFO(b8x, b8y).is_inter) : 0;
         if (inter_frame) {
           // inter_frame_mode_info (§5.11.18): is_inter, context from the neighbours' intra-ness
-          const int a_intra = avail_u ? !uni(S->info[(b8y - 1) * 8 + b8x].is_inter) : 0;
-          const int l_intra = avail_l ? !uni(S->info[b8y * 8 + b8x - 1].is_inter) : 0;
+          const int a_intra = avail_u ? !uni(INFO(b8x, b8y - 1).is_inter) : 0;
+          const int l_intra = avail_l ? !uni(INFO(b8x - 1, b8y).is_inter) : 0;
           int ictx;
           if (avail_u && avail_l) ictx = (l_intra && a_intra) ? 3 : ((l_intra || a_intra) ? 1 : 0);
           else if (avail_u || avail_l) ictx = 2 * (avail_u ? a_intra : l_intra);
@@ -604,14 +649,14 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
         if (is_inter) {
           // inter_block_mode_info (§5.11.23): LAST_FRAME = single_ref_p1 0, p3 0, p4 0; then the cheapest name of
           // the vector the recon kernel used: NEARESTMV, NEARMV, GLOBALMV, else NEWMV against the list's head
-          const int n_last = (avail_u ? uni(S->info[(b8y - 1) * 8 + b8x].is_inter) : 0) + (avail_l ? uni(S->info[b8y * 8 + b8x - 1].is_inter) : 0);
+          const int n_last = (avail_u ? uni(INFO(b8x, b8y - 1).is_inter) : 0) + (avail_l ? uni(INFO(b8x - 1, b8y).is_inter) : 0);
           const int rctx = n_last > 0 ? 2 : 1;
           sym_wide<1>(y, lane, adapt, 0, CL::SINGLE_REF + (0 * 3 + rctx) * 3, 2);
           sym_wide<1>(y, lane, adapt, 0, CL::SINGLE_REF + (2 * 3 + rctx) * 3, 2);
           sym_wide<1>(y, lane, adapt, 0, CL::SINGLE_REF + (3 * 3 + rctx) * 3, 2);
           int new_ctx, ref_ctx;
-          const int num = build_mv_stack(P, tg, by >> 2, bx >> 2, n >> 2, new_ctx, ref_ctx);
-          const int mvr = uni(S->info[b8y * 8 + b8x].mv_row), mvc = uni(S->info[b8y * 8 + b8x].mv_col);
+          const int num = build_mv_stack<TSB>(P, tg, (by + toy) >> 2, (bx + tox) >> 2, n >> 2, new_ctx, ref_ctx);
+          const int mvr = uni(INFO(b8x, b8y).mv_row), mvc = uni(INFO(b8x, b8y).mv_col);
           const int s0r = uni(g_inter.stk_row[0]), s0c = uni(g_inter.stk_col[0]), s1r = uni(g_inter.stk_row[1]), s1c = uni(g_inter.stk_col[1]);
           int mode;  // 0 NEARESTMV 1 NEARMV 2 GLOBALMV 3 NEWMV
           if (num >= 1 && mvr == s0r && mvc == s0c) mode = 0;
@@ -633,15 +678,15 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
           }
           {
             const int n8 = n >> 3;
-            if (lane < n8 * n8) g_inter.newmv[(b8y + lane / n8) * 8 + b8x + lane % n8] = (uint8_t)(mode == 3);
+            if (lane < n8 * n8) g_inter.newmv[(b8y + toy8 + lane / n8) * TW + b8x + tox8 + lane % n8] = (uint8_t)(mode == 3);
           }
         } else {
           if (inter_frame) {
             // intra_block_mode_info (§5.11.22): y_mode by block-size group
             sym_wide<1>(y, lane, adapt, ymode, CL::IF_Y_MODE + (bsl <= 3 ? 1 : (bsl == 4 ? 2 : 3)) * 14, 13);
           } else {
-            const int am = uni(c_intra_mode_ctx[avail_u ? S->info[(b8y - 1) * 8 + b8x].ymode : 0]);
-            const int lm = uni(c_intra_mode_ctx[avail_l ? S->info[b8y * 8 + b8x - 1].ymode : 0]);
+            const int am = uni(c_intra_mode_ctx[avail_u ? INFO(b8x, b8y - 1).ymode : 0]);
+            const int lm = uni(c_intra_mode_ctx[avail_l ? INFO(b8x - 1, b8y).ymode : 0]);
             sym_wide(y, lane, adapt, ymode, CL::KF_Y_MODE + (am * 5 + lm) * 14, 13);
           }
           if (ymode >= 1 && ymode <= 8) sym_wide(y, lane, adapt, 3, CL::ANGLE_DELTA + (ymode - 1) * 8, 7);
@@ -654,21 +699,23 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
         const int log2c = bsl - 1;
         if (skip) {
           __syncthreads();
-          if (lane < w4) { S->above_lvl[0][(bx >> 2) + lane] = 0; S->above_dc[0][(bx >> 2) + lane] = 0; S->left_lvl[0][(by >> 2) + lane] = 0; S->left_dc[0][(by >> 2) + lane] = 0; }
+          if (lane < w4) { TI.above_lvl[0][((bx + tox) >> 2) + lane] = 0; TI.above_dc[0][((bx + tox) >> 2) + lane] = 0; S->left_lvl[0][(by >> 2) + lane] = 0; S->left_dc[0][(by >> 2) + lane] = 0; }
           if (lane < w4c) {
-            for (int pl = 1; pl < 3; pl++) { S->above_lvl[pl][(bx >> 3) + lane] = 0; S->above_dc[pl][(bx >> 3) + lane] = 0; S->left_lvl[pl][(by >> 3) + lane] = 0; S->left_dc[pl][(by >> 3) + lane] = 0; }
+            for (int pl = 1; pl < 3; pl++) { TI.above_lvl[pl][((bx + tox) >> 3) + lane] = 0; TI.above_dc[pl][((bx + tox) >> 3) + lane] = 0; S->left_lvl[pl][(by >> 3) + lane] = 0; S->left_dc[pl][(by >> 3) + lane] = 0; }
           }
           __syncthreads();
         } else {
           for (int pl = 0; pl < 3; pl++) {
             const int l2 = pl ? log2c : bsl;
             const int16_t *lvp = pl == 0 ? sb_levels + by * 64 + bx * n : sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * (n >> 1);
-            sym_coeffs<FULL>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, is_inter, lvp);
+            sym_coeffs<FULL, TSB>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, is_inter, lvp);
           }
         }
       }
     }
   }
+#undef INFO
+  }  // superblocks of the tile
   if (lane == 0) {
     stream_len[blockIdx.x] = (uint32_t)y.pos;
     tile_combos[blockIdx.x] = (uint32_t)((y.combo0 & 0xFF) | ((y.combo1 & 0xFF) << 8));
@@ -866,13 +913,19 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
 extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels,
                                            const Av1miBlkInfo *blk, uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos,
                                            uint8_t *slots, uint32_t *tile_bytes, const uint8_t *lr_choice, hipStream_t stream, hipEvent_t mid) {
-  const int n_tiles = P->n_frames * P->sb_rows * P->sb_cols;
-  hipLaunchKernelGGL((symbolize_tile_kernel<false, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
-  hipLaunchKernelGGL((symbolize_tile_kernel<true, false>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
-  if (P->keyint > 1 && P->n_frames > 1) {  // the chunk has inter frames
-    hipLaunchKernelGGL((symbolize_tile_kernel<false, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
-    hipLaunchKernelGGL((symbolize_tile_kernel<true, true>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, stream_len, tile_combos, lr_choice);
+  const int n_tiles = P->n_frames * P->tile_rows * P->tile_cols;
+  const bool has_inter = P->keyint > 1 && P->n_frames > 1;
+#define SYM_LAUNCH(FULLV, INTERV, TSBV)                                                                                                   \
+  hipLaunchKernelGGL((symbolize_tile_kernel<FULLV, INTERV, TSBV>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, \
+                     stream_len, tile_combos, lr_choice)
+  if (P->tile_sb == 1) {
+    SYM_LAUNCH(false, false, 1); SYM_LAUNCH(true, false, 1);
+    if (has_inter) { SYM_LAUNCH(false, true, 1); SYM_LAUNCH(true, true, 1); }
+  } else {
+    SYM_LAUNCH(false, false, 2); SYM_LAUNCH(true, false, 2);
+    if (has_inter) { SYM_LAUNCH(false, true, 2); SYM_LAUNCH(true, true, 2); }
   }
+#undef SYM_LAUNCH
   if (mid) (void)hipEventRecord(mid, stream);
   hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
                      tile_combos, slots, tile_bytes);

@@ -46,10 +46,21 @@ __constant__ uint8_t c_mode_txfm[13] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3 }
 // x, left[p][y] = right column of the last block reconstructed over row y, corner[p][y4][x4] = pixel
 // (4*y4-1, 4*x4-1).  Z-order + quadtree alignment guarantee that whenever the decoded-block map says an
 // edge is available these hold exactly the pixels spec §7.11.2 asks for.
+// line buffers of a tile of TSB x TSB superblocks (coordinates tile-local); only the instantiations for two-superblock
+// tiles reference - and therefore allocate - the larger set
+template <int TSB>
+struct LineLds {
+  uint16_t above[3][64 * TSB];
+  uint16_t left[3][64 * TSB];
+  uint16_t corner[3][16 * TSB + 1][16 * TSB + 1];
+};
+__shared__ LineLds<1> g_lines1;
+__shared__ LineLds<2> g_lines2;
+template <int TSB> struct LinesSel;
+template <> struct LinesSel<1> { static __device__ __forceinline__ LineLds<1> &get() { return g_lines1; } };
+template <> struct LinesSel<2> { static __device__ __forceinline__ LineLds<2> &get() { return g_lines2; } };
+#define LN (LinesSel<TSB>::get())
 struct SbLds {
-  uint16_t above[3][64];
-  uint16_t left[3][64];
-  uint16_t corner[3][17][17];
   uint16_t blkpix[32 * 32];     // prediction, then reconstruction, of the current transform block
   uint16_t srcblk[32 * 32];     // source pixels of the block; reused for the quantised levels
   int16_t scratch[32 * 33];     // 2-D transform staging (every intermediate fits 16 bits)
@@ -179,6 +190,7 @@ struct SbCtx {
   const Av1miDevParams *P;
   int lane;
   int sb_x, sb_y;          // superblock origin in luma pixels
+  int tox, toy;            // the same relative to the tile origin (0 or 64): line buffers are tile-local
 };
 
 // Inter decision of the current block (inter frames): in = the motion search's result for the block, out (luma
@@ -213,7 +225,7 @@ __device__ __forceinline__ int mc_sample(const PIX *plane, int stride, int last_
 // SAD, DESIGN.md §3.3] -> prediction -> forward transform -> dead-zone quantiser -> normative
 // dequantiser + inverse transform -> reconstruction (HBM + line buffers).
 // `mode_io`: in = mode to use (chroma), out = decided mode (luma).  eob_out[g] = eob of group g.
-template <typename PIX, int LOG2N, int NPL, bool INTER>
+template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB>
 __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
                                                   int &mode_io, InterInfo &ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
   constexpr int N = 1 << LOG2N;
@@ -237,7 +249,9 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   const long poff = plane == 0 ? 0 : (plane == 1 ? P->plane_off_u : P->plane_off_v);
   const int gs = plane0 ? P->stride_c : P->stride_y;
   const int gx = (plane0 ? cx.sb_x >> 1 : cx.sb_x) + x0, gy = (plane0 ? cx.sb_y >> 1 : cx.sb_y) + y0;
-  const int have_above = y0 > 0, have_left = x0 > 0;
+  // tile-local plane coordinates of the block: what the line buffers and edge availability are indexed by
+  const int lx = (plane0 ? cx.tox >> 1 : cx.tox) + x0, ly = (plane0 ? cx.toy >> 1 : cx.toy) + y0;
+  const int have_above = ly > 0, have_left = lx > 0;
   // ---- source block -> LDS (coalesced rows)
   {
     const PIX *pl = frame + poff;
@@ -246,32 +260,32 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   }
   // ---- edges from the line buffers (spec §7.11.2; tile == superblock: nothing outside it is available)
   {
-    const int max_x = ((plane0 ? P->width >> 1 : P->width) - 1) - (plane0 ? cx.sb_x >> 1 : cx.sb_x);
-    const int max_y = ((plane0 ? P->height >> 1 : P->height) - 1) - (plane0 ? cx.sb_y >> 1 : cx.sb_y);
+    const int max_x = ((plane0 ? P->width >> 1 : P->width) - 1) - (gx - lx);   // frame limit, tile-local
+    const int max_y = ((plane0 ? P->height >> 1 : P->height) - 1) - (gy - ly);
     for (int i = sl; i < 2 * N; i += G) {
       int a, l;
-      if (!have_above && have_left) a = S->left[plane][y0];           // pixel (y0, x0-1)
+      if (!have_above && have_left) a = LN.left[plane][ly];           // pixel (y0, x0-1)
       else if (!have_above) a = (1 << (bd - 1)) - 1;
       else {
-        int lim = x0 + (have_ar ? 2 * N : N) - 1;
+        int lim = lx + (have_ar ? 2 * N : N) - 1;
         if (lim > max_x) lim = max_x;
-        a = S->above[plane][x0 + i < lim ? x0 + i : lim];             // pixel (y0-1, .)
+        a = LN.above[plane][lx + i < lim ? lx + i : lim];             // pixel (y0-1, .)
       }
-      if (!have_left && have_above) l = S->above[plane][x0];          // pixel (y0-1, x0)
+      if (!have_left && have_above) l = LN.above[plane][lx];          // pixel (y0-1, x0)
       else if (!have_left) l = (1 << (bd - 1)) + 1;
       else {
-        int lim = y0 + (have_bl ? 2 * N : N) - 1;
+        int lim = ly + (have_bl ? 2 * N : N) - 1;
         if (lim > max_y) lim = max_y;
-        l = S->left[plane][y0 + i < lim ? y0 + i : lim];              // pixel (., x0-1)
+        l = LN.left[plane][ly + i < lim ? ly + i : lim];              // pixel (., x0-1)
       }
       S->edge_a[eo + 1 + i] = (uint16_t)a;
       S->edge_l[eo + 1 + i] = (uint16_t)l;
     }
     if (sl == 0) {
       int tl;
-      if (have_above && have_left) tl = S->corner[plane][y0 >> 2][x0 >> 2];
-      else if (have_above) tl = S->above[plane][x0];
-      else if (have_left) tl = S->left[plane][y0];
+      if (have_above && have_left) tl = LN.corner[plane][ly >> 2][lx >> 2];
+      else if (have_above) tl = LN.above[plane][lx];
+      else if (have_left) tl = LN.left[plane][ly];
       else tl = 1 << (bd - 1);
       S->edge_a[eo] = (uint16_t)tl;
       S->edge_l[eo] = (uint16_t)tl;
@@ -424,13 +438,13 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))] = (PIX)S->blkpix[po + p];
     if (sl < N) {
-      S->above[plane][x0 + sl] = S->blkpix[po + (N - 1) * N + sl];
-      S->left[plane][y0 + sl] = S->blkpix[po + sl * N + (N - 1)];
+      LN.above[plane][lx + sl] = S->blkpix[po + (N - 1) * N + sl];
+      LN.left[plane][ly + sl] = S->blkpix[po + sl * N + (N - 1)];
     }
     if (sl < step) {  // corners at every 4-aligned position of the bottom row and right column
       const int j = sl + 1;
-      S->corner[plane][(y0 + N) >> 2][(x0 >> 2) + j] = S->blkpix[po + (N - 1) * N + 4 * j - 1];
-      S->corner[plane][(y0 >> 2) + j][(x0 + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
+      LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = S->blkpix[po + (N - 1) * N + 4 * j - 1];
+      LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
     }
     for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
   }
@@ -456,7 +470,7 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
   return 0;
 }
 
-template <typename PIX, bool INTER>
+template <typename PIX, bool INTER, int TSB>
 __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
                                                   Av1miBlkInfo *info, int b8_stride, const PIX *ref_frame,
                                                   const unsigned long long *me_best /* this superblock's first unit */) {
@@ -484,14 +498,14 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     int16_t *lv_u = sb_levels + 4096 + (by >> 1) * 32 + (bx >> 1) * (n >> 1), *lv_v = lv_u + 1024;
     // luma (mode decision inside), then U and V together
     switch (bsl) {
-      case 5: tx_item<PIX, 5, 1, INTER>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      case 4: tx_item<PIX, 4, 1, INTER>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      default: tx_item<PIX, 3, 1, INTER>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 5: tx_item<PIX, 5, 1, INTER, TSB>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 4: tx_item<PIX, 4, 1, INTER, TSB>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      default: tx_item<PIX, 3, 1, INTER, TSB>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
     }
     switch (bsl) {
-      case 5: tx_item<PIX, 4, 2, INTER>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      case 4: tx_item<PIX, 3, 2, INTER>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      default: tx_item<PIX, 2, 2, INTER>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 5: tx_item<PIX, 4, 2, INTER, TSB>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 4: tx_item<PIX, 3, 2, INTER, TSB>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      default: tx_item<PIX, 2, 2, INTER, TSB>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
     }
     if (cx.lane == 0) {
       const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
@@ -509,39 +523,53 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
   }
 }
 
-template <typename PIX, bool INTER>
+template <typename PIX, bool INTER, int TSB>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_sb_kernel(Av1miDevParams P, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
                                                      const unsigned long long *__restrict__ me_best) {
-  const int sbs_per_frame = P.sb_rows * P.sb_cols;
-  const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
-  const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
-  SbCtx cx;
-  cx.P = &P; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
+  // one wave per TILE: TSB x TSB superblocks in raster order (TSB = 1 unless the frame needs more than 64 x 64 tiles)
+  const int tiles_per_frame = P.tile_rows * P.tile_cols, sbs_per_frame = P.sb_rows * P.sb_cols;
+  const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
+  const int tr = tile / P.tile_cols, tc = tile % P.tile_cols;
+  // tile extent in 4x4 units, clipped to the frame
+  const int tile_mi_r0 = tr * TSB * 16, tile_mi_c0 = tc * TSB * 16;
+  const int tile_mi_r1 = (tile_mi_r0 + TSB * 16 < P.mi_rows) ? tile_mi_r0 + TSB * 16 : P.mi_rows;
+  const int tile_mi_c1 = (tile_mi_c0 + TSB * 16 < P.mi_cols) ? tile_mi_c0 + TSB * 16 : P.mi_cols;
   const PIX *frame = src + (size_t)f * P.frame_samples;
-  // decoded-block map (clear_block_decoded_flags, spec §5.11.3) with tile == superblock
-  {
-    const int w4 = (P.mi_cols - sbc * 16), h4 = (P.mi_rows - sbr * 16);
-    for (int t = cx.lane; t < 2 * 19 * 19; t += 64) {
-      int pl = t / 361, y = (t % 361) / 19 - 1, x = t % 19 - 1;
-      int sz = 16 >> pl;
-      int sw = (w4 < 16 ? w4 : 16) >> pl, sh = (h4 < 16 ? h4 : 16) >> pl;
-      int v = 0;
-      if (y <= sz && x <= sz) {
-        if (y < 0 && x < sw) v = 1;
-        else if (x < 0 && y < sh) v = 1;
-        if (y == sz && x == -1) v = 0;
+#pragma nounroll
+  for (int si = 0; si < TSB * TSB; si++) {
+    const int sbr = tr * TSB + si / TSB, sbc = tc * TSB + si % TSB;
+    if (sbr >= P.sb_rows || sbc >= P.sb_cols) continue;
+    const int sb = sbr * P.sb_cols + sbc;
+    SbCtx cx;
+    cx.P = &P; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
+    cx.tox = (si % TSB) * 64; cx.toy = (si / TSB) * 64;
+    // decoded-block map (clear_block_decoded_flags, spec §5.11.3): the row above and the column left of the superblock
+    // are decoded as far as the TILE reaches (so the above-right superblock of a two-superblock tile counts)
+    __syncthreads();
+    {
+      const int w4 = tile_mi_c1 - sbc * 16, h4 = tile_mi_r1 - sbr * 16;
+      for (int t = cx.lane; t < 2 * 19 * 19; t += 64) {
+        int pl = t / 361, y = (t % 361) / 19 - 1, x = t % 19 - 1;
+        int sz = 16 >> pl;
+        int sw = w4 >> pl, sh = h4 >> pl;
+        int v = 0;
+        if (y <= sz && x <= sz) {
+          if (y < 0 && x < sw) v = 1;
+          else if (x < 0 && y < sh) v = 1;
+          if (y == sz && x == -1) v = 0;
+        }
+        S->blkdec[pl][y + 1][x + 1] = (uint8_t)v;
       }
-      S->blkdec[pl][y + 1][x + 1] = (uint8_t)v;
     }
+    __syncthreads();
+    int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
+    Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
+    // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
+    encode_superblock<PIX, INTER, TSB>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
+                                       me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
   }
-  __syncthreads();
-  int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
-  Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
-  // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
-  encode_superblock<PIX, INTER>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
-                         me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
 }
 #undef S
 
@@ -551,14 +579,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // predicted from `ref` with the motion search results `me_best` of that frame.
 extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels,
                                          Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, hipStream_t stream) {
-  const int grid = P->n_frames * P->sb_rows * P->sb_cols;
+  const int grid = P->n_frames * P->tile_rows * P->tile_cols;
   const bool inter = ref != nullptr;
+#define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                         \
+  hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)src, (PIXT *)rec, \
+                     levels, blk, (const PIXT *)ref, me_best)
   if (P->bit_depth == 8) {
-    if (inter) hipLaunchKernelGGL((recon_sb_kernel<uint8_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk, (const uint8_t *)ref, me_best);
-    else hipLaunchKernelGGL((recon_sb_kernel<uint8_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)src, (uint8_t *)rec, levels, blk, (const uint8_t *)ref, me_best);
+    if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(uint8_t, true, 1); else RECON_LAUNCH(uint8_t, false, 1); }
+    else { if (inter) RECON_LAUNCH(uint8_t, true, 2); else RECON_LAUNCH(uint8_t, false, 2); }
   } else {
-    if (inter) hipLaunchKernelGGL((recon_sb_kernel<uint16_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk, (const uint16_t *)ref, me_best);
-    else hipLaunchKernelGGL((recon_sb_kernel<uint16_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)src, (uint16_t *)rec, levels, blk, (const uint16_t *)ref, me_best);
+    if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(uint16_t, true, 1); else RECON_LAUNCH(uint16_t, false, 1); }
+    else { if (inter) RECON_LAUNCH(uint16_t, true, 2); else RECON_LAUNCH(uint16_t, false, 2); }
   }
+#undef RECON_LAUNCH
   return hipGetLastError();
 }

@@ -58,7 +58,9 @@ typedef struct {
   uint32_t me_range;        /* inter frames: motion search range in luma samples, 8 or 16 (0 = 8) */
   uint32_t enable_lr;       /* 1 = loop restoration on luma (Wiener, 64x64 units, each unit off or one of 3 filters by SSE);
                                default 0: the decision needs the CDEF output, which serialises CDEF before entropy coding */
-  uint32_t reserved[3];
+  uint32_t tile_sb;         /* tile size in 64x64 superblocks, both ways: 0 = automatic (1; 2 when the frame has more than 64
+                               superblock rows or columns, e.g. 8K - AV1 allows at most 64 x 64 tiles), or force 1 / 2 */
+  uint32_t reserved[2];
 } av1mi_params;
 
 typedef struct {

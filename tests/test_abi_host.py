@@ -75,7 +75,8 @@ def test_invalid_parameters_map_to_failed(av1mi):
         av1mi.write_headers(p)
     assert ei.value.code == av1mi.E_INVALID_ARG
     av1mi.write_headers(av1mi.default_params(64, 64, 8, keyint=240))   # the reference's production keyint (av1an.rs:14)
-    p = av1mi.default_params(64 * 65, 64, 8)   # more than 64 superblock columns: needs tiles larger than one superblock
+    av1mi.write_headers(av1mi.default_params(7680, 4320, 10))   # 120 x 68 superblocks: tiles of 2 x 2 superblocks
+    p = av1mi.default_params(64 * 129, 64, 8)   # more than 128 superblock columns: would need tiles wider than two superblocks
     with pytest.raises(av1mi.EncodeFailed) as ei:
         av1mi.write_headers(p)
     assert ei.value.code == av1mi.E_UNSUPPORTED

@@ -405,3 +405,36 @@ def test_loop_restoration_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, key
     fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
     for i, rec in enumerate(recs):
         assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint,lr", [(328, 248, 8, 2, 4, 1, 0), (200, 120, 10, 3, 5, 240, 0), (264, 200, 8, 3, 3, 2, 1),
+                                                  (648, 360, 10, 2, 5, 2, 1), (136, 136, 8, 2, 5, 1, 0)])
+def test_tiles_of_two_by_two_superblocks_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, lr):
+    """tile_sb = 2 (what frames beyond 64 superblock rows/columns, i.e. 8K, need): intra edges, entropy contexts, CDF
+    adaptation, motion-vector candidates and the restoration reference all run across the four superblocks of a
+    tile.  Forced on small frames and compared with the oracle's 2 x 2 tiles (golden-pinned by dav1d)."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=700 + w, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, enable_lr=lr, tile_sb=2)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, enable_lr=lr, tile_w_sb=2, tile_h_sb=2)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert list(sizes) == [len(t) for t in tus]
+    assert data == b"".join(tus)
+    fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+    for i, rec in enumerate(recs):
+        assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
+
+
+def test_8k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):
+    """BASELINE config 5's frame size (7680x4320, 10-bit): 120 x 68 superblocks exceed AV1's 64 x 64 tile limit, so the
+    encoder switches to tiles of 2 x 2 superblocks by itself (60 x 34 tiles).  One key frame and one P frame, bit-exact
+    against the oracle."""
+    w, h, bd, n = 7680, 4320, 10, 2
+    frames = [oracle.synthclip_frame(w, h, bd, seed=4320, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, keyint=2)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5, tile_w_sb=2, tile_h_sb=2)
+    tus, recs = oracle_chunk(oracle, cfg, frames, 2)
+    assert data == b"".join(tus)
+    fb = w * h * 3
+    assert recon.tobytes()[fb:2 * fb] == raw_of(recs[1], bd)
