@@ -153,7 +153,7 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
 }
 
 template <typename PIX>
-__global__ void __launch_bounds__(64) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
                                                     const Av1miBlkInfo *__restrict__ blk) {
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
