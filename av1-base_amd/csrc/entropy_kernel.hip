@@ -49,7 +49,6 @@ __shared__ InterLds g_inter;
 struct SymLds {
   uint16_t cdf[CL::COEFF_BASE + 64];   // wide rows; +64: whole-row reads by 17 lanes may run past the last row
   int16_t lv[32 * 32];
-  uint16_t scan[1024 + 256 + 64 + 16];  // scan index -> position, for n = 32, 16, 8, 4
   uint8_t left_lvl[3][16], left_dc[3][16];   // per superblock row of the tile
 };
 __shared__ SymLds g_sym;
@@ -130,7 +129,22 @@ __device__ __forceinline__ int scan_index(int row, int col, int n) {
   int lo = d - (n - 1) > 0 ? d - (n - 1) : 0;
   return before + ((d & 1) ? row - lo : col - lo);
 }
-__device__ __forceinline__ int scan_table_off(int log2n) { return log2n == 5 ? 0 : (log2n == 4 ? 1024 : (log2n == 3 ? 1280 : 1344)); }
+// position (row << log2n | col) of scan index c in the default zig-zag of an n x n block: the inverse of scan_index,
+// computed (anti-diagonal by a float square root + integer fix-up) instead of looked up - the table cost 2.7 KB of LDS
+// per wave, i.e. a quarter of the kernel's occupancy
+__device__ __forceinline__ int scan_pos(int c, int log2n) {
+  const int n = 1 << log2n, half = (n * (n + 1)) >> 1;
+  const bool lower = c >= half;
+  const int cm = lower ? n * n - 1 - c : c;          // mirrored index in the lower-right triangle
+  int e = (int)((__builtin_sqrtf(8.0f * (float)cm + 1.0f) - 1.0f) * 0.5f);
+  e += ((e + 1) * (e + 2)) >> 1 <= cm;
+  e -= (e * (e + 1)) >> 1 > cm;
+  const int d = lower ? 2 * n - 2 - e : e;
+  const int before = lower ? n * n - (((2 * n - 1 - d) * (2 * n - d)) >> 1) : (d * (d + 1)) >> 1;
+  const int k = c - before, lo = lower ? d - (n - 1) : 0;
+  const int row = (d & 1) ? lo + k : d - (lo + k), col = d - row;
+  return (row << log2n) | col;
+}
 
 __constant__ uint8_t c_base_ctx_off[5][5] = { { 0, 1, 6, 6, 21 }, { 1, 6, 6, 21, 21 }, { 6, 6, 21, 21, 21 }, { 6, 21, 21, 21, 21 }, { 21, 21, 21, 21, 21 } };
 __constant__ uint8_t c_intra_mode_ctx[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };
@@ -209,8 +223,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
         for (int i = 1; i < nbits; i++) emit1(y, lane, ENT_LITERAL((extra >> (nbits - 1 - i)) & 1));
       }
     }
-    const int scan_off = scan_table_off(log2n);
-#define scan(i_) S->scan[scan_off + (i_)]
+#define scan(i_) scan_pos((i_), log2n)
     // slot range of this (tx size, plane type): the first MAX_COMBOS combinations met in a tile
     // adapt per lane in K4; any further combination is resolved here (cooperatively, slowly).
     const int combo = txs * 2 + ptype;
@@ -528,11 +541,6 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   if (INTER) {
     for (int i = lane; i < CL::TOTAL - CL::INTER_BASE; i += 64) g_cdf_inter[i] = cdf_init[CL::INTER_BASE + i];
     g_cdf_inter[CL::TOTAL - CL::INTER_BASE + lane] = 0;
-  }
-  for (int l2 = 5; l2 >= 2; l2--) {
-    const int n = 1 << l2;
-    const int to = scan_table_off(l2);
-    for (int p = lane; p < n * n; p += 64) S->scan[to + scan_index(p >> l2, p & (n - 1), n)] = (uint16_t)p;
   }
   {
     // block info of the whole tile (zero outside the frame), above contexts cleared (clear_above_context)
