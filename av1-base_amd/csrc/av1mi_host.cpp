@@ -446,7 +446,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     // on the context's own stream: hipMemset would run on the null stream, which a non-blocking stream does not wait
     // for - the fill could land after the first reconstruction kernel had written its block info
     HIPCHK(c, hipMemsetAsync(c->d_blk, 0, nf * nb8 * sizeof(Av1miBlkInfo), c->stream));
-    HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * ntile * slot));
+    HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * ntile * slot * 2));  // 16-bit pre-carry entries, one per output byte
     c->out_cap = nf * (ntile * (size_t)(slot + 4) + 256);
     HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));
     HIPCHK(c, hipMalloc((void **)&c->d_hdr, 256 + nf * 512));

@@ -377,8 +377,27 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
     if (lane < P.tile_size_bytes) dst[lane] = (uint8_t)((n - 1) >> (8 * lane));
     dst += P.tile_size_bytes;
   }
-  const uint8_t *src = slots + (size_t)blockIdx.x * P.tile_slot_bytes;
-  for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+  // The range-coding kernel left 16-bit pre-carry entries d[i] = byte | carry << 8 (carry: +1 to the number formed by the
+  // bytes before i).  Final byte i = (lo(d[i]) + hi(d[i+1]) + carry-in from the right) & 0xFF: a long addition whose
+  // carries are resolved 64 positions at a time, from the end of the tile, with generate/propagate masks and one 64-bit
+  // add per chunk (carry-lookahead: carries = (X + Y + cin) ^ P with X = G | P, Y = G).
+  const uint16_t *pre = reinterpret_cast<const uint16_t *>(slots) + (size_t)blockIdx.x * P.tile_slot_bytes;
+  unsigned long long carry = 0;
+  for (long base = n ? (long)((n - 1) & ~63u) : -1; base >= 0; base -= 64) {
+    const uint32_t i = (uint32_t)base + (uint32_t)lane;
+    const bool valid = i < n;
+    const unsigned d = valid ? pre[i] : 0u, dn = (i + 1 < n) ? pre[i + 1] : 0u;
+    const unsigned sv = (d & 0xFFu) + (dn >> 8);                 // 0 .. 256
+    // bit (63 - lane): carries run from larger i (low bits) to smaller i (high bits)
+    const unsigned long long G = __brevll(__ballot(valid && sv == 256u)), Pm = __brevll(__ballot(valid && sv == 255u));
+    const unsigned long long X = G | Pm;
+    const unsigned long long S1 = X + G, S = S1 + carry;
+    const unsigned long long cout = (S1 < X) | (S < S1);         // carry out of bit 63 = into the previous chunk
+    const unsigned long long C = S ^ Pm;                         // S ^ X ^ Y: carry into every position
+    const unsigned cin = (unsigned)((C >> (63 - lane)) & 1ull);
+    if (valid) dst[i] = (uint8_t)(sv + cin);
+    carry = cout;
+  }
 }
 
 }  // namespace

@@ -778,58 +778,51 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
   // ---- coder state
   uint32_t low = 0, rng = 0x8000;
   int cnt = -9, out_pos = 0;
-  uint32_t acc = 0;  // up to 3 buffered output bytes
-  uint8_t *const out = slots + (size_t)(live ? tile : 0) * P.tile_slot_bytes;
-  const int out_cap = P.tile_slot_bytes;
-
-  // Output: append-only big-endian byte string.  A carry out of the coder (bit 8 of an emitted value)
-  // adds 1 to the number formed by the bytes written so far - first inside the partially filled
-  // word `acc`, then (rare) by read-modify-write of words already stored (after waiting for the
-  // wave's own stores; agent-scope accesses so that no stale L1 line can be read).
+  uint32_t acc = 0;  // one buffered 16-bit entry
+  // Output: "pre-carry" entries, one 16-bit value per output byte holding the byte and, in bit 8, a carry that still
+  // has to be added to the bytes before it (od_ec's precarry buffer).  Nothing already written is ever touched here;
+  // pack_tiles_kernel resolves the carries of a whole tile with a wave-parallel carry-lookahead when it copies the
+  // tile to its final place.  This keeps the serial chain per symbol short: the kernel lasts as long as its longest tile.
+  uint16_t *const out = reinterpret_cast<uint16_t *>(slots) + (size_t)(live ? tile : 0) * P.tile_slot_bytes;
+  const int out_cap = P.tile_slot_bytes;  // entries
 #define EMIT(v_)                                                                               \
   do {                                                                                         \
-    const unsigned ev = (v_);                                                                  \
-    if (ev & 0x100u) {                                                                         \
-      int k = out_pos - 1;                                                                     \
-      for (; k >= (out_pos & ~3); k--) {                                                       \
-        const int sh = 8 * (k & 3);                                                            \
-        if (((acc >> sh) & 0xFF) == 0xFF) acc &= ~(0xFFu << sh);                               \
-        else { acc += 1u << sh; k = -2; break; }                                               \
-      }                                                                                        \
-      if (k >= 0) {                                                                            \
-        /* words already stored: wait for this wave's stores, then read-modify-write through L2 */ \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-        for (; k >= 0; k--) {                                                                  \
-          if ((k | 3) >= out_cap) break; /* slot outgrown: the result is discarded anyway */      \
-          uint32_t *wp = reinterpret_cast<uint32_t *>(out + (k & ~3));                         \
-          uint32_t wv = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
-          const int sh = 8 * (k & 3);                                                          \
-          const bool ff = ((wv >> sh) & 0xFF) == 0xFF;                                         \
-          wv = ff ? (wv & ~(0xFFu << sh)) : wv + (1u << sh);                                   \
-          __hip_atomic_store(wp, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
-          if (!ff) break;                                                                      \
-        }                                                                                      \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-      }                                                                                        \
-    }                                                                                          \
-    acc |= (ev & 0xFFu) << (8 * (out_pos & 3));                                                \
+    const unsigned ev = (v_) & 0x1FFu;                                                         \
+    acc |= ev << (16 * (out_pos & 1));                                                         \
     out_pos++;                                                                                 \
-    if ((out_pos & 3) == 0) {                                                                  \
-      if (out_pos <= out_cap) *reinterpret_cast<uint32_t *>(out + out_pos - 4) = acc;          \
+    if ((out_pos & 1) == 0) {                                                                  \
+      if (out_pos <= out_cap) *reinterpret_cast<uint32_t *>(out + out_pos - 2) = acc;          \
       acc = 0;                                                                                 \
     }                                                                                          \
   } while (0)
 
   __syncthreads();
-  // batch k is resolved by wave 0 in trip k and coded by wave 1 in trip k + 1
+  // batch k is resolved by wave 0 in trip k and coded by wave 1 in trip k + 1.  The resolver's stream reads are one
+  // 16-byte request per lane into 64 different streams (an HBM round trip each): batch k + 1 is loaded while batch k is
+  // being resolved, otherwise every trip would start with that latency.
+  uint4 qn[RC_BATCH / 4];
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < RC_BATCH; j += 4) qn[j / 4] = j < count ? *reinterpret_cast<const uint4 *>(st + j) : make_uint4(0, 0, 0, 0);
+  }
   for (int k = 0; k <= nb; k++) {
     if (wave == 0) {
       if (k < nb) {
-#pragma unroll 4
+        uint4 qc[RC_BATCH / 4];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH / 4; j++) qc[j] = qn[j];
+        if (k + 1 < nb) {
+#pragma unroll
+          for (int j = 0; j < RC_BATCH; j += 4) {
+            const int i1 = (k + 1) * RC_BATCH + j;
+            qn[j / 4] = i1 < count ? *reinterpret_cast<const uint4 *>(st + i1) : make_uint4(0, 0, 0, 0);
+          }
+        }
+#pragma unroll
         for (int j = 0; j < RC_BATCH; j += 4) {
           const int i0 = k * RC_BATCH + j;
           // 4 entries per 16-byte load; stream_cap is a multiple of 4 so the group is in bounds
-          const uint4 q = i0 < count ? *reinterpret_cast<const uint4 *>(st + i0) : make_uint4(0, 0, 0, 0);
+          const uint4 q = qc[j / 4];
 #pragma unroll
           for (int jj = 0; jj < 4; jj++) {
             uint32_t ent = jj == 0 ? q.x : (jj == 1 ? q.y : (jj == 2 ? q.z : q.w));
@@ -909,7 +902,7 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
           n >>= 8;
         } while (s > 0);
       }
-      if ((out_pos & 3) && ((out_pos + 3) & ~3) <= out_cap) *reinterpret_cast<uint32_t *>(out + (out_pos & ~3)) = acc;
+      if ((out_pos & 1) && out_pos + 1 <= out_cap) *reinterpret_cast<uint32_t *>(out + out_pos - 1) = acc;
     }
     if (live) tile_bytes[tile] = overflow ? 0xFFFFFFFFu : (uint32_t)out_pos;
   }
