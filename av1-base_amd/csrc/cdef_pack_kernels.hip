@@ -175,55 +175,66 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
   {
     int ydir = 0, var = 0;
     if (do_filter) {
-      // direction search §7.15.2 on the block's 8 rows of 8 samples (16-byte / 8-byte row loads)
+      // direction search §7.15.2 on the block's 8 rows of 8 samples.  The eight directions' partial sums would need
+      // 120 registers at once; they are built in two groups of four over the same 64 samples (the second read hits L1),
+      // which keeps the kernel at 6 waves/SIMD without spilling.
       const PIX *ty = fr + (size_t)(y0 + b8r * 8) * P.stride_y + x0 + b8c * 8;
-      int cost[8], partial[8][15];
+      int cost[8];
 #pragma unroll
-      for (int a = 0; a < 8; a++) {
-        cost[a] = 0;
+      for (int a = 0; a < 8; a++) cost[a] = 0;
 #pragma unroll
-        for (int b = 0; b < 15; b++) partial[a][b] = 0;
-      }
+      for (int grp = 0; grp < 2; grp++) {
+        int partial[4][15];
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        PIX rowpx[8];
+        for (int a = 0; a < 4; a++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) rowpx[j] = ty[(size_t)i * P.stride_y + j];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int x = ((int)rowpx[j] >> coeff_shift) - 128;
-          partial[0][i + j] += x;
-          partial[1][i + j / 2] += x;
-          partial[2][i] += x;
-          partial[3][3 + i - j / 2] += x;
-          partial[4][7 + i - j] += x;
-          partial[5][3 - i / 2 + j] += x;
-          partial[6][j] += x;
-          partial[7][i / 2 + j] += x;
+          for (int b = 0; b < 15; b++) partial[a][b] = 0;
         }
-      }
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        cost[2] += partial[2][i] * partial[2][i];
-        cost[6] += partial[6][i] * partial[6][i];
-      }
-      cost[2] *= 105;
-      cost[6] *= 105;
+        for (int i = 0; i < 8; i++) {
+          PIX rowpx[8];
 #pragma unroll
-      for (int i = 0; i < 7; i++) {
-        cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * c_div_table[i + 1];
-        cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * c_div_table[i + 1];
-      }
-      cost[0] += partial[0][7] * partial[0][7] * 105;
-      cost[4] += partial[4][7] * partial[4][7] * 105;
+          for (int j = 0; j < 8; j++) rowpx[j] = ty[(size_t)i * P.stride_y + j];
 #pragma unroll
-      for (int i = 1; i < 8; i += 2) {
+          for (int j = 0; j < 8; j++) {
+            const int x = ((int)rowpx[j] >> coeff_shift) - 128;
+            if (grp == 0) {
+              partial[0][i + j] += x;            // direction 0
+              partial[1][i + j / 2] += x;        // 1
+              partial[2][i] += x;                // 2
+              partial[3][3 + i - j / 2] += x;    // 3
+            } else {
+              partial[0][7 + i - j] += x;        // 4
+              partial[1][3 - i / 2 + j] += x;    // 5
+              partial[2][j] += x;                // 6
+              partial[3][i / 2 + j] += x;        // 7
+            }
+          }
+        }
+        // group 0 holds directions 0..3 in partial[0..3], group 1 directions 4..7
+        const int d0 = grp * 4;
+        {  // directions 2 and 6: 8 sums
+          int c = 0;
 #pragma unroll
-        for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
-        cost[i] *= 105;
+          for (int i = 0; i < 8; i++) c += partial[2][i] * partial[2][i];
+          cost[d0 + 2] = c * 105;
+        }
+        {  // directions 0 and 4: 15 diagonals
+          int c = 0;
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-          cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * c_div_table[2 * j + 2];
+          for (int i = 0; i < 7; i++) c += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * c_div_table[i + 1];
+          cost[d0] = c + partial[0][7] * partial[0][7] * 105;
+        }
+#pragma unroll
+        for (int q = 1; q < 4; q += 2) {  // odd directions: 11 sums
+          int c = 0;
+#pragma unroll
+          for (int j = 0; j < 5; j++) c += partial[q][3 + j] * partial[q][3 + j];
+          c *= 105;
+#pragma unroll
+          for (int j = 0; j < 3; j++) c += (partial[q][j] * partial[q][j] + partial[q][10 - j] * partial[q][10 - j]) * c_div_table[2 * j + 2];
+          cost[d0 + q] = c;
+        }
       }
       int best = 0;
 #pragma unroll
