@@ -27,8 +27,8 @@
 extern "C" {
 hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
                               const unsigned long long *me_best, hipStream_t s);
-hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *src, const void *ref, unsigned long long *best, int me_range,
-                                      hipStream_t s);
+hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
+                                      int count, hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
 hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
@@ -363,6 +363,7 @@ struct av1mi_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // CDEF + SSE run here, beside the entropy kernels on `stream`
   hipEvent_t ev[12] = {};
+  std::vector<hipEvent_t> me_ev;       // per frame: its motion search has finished (second stream -> main stream)
   std::string err;
   // workspace (device)
   size_t cap_frames = 0;
@@ -543,8 +544,13 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   av1mi_ctx *c = new (std::nothrow) av1mi_ctx();
   if (!c) return AV1MI_E_OOM;
   c->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) {
+  // the main stream carries the serial chain of a chunk (and the latency-bound range coder): highest priority, so that
+  // the bulk work put beside it on the second stream (CDEF, SSE, the chunk-wide motion search) fills gaps instead of
+  // taking its slots
+  int prio_lo = 0, prio_hi = 0;
+  if (hipSetDevice(device_id) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess) {
     delete c;
     return AV1MI_E_NO_DEVICE;
   }
@@ -559,6 +565,7 @@ void av1mi_ctx_destroy(av1mi_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_workspace(c);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->me_ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -703,7 +710,22 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     Av1miDevParams P1 = P;
     P1.n_frames = 1;
     const size_t fbytes = (size_t)P.frame_samples * bps, nb8 = (size_t)P.b8_rows * P.b8_cols, nsb = (size_t)P.sb_rows * P.sb_cols;
-    HIPCHK(c, hipMemsetAsync(c->d_me, 0xFF, (size_t)n_frames * nb8 * 8, s));
+    // Motion search is open loop (source against previous source): all inter frames at once, on the second stream,
+    // beside the chain below; the first inter frame's reconstruction waits for it.
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[1], 0));  // the source frames are in HBM
+    HIPCHK(c, hipMemsetAsync(c->d_me, 0xFF, (size_t)n_frames * nb8 * 8, c->stream2));
+    // one launch + one event per frame: the chain starts as soon as the first vectors exist and the search of the later
+    // frames fills the SIMDs the chain's one-frame kernels leave idle
+    while (c->me_ev.size() < n_frames) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->me_ev.push_back(e);
+    }
+    for (uint32_t f = 0; f < n_frames; f++) {
+      if (!av1mi_frame_is_inter(P, (int)f)) continue;
+      HIPCHK(c, av1mi_launch_motion_search(&P, d_src, c->d_me, P.me_range, (int)f, 1, c->stream2));
+      HIPCHK(c, hipEventRecord(c->me_ev[f], c->stream2));
+    }
     for (uint32_t f = 0; f < n_frames; f++) {
       const uint8_t *srcf = (const uint8_t *)d_src + f * fbytes;
       uint8_t *recf = (uint8_t *)c->d_rec + f * fbytes, *finf = (uint8_t *)c->d_fin + f * fbytes, *cdf_ = (uint8_t *)cdef_out + f * fbytes;
@@ -714,7 +736,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       } else {
         const uint8_t *reff = (const uint8_t *)c->d_fin + (f - 1) * fbytes;
         unsigned long long *mef = c->d_me + f * nb8;
-        HIPCHK(c, av1mi_launch_motion_search(&P1, srcf, reff, mef, P.me_range, s));
+        HIPCHK(c, hipStreamWaitEvent(s, c->me_ev[f], 0));
         HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, reff, mef, s));
       }
       HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, s));

@@ -3,13 +3,14 @@
 // Replaces the motion search SVT-AV1 runs inside the av1an worker the reference forks
 // (/root/reference/crates/daemon/src/encode/av1an.rs:126-139).  Encoder-side, non-normative; the algorithm is the
 // one DESIGN.md §3.9 defines and oracle/av1o_enc.c (motion_search) restates: for every leaf block of the partition,
-// cost(dx, dy) = SAD(source block, previous reconstruction displaced by (dx, dy)) + n * (|dx| + |dy|) over
+// cost(dx, dy) = SAD(source block, previous SOURCE frame displaced by (dx, dy)) + n * (|dx| + |dy|) over
 // |dx|, |dy| <= R with the displaced block kept within 16 samples of the frame; minimum cost, ties to the first
 // candidate in (dy, dx) raster order.
 //
-// MI355X mapping: frames of a chunk are coded one after the other (each P frame needs the previous
-// reconstruction), so one launch sees only one frame: the grid is (32x32 cells of the frame) x (2R+1 values of
-// dy) = 34 680 waves at 1080p, R = 8 - enough to fill the chip from a single frame.  A wave owns one cell and one
+// MI355X mapping: the search is open loop (source against previous source), so it does not sit on the frame-by-frame
+// reconstruction chain of a chunk: ONE launch searches every inter frame of the chunk (grid.z = frame) on a second
+// stream while the chain runs.  Grid x/y = (32x32 cells of the frame) x (2R+1 values of dy) = 34 680 waves per 1080p
+// frame at R = 8.  A wave owns one cell and one
 // dy: lane = 16 consecutive samples of one cell row (source in registers, the 16 + 2R reference samples the
 // 2R+1 dx candidates need in registers, each loaded once); per dx the lane forms two 8-sample partial SADs,
 // xor-shuffles over the row bits turn them into the 16 8x8 sub-block SADs of the cell, and the leaf blocks of the
@@ -39,49 +40,71 @@ __device__ __forceinline__ int leaf_bsl_cell(const Av1miDevParams &P, int cx, in
 }
 
 template <typename PIX, int R>
-__global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, const PIX *__restrict__ src, const PIX *__restrict__ ref,
-                                                          unsigned long long *__restrict__ best /* per 8x8 unit of the frame */) {
+__global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, const PIX *__restrict__ frames,
+                                                          unsigned long long *__restrict__ best_all /* [frame][8x8 unit] */, int frame0,
+                                                          int vec_ok /* frames are 16-byte aligned */) {
   constexpr int NC = 2 * R + 1;
   __shared__ uint32_t sad8[NC][16];  // [dx][8x8 sub-block of the cell, raster]
+  const int f = frame0 + blockIdx.z;
+  if (!av1mi_frame_is_inter(P, f)) return;  // key frames have no reference
+  const PIX *src = frames + (size_t)f * P.frame_samples, *ref = src - P.frame_samples;  // luma of this and of the previous source frame
+  unsigned long long *best = best_all + (size_t)f * P.b8_rows * P.b8_cols;
   const int cells_x = (P.width + 31) >> 5;
   const int cell = blockIdx.x, dyi = blockIdx.y, dy = dyi - R;
   const int cx = (cell % cells_x) * 32, cy = (cell / cells_x) * 32;
   const int lane = threadIdx.x, r = lane >> 1, half = lane & 1;
   const int W = P.width, H = P.height;
-  // ---- source: 16 samples of row cy + r (zeros outside the frame: those sub-blocks are never used)
-  int s[16];
+  // ---- source: 16 samples of row cy + r (zeros outside the frame: those sub-blocks are never used), reference: samples
+  // x0 - R .. x0 + 15 + R of row cy + r + dy (coordinates clamped to the frame); both packed two samples per register:
+  // s2[k] = source (2k, 2k+1); rE[k] = reference (2k, 2k+1), rO[k] = (2k+1, 2k+2): the source pair k meets rE[k + dx/2]
+  // for even dx and rO[k + (dx-1)/2] for odd dx, compared with v_sad_u16 (4 instructions per 8 samples).
+  uint32_t s2[8], rE[8 + R], rO[8 + R];
   {
-    const int y = cy + r, x0 = cx + half * 16;
+    const int y = cy + r, xs = cx + half * 16;
+    int yr = cy + r + dy;
+    yr = yr < 0 ? 0 : (yr > H - 1 ? H - 1 : yr);
+    const int xr = xs - R;
+    const PIX *srow = src + (size_t)(y < H ? y : H - 1) * P.stride_y, *rrow = ref + (size_t)yr * P.stride_y;
+    if (sizeof(PIX) == 2 && vec_ok && y < H && xs + 16 <= W && xr >= 0 && xr + 16 + 2 * R <= W) {
+      // interior, 16-bit samples: 16-byte loads (xs and xr are multiples of 8 samples)
+      const uint4 *sv = reinterpret_cast<const uint4 *>(srow + xs), *rv = reinterpret_cast<const uint4 *>(rrow + xr);
 #pragma unroll
-    for (int j = 0; j < 16; j++) s[j] = (y < H && x0 + j < W) ? (int)src[(size_t)y * P.stride_y + x0 + j] : 0;
-  }
-  // ---- reference: samples x0 - R .. x0 + 15 + R of row cy + r + dy, coordinates clamped to the frame
-  int rf[16 + 2 * R];
-  {
-    int y = cy + r + dy;
-    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
-    const int x0 = cx + half * 16 - R;
-    const PIX *row = ref + (size_t)y * P.stride_y;
-    if (x0 >= 0 && x0 + 16 + 2 * R <= W) {
+      for (int q = 0; q < 2; q++) { const uint4 v = sv[q]; s2[4 * q] = v.x; s2[4 * q + 1] = v.y; s2[4 * q + 2] = v.z; s2[4 * q + 3] = v.w; }
 #pragma unroll
-      for (int j = 0; j < 16 + 2 * R; j++) rf[j] = (int)row[x0 + j];
+      for (int q = 0; q < (8 + R) / 4; q++) { const uint4 v = rv[q]; rE[4 * q] = v.x; rE[4 * q + 1] = v.y; rE[4 * q + 2] = v.z; rE[4 * q + 3] = v.w; }
     } else {
 #pragma unroll
-      for (int j = 0; j < 16 + 2 * R; j++) { int x = x0 + j; x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x); rf[j] = (int)row[x]; }
+      for (int k = 0; k < 8; k++) {
+        const int xa = xs + 2 * k;
+        const uint32_t p0 = (y < H && xa < W) ? (uint32_t)srow[xa] : 0u, p1 = (y < H && xa + 1 < W) ? (uint32_t)srow[xa + 1] : 0u;
+        s2[k] = p0 | (p1 << 16);
+      }
+#pragma unroll
+      for (int k = 0; k < 8 + R; k++) {
+        int xa = xr + 2 * k, xb = xa + 1;
+        xa = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa); xb = xb < 0 ? 0 : (xb > W - 1 ? W - 1 : xb);
+        rE[k] = (uint32_t)rrow[xa] | ((uint32_t)rrow[xb] << 16);
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 8 + R; k++) rO[k] = k < 8 + R - 1 ? (rE[k] >> 16) | (rE[k + 1] << 16) : 0u;
   }
   // ---- per dx: two 8-sample partial SADs, reduced over the 8 rows of a sub-block (lane bits 1..3)
 #pragma unroll
   for (int dxi = 0; dxi < NC; dxi++) {
-    int a = 0, b = 0;
+    uint32_t a = 0, b = 0;
+    const int h = dxi >> 1;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { a += iabs(s[j] - rf[j + dxi]); b += iabs(s[j + 8] - rf[j + 8 + dxi]); }
+    for (int k = 0; k < 4; k++) {
+      a = __builtin_amdgcn_sad_u16(s2[k], (dxi & 1) ? rO[k + h] : rE[k + h], a);
+      b = __builtin_amdgcn_sad_u16(s2[k + 4], (dxi & 1) ? rO[k + 4 + h] : rE[k + 4 + h], b);
+    }
     a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
     a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
     a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
     if ((r & 7) == 0) {  // lanes of the first row of each sub-block row: sub-blocks (r >> 3, 2 * half) and (.., 2 * half + 1)
-      sad8[dxi][(r >> 3) * 4 + 2 * half] = (uint32_t)a;
-      sad8[dxi][(r >> 3) * 4 + 2 * half + 1] = (uint32_t)b;
+      sad8[dxi][(r >> 3) * 4 + 2 * half] = a;
+      sad8[dxi][(r >> 3) * 4 + 2 * half + 1] = b;
     }
   }
   __syncthreads();
@@ -112,18 +135,20 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
 
 }  // namespace
 
-// best[] must be filled with 0xFF bytes before the launch.  `src`, `ref`: luma planes of the frame and of the
-// previous frame's final reconstruction.  R must be 8 or 16.
-extern "C" hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *src, const void *ref, unsigned long long *best,
-                                                 int me_range, hipStream_t stream) {
+// best[] (n_frames x 8x8 units) must be filled with 0xFF bytes before the launch.  `frames`: the chunk's source frames
+// (P->n_frames of them); every inter frame is searched against the source frame before it.  R must be 8 or 16.
+// Searches frames [frame0, frame0 + count) of the chunk.
+extern "C" hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range,
+                                                 int frame0, int count, hipStream_t stream) {
   const int cells = ((P->width + 31) >> 5) * ((P->height + 31) >> 5);
-  dim3 grid(cells, 2 * me_range + 1);
+  dim3 grid(cells, 2 * me_range + 1, count);
+  const int vec_ok = ((uintptr_t)frames & 15) == 0;  // frame size in bytes is a multiple of 32
   if (P->bit_depth == 8) {
-    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint8_t, 8>), grid, dim3(64), 0, stream, *P, (const uint8_t *)src, (const uint8_t *)ref, best);
-    else hipLaunchKernelGGL((motion_search_kernel<uint8_t, 16>), grid, dim3(64), 0, stream, *P, (const uint8_t *)src, (const uint8_t *)ref, best);
+    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint8_t, 8>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok);
+    else hipLaunchKernelGGL((motion_search_kernel<uint8_t, 16>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok);
   } else {
-    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint16_t, 8>), grid, dim3(64), 0, stream, *P, (const uint16_t *)src, (const uint16_t *)ref, best);
-    else hipLaunchKernelGGL((motion_search_kernel<uint16_t, 16>), grid, dim3(64), 0, stream, *P, (const uint16_t *)src, (const uint16_t *)ref, best);
+    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint16_t, 8>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok);
+    else hipLaunchKernelGGL((motion_search_kernel<uint16_t, 16>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok);
   }
   return hipGetLastError();
 }

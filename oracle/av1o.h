@@ -93,9 +93,10 @@ long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq
                        uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats);
 
 /* Same, with a reference: ref == NULL -> key frame (as av1o_encode_frame); ref != NULL -> INTER_FRAME predicted from
- * `ref` (the previous frame's final reconstruction, the only reference: LAST_FRAME, slot 0 refreshed every frame).
+ * `ref` (the previous frame's final reconstruction, the only reference: LAST_FRAME, slot 0 refreshed every frame), with
+ * motion vectors searched against `prev_src` (the previous SOURCE frame: open-loop search).
  * SURVEY.md §8a rows a13 (motion estimation) and a14 (motion compensation). */
-long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, int with_seq_hdr,
+long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, const Av1oFrame *prev_src, int with_seq_hdr,
                         uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats);
 
 /* size of the sequence header OBU etc. helpers used by the tests */

@@ -58,7 +58,7 @@ def lib():
         L.av1o_encode_frame.argtypes = [C.POINTER(Config), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_size_t,
                                         C.POINTER(Frame), C.POINTER(Stats)]
         L.av1o_encode_frame2.restype = C.c_long
-        L.av1o_encode_frame2.argtypes = [C.POINTER(Config), C.POINTER(Frame), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_size_t,
+        L.av1o_encode_frame2.argtypes = [C.POINTER(Config), C.POINTER(Frame), C.POINTER(Frame), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_size_t,
                                          C.POINTER(Frame), C.POINTER(Stats)]
         L.av1o_synthclip_frame.argtypes = [C.POINTER(Frame), C.c_int, C.c_uint64, C.c_int, C.c_int]
         L.av1o_fwd_txfm2d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -116,20 +116,24 @@ def synthclip_frame(w, h, bit_depth=8, seed=1080, t=0, scene_len=0):
     return planes
 
 
-def encode_frame(cfg, planes, with_seq_hdr=True, ref=None):
+def encode_frame(cfg, planes, with_seq_hdr=True, ref=None, prev_src=None):
     """Returns (temporal-unit bytes, [Y,U,V] reconstruction (uint16), Stats).  `ref`: the previous frame's
-    reconstruction -> the frame is coded as an INTER_FRAME predicted from it; None -> key frame."""
+    reconstruction -> the frame is coded as an INTER_FRAME predicted from it, with motion searched against
+    `prev_src` (the previous source frame); None -> key frame."""
     src = _planes_to_frame(planes)
     rf = _planes_to_frame(ref) if ref is not None else None
+    ps = _planes_to_frame(prev_src) if prev_src is not None else None
     rec = lib().av1o_frame_alloc(cfg.width, cfg.height)
     cap = cfg.width * cfg.height * 6 + (1 << 16)
     buf = C.create_string_buffer(cap)
     st = Stats()
-    n = lib().av1o_encode_frame2(C.byref(cfg), src, rf, 1 if with_seq_hdr else 0, buf, cap, rec, C.byref(st))
+    n = lib().av1o_encode_frame2(C.byref(cfg), src, rf, ps, 1 if with_seq_hdr else 0, buf, cap, rec, C.byref(st))
     recon = _frame_to_planes(rec)
     lib().av1o_frame_free(src)
     if rf is not None:
         lib().av1o_frame_free(rf)
+    if ps is not None:
+        lib().av1o_frame_free(ps)
     lib().av1o_frame_free(rec)
     if n < 0:
         raise RuntimeError("av1o_encode_frame failed: %d" % n)

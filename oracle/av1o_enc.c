@@ -454,6 +454,7 @@ typedef struct Enc_ {
   uint8_t *mi_ymode;
   /* inter frames */
   const Av1oFrame *ref; /* LAST_FRAME: the previous frame's final reconstruction; NULL on key frames */
+  const Av1oFrame *prev_src; /* the previous SOURCE frame: what the motion search looks at */
   uint8_t *mi_is_inter; /* 1: block predicted from LAST_FRAME */
   uint8_t *mi_newmv;    /* 1: coded as NEWMV (counts towards NewMvCount of later blocks) */
   int16_t *mi_mv;       /* [mi][2] = {row, col} in 1/8 luma samples */
@@ -828,15 +829,18 @@ static void predict_inter(const Enc *e, int plane, int x0, int y0, int n, Mv mv,
   free(mid);
 }
 
-/* Integer-pel full search on luma, encoder-side: cost = SAD(source, reference) +
+/* Integer-pel full search on luma, encoder-side, OPEN LOOP: the search compares the source block
+ * with the previous SOURCE frame (e->prev_src), not with the reconstruction it will be predicted from - the vectors of
+ * a whole chunk can then be searched up front, off the frame-by-frame reconstruction chain; its SAD
+ * is also what the inter/intra decision uses.  cost = SAD(source, previous source displaced) +
  * n * (|dx| + |dy|); candidates keep the reference block within 16 samples of the frame (so no motion
  * vector ever needs the clamping of §7.10.2.14); ties go to the first candidate in (dy, dx) raster order.
  * Returns the SAD of the chosen vector. */
 static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
   const int R = e->cfg->me_range, W = e->cfg->width, H = e->cfg->height;
   const uint16_t *src = e->src->p[0] + (size_t)y * e->src->stride[0] + x;
-  const uint16_t *ref = e->ref->p[0];
-  const int rs = e->ref->stride[0], sstr = e->src->stride[0];
+  const uint16_t *ref = e->prev_src->p[0];
+  const int rs = e->prev_src->stride[0], sstr = e->src->stride[0];
   long best_cost = -1;
   int best_sad = 0, dy, dx, i, j;
   best->row = best->col = 0;
@@ -1439,11 +1443,11 @@ static size_t encode_tile(Enc *e, int tr, int tc, uint8_t *out, size_t cap) {
 /* ------------------------------------------------------------------ frame */
 long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq_hdr, uint8_t *out, size_t out_cap,
                        Av1oFrame *recon, Av1oStats *stats) {
-  return av1o_encode_frame2(cfg, src, NULL, with_seq_hdr, out, out_cap, recon, stats);
+  return av1o_encode_frame2(cfg, src, NULL, NULL, with_seq_hdr, out, out_cap, recon, stats);
 }
 
-long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, int with_seq_hdr, uint8_t *out,
-                        size_t out_cap, Av1oFrame *recon, Av1oStats *stats) {
+long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, const Av1oFrame *prev_src, int with_seq_hdr,
+                        uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats) {
   Geom g;
   Enc *e;
   Av1oLrUnit *lr_units = NULL;
@@ -1455,6 +1459,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   if (cfg->width % 8 || cfg->height % 8 || cfg->width < 8 || cfg->height < 8) return -2;
   if (bd != 8 && bd != 10) return -2;
   if (cfg->still_picture && ref) return -2;
+  if (ref && !prev_src) return -2;
   make_geom(cfg, &g);
   if (g.tile_cols > 64 || g.tile_rows > 64) return -3;
   e = (Enc *)calloc(1, sizeof(Enc));
@@ -1467,6 +1472,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   e->mi_skip = (uint8_t *)calloc(n_mi, 1);
   e->mi_ymode = (uint8_t *)calloc(n_mi, 1);
   e->ref = ref;
+  e->prev_src = prev_src;
   e->mi_is_inter = (uint8_t *)calloc(n_mi, 1);
   e->mi_newmv = (uint8_t *)calloc(n_mi, 1);
   e->mi_mv = (int16_t *)calloc(n_mi * 2, sizeof(int16_t));

@@ -214,13 +214,13 @@ def test_film_grain_table_in_frame_headers(av1mi, ctx, oracle):
 
 def oracle_chunk(oracle, cfg, frames, keyint):
     """The oracle's restatement of a chunk: key frame every `keyint` frames, P frames from the previous reconstruction."""
-    tus, recs, ref = [], [], None
+    tus, recs, ref, prev = [], [], None, None
     for t, f in enumerate(frames):
         key = t % keyint == 0
-        tu, rec, st = oracle.encode_frame(cfg, f, with_seq_hdr=key, ref=None if key else ref)
+        tu, rec, st = oracle.encode_frame(cfg, f, with_seq_hdr=key, ref=None if key else ref, prev_src=None if key else prev)
         tus.append(tu)
         recs.append(rec)
-        ref = rec
+        ref, prev = rec, f
     return tus, recs
 
 

@@ -37,14 +37,14 @@ def test_golden_inter_sequences(oracle, golden_sequences):
     modes = [0, 0, 0, 0]
     for m in golden_sequences:
         cfg = oracle.default_config(m["width"], m["height"], m["bit_depth"], **m["config"])
-        ref, pos = None, 0
+        ref, prev, pos = None, None, 0
         for t in range(m["frames"]):
             src = oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t)
-            tu, rec, st = oracle.encode_frame(cfg, src, with_seq_hdr=(t == 0), ref=ref)
+            tu, rec, st = oracle.encode_frame(cfg, src, with_seq_hdr=(t == 0), ref=ref, prev_src=prev)
             assert tu == m["obu"][pos:pos + m["frame_bytes"][t]], (m["name"], t)
             assert sha(rec) == m["dav1d_sha256"][t], (m["name"], t)
             pos += m["frame_bytes"][t]
-            ref = rec
+            ref, prev = rec, src
             modes = [a + int(b) for a, b in zip(modes, st.inter_mode_hist)]
         assert pos == len(m["obu"])
     assert all(x > 50 for x in modes), modes   # every inter mode is exercised

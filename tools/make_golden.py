@@ -92,13 +92,13 @@ def make_sequences():
     index = []
     for name, w, h, bd, seed, n, kw in SEQ_CASES:
         cfg = av1o.default_config(w, h, bd, **kw)
-        tus, recs, ref, modes, ninter = [], [], None, [0, 0, 0, 0], 0
+        tus, recs, ref, prev, modes, ninter = [], [], None, None, [0, 0, 0, 0], 0
         for t in range(n):
             src = av1o.synthclip_frame(w, h, bd, seed=seed, t=t)
-            tu, rec, st = av1o.encode_frame(cfg, src, with_seq_hdr=(t == 0), ref=ref)
+            tu, rec, st = av1o.encode_frame(cfg, src, with_seq_hdr=(t == 0), ref=ref, prev_src=prev)
             tus.append(tu)
             recs.append(rec)
-            ref = rec
+            ref, prev = rec, src
             ninter += int(st.n_inter_blocks)
             modes = [a + int(b) for a, b in zip(modes, st.inter_mode_hist)]
         dec = oracle_avif.decode_sequence(oracle_avif.wrap_avis(tus, w, h, bd), w, h)
