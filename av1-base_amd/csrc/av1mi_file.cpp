@@ -353,7 +353,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
       ck->frames.resize((size_t)chunk_frames * y.frame_bytes);
       int r = 1;
       while (ck->n_frames < chunk_frames && (r = y4m_read_frame(&y, ck->frames.data() + (size_t)ck->n_frames * y.frame_bytes)) == 1) ck->n_frames++;
-      if (r < 0 && !first_err) first_err = r;
+      if (r != 0 && r != 1 && !first_err) first_err = r;  // a malformed or truncated frame (AV1MI_E_FORMAT) or an I/O error
       if (ck->n_frames == 0) { delete ck; break; }
       enqueue(ck);
       if (r != 1 || first_err) break;
@@ -372,7 +372,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
       uint32_t nw = 0;
       int r = 1;
       while (nw < WIN && (r = y4m_read_frame(&y, win.data() + (size_t)nw * y.frame_bytes)) == 1) nw++;
-      if (r < 0 && !first_err) first_err = r;
+      if (r != 0 && r != 1 && !first_err) first_err = r;  // a malformed or truncated frame (AV1MI_E_FORMAT) or an I/O error
       if (nw == 0) break;
       int src = av1mi_scene_cuts(det_ctx, &prm, win.data(), nw, 0, has_prev ? prev.data() : nullptr, &st, MIN_SCENE, nullptr, cuts.data());
       if (src && !first_err) { first_err = src; break; }

@@ -438,3 +438,26 @@ def test_8k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):
     assert data == b"".join(tus)
     fb = w * h * 3
     assert recon.tobytes()[fb:2 * fb] == raw_of(recs[1], bd)
+
+
+def test_encode_file_ragged_and_empty_inputs(av1mi, oracle, tmp_path):
+    """Edge cases at the file boundary: a Y4M with a header but no frames, a truncated last frame, a frame size that
+    is not a multiple of 8 - each a clean encoder failure (-> EncodeError::Av1anFailed in the reference's taxonomy),
+    no output file and no temporary file left behind; a one-frame clip encodes."""
+    w, h = 72, 56
+    fr = raw_of(oracle.synthclip_frame(w, h, 8, seed=81, t=0), 8)
+    hdr = b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h)
+    cases = {"empty": hdr, "truncated": hdr + b"FRAME\n" + fr + b"FRAME\n" + fr[:100], "odd_size": b"YUV4MPEG2 W70 H56 F30:1 C420jpeg\nFRAME\n" + bytes(70 * 56 * 3 // 2)}
+    for name, blob in cases.items():
+        src = tmp_path / (name + ".y4m")
+        src.write_bytes(blob)
+        out = tmp_path / (name + ".ivf")
+        with pytest.raises(av1mi.EncodeFailed) as ei:
+            av1mi.run_mi355x(av1mi.EncodeParams(src, out, tmp_path, av1mi.derive_plan(8)))
+        assert ei.value.code in (av1mi.E_FORMAT, av1mi.E_INVALID_ARG), name
+        assert not out.exists() and not list(tmp_path.glob("*.tmp*")), name
+    one = tmp_path / "one.y4m"
+    one.write_bytes(hdr + b"FRAME\n" + fr)
+    out = tmp_path / "one.ivf"
+    rep = av1mi.run_mi355x(av1mi.EncodeParams(one, out, tmp_path, av1mi.derive_plan(8), chunk_frames=0))
+    assert rep.frames == 1 and rep.chunks == 1 and out.stat().st_size > 32
