@@ -104,7 +104,8 @@ __device__ __forceinline__ int cdef_pixel(const PIX *pl, int stride, int w, int 
 }
 
 template <typename PIX, bool EDGE>
-__device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PIX *fr, PIX *fo, int x0, int y0, int w, int h, int lane) {
+__device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PIX *fr, PIX *fo, int x0, int y0, int w, int h, int lane,
+                                               int row0, int row1 /* luma rows [row0, row1) of the superblock, multiples of 8 */) {
   const int coeff_shift = P.bit_depth - 8;
   // ---- luma: lane = column, loop over rows (row-contiguous HBM loads and stores)
   {
@@ -114,7 +115,7 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
     const int ypri0 = P.cdef_y_pri;
     if (lane < w) {
 #pragma unroll 8
-      for (int r = 0; r < h; r++) {   // h is a multiple of 8: the 8 rows of a block share the decisions and their loads overlap
+      for (int r = row0; r < (row1 < h ? row1 : h); r++) {   // multiples of 8: the 8 rows of a block share the decisions and their loads overlap
         const int b = (r >> 3) * 8 + (lane >> 3);
         const int gx = x0 + lane, gy = y0 + r;
         int v = fr[(size_t)gy * P.stride_y + gx];
@@ -139,7 +140,7 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
     const int wc = w >> 1, hc = h >> 1;
     if (col < wc) {
 #pragma unroll 4
-      for (int r = 0; r < hc; r++) {
+      for (int r = row0 >> 1; r < ((row1 >> 1) < hc ? (row1 >> 1) : hc); r++) {
         const int b = (r >> 2) * 8 + (col >> 2);
         const int gx = (x0 >> 1) + col, gy = (y0 >> 1) + r;
         int v = cp[(size_t)gy * P.stride_c + gx];
@@ -152,11 +153,15 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
   }
 }
 
-template <typename PIX>
+// NS = 1: one wave per superblock (chunk-wide launches: throughput).  NS = 4: one wave per 16-row strip of a superblock
+// (one-frame launches of inter chunks: 4x the waves and a quarter of the serial work per wave: latency).
+template <typename PIX, int NS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
                                                     const Av1miBlkInfo *__restrict__ blk) {
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
-  const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
+  const int strip = NS == 1 ? 0 : (int)(blockIdx.x % NS);
+  const int item = blockIdx.x / NS;
+  const int f = item / sbs_per_frame, sb = item % sbs_per_frame;
   const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols;
   const int lane = threadIdx.x;
   const PIX *fr = rec + (size_t)f * P.frame_samples;
@@ -172,9 +177,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
   // cdef_idx of the superblock is coded (== 0) iff some block in it is not skipped (§5.11.56)
   const bool sb_on = __ballot(inside && !skip) != 0ull;
   const bool do_filter = P.enable_cdef && sb_on && inside && !skip;
+  const bool mine = NS == 1 || (b8r >> 1) == strip;   // this wave decides (and filters) only the blocks of its strip
   {
     int ydir = 0, var = 0;
-    if (do_filter) {
+    if (do_filter && mine) {
       // direction search §7.15.2 on the block's 8 rows of 8 samples.  The eight directions' partial sums would need
       // 120 registers at once; they are built in two groups of four over the same 64 samples (the second read hits L1),
       // which keeps the kernel at 6 waves/SIMD without spilling.
@@ -257,8 +263,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
   __syncthreads();
   // taps reach 2 samples beyond the superblock (1 in chroma): interior superblocks need no tests
   const bool edge = x0 < 2 || y0 < 2 || x0 + 66 > P.width || y0 + 66 > P.height;
-  if (edge) cdef_filter_sb<PIX, true>(P, fr, fo, x0, y0, w, h, lane);
-  else cdef_filter_sb<PIX, false>(P, fr, fo, x0, y0, w, h, lane);
+  const int row0 = NS == 1 ? 0 : strip * 16, row1 = NS == 1 ? 64 : strip * 16 + 16;
+  if (edge) cdef_filter_sb<PIX, true>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
+  else cdef_filter_sb<PIX, false>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
 }
 
 // ------------------------------------------------------------------------------ SSE (PSNR)
@@ -415,10 +422,14 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
 
 extern "C" hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t stream) {
   const int grid = P->n_frames * P->sb_rows * P->sb_cols;
-  if (P->bit_depth == 8)
-    hipLaunchKernelGGL(cdef_sb_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)rec, (uint8_t *)fin, blk);
-  else
-    hipLaunchKernelGGL(cdef_sb_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)rec, (uint16_t *)fin, blk);
+  const bool strips = P->n_frames == 1;  // a one-frame launch sits on an inter chunk's serial chain
+  if (P->bit_depth == 8) {
+    if (strips) hipLaunchKernelGGL((cdef_sb_kernel<uint8_t, 4>), dim3(grid * 4), dim3(64), 0, stream, *P, (const uint8_t *)rec, (uint8_t *)fin, blk);
+    else hipLaunchKernelGGL((cdef_sb_kernel<uint8_t, 1>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)rec, (uint8_t *)fin, blk);
+  } else {
+    if (strips) hipLaunchKernelGGL((cdef_sb_kernel<uint16_t, 4>), dim3(grid * 4), dim3(64), 0, stream, *P, (const uint16_t *)rec, (uint16_t *)fin, blk);
+    else hipLaunchKernelGGL((cdef_sb_kernel<uint16_t, 1>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)rec, (uint16_t *)fin, blk);
+  }
   return hipGetLastError();
 }
 
