@@ -23,16 +23,72 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "av1-base_amd"))
 
 
-def make_clip(w, h, bd, n, seed):
-    """synthclip v1 frames as one I420 byte string (generated with the oracle's generator: test
-    infrastructure used only to SYNTHESISE INPUT, never in the measured path)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    """numpy uint64 arrays (or a Python int); arithmetic modulo 2^64"""
     import numpy as np
-    import av1o
+    if isinstance(x, int):
+        x = (x + 0x9E3779B97F4A7C15) & _M64
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+        return x ^ (x >> 31)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def synthclip_frame(w, h, bd, seed, t):
+    """`synthclip v1` in numpy: gradients panning (2, 1) px/frame, 6 opaque rectangles moving (+-3, +-2),
+    splitmix64 noise; byte for byte what oracle/av1o_synth.c generates (tests/test_oracle.py checks that), written here
+    so that synthesising the benchmark input needs nothing from oracle/."""
+    import numpy as np
+
+    def tri(v, P):
+        m = v % (2 * P)
+        m = np.where(m > P, 2 * P - m, m)
+        return (m * 64) // P
+    sh, maxv, G = bd - 8, (1 << bd) - 1, (1 if bd == 8 else 4)
+    rects = []
+    for k in range(6):
+        hh = _splitmix64((seed * 977 + k) & _M64)
+        vx, vy = (3 if hh & 1 else -3), (2 if hh & 2 else -2)
+        rw, rh = 32 + (hh >> 8) % (w // 4 + 1), 32 + (hh >> 24) % (h // 4 + 1)
+        rx, ry = (hh >> 40) % w + vx * t, (hh >> 52) % h + vy * t
+        h2 = _splitmix64(hh)
+        rects.append((rx % w, ry % h, rw, rh, [(h2 >> 3) & 255, (h2 >> 13) & 255, (h2 >> 23) & 255]))
+    planes = []
+    for pl in range(3):
+        ss = 1 if pl else 0
+        pw, ph = w >> ss, h >> ss
+        A1, A2, P1, P2 = (48, 32, 53, 41) if pl else (96, 64, 97, 61)
+        base = 128 - (A1 + A2) // 2 if pl else 16
+        x = np.arange(pw, dtype=np.int64)[None, :]
+        y = np.arange(ph, dtype=np.int64)[:, None]
+        v = base + (tri(x + ((2 * t) >> ss), P1) * A1) // 64 + (tri(y + (t >> ss), P2) * A2) // 64
+        v = np.broadcast_to(v, (ph, pw)).copy()
+        fx, fy = x << ss, y << ss
+        for (px, py, rw, rh, rv) in rects:
+            inside = (fx >= px) & (fx < px + rw) & (fy >= py) & (fy < py + rh)
+            v = np.where(inside, rv[pl], v)
+        v = v << sh
+        key = (np.uint64(seed) ^ np.uint64((t << 40) & _M64)) ^ ((np.uint64(pl * 8192) + y.astype(np.uint64)) << np.uint64(20)) ^ x.astype(np.uint64)
+        nz = _splitmix64(key)
+        v = v + ((nz & np.uint64(15)).astype(np.int64) - 8) * G
+        planes.append(np.clip(v, 0, maxv).astype(np.uint16))
+    return planes
+
+
+def make_clip(w, h, bd, n, seed):
+    """synthclip v1 frames as one I420 byte string"""
+    import numpy as np
     dt = np.uint8 if bd == 8 else np.dtype("<u2")
     out = []
     for t in range(n):
-        fr = av1o.synthclip_frame(w, h, bd, seed=seed, t=t)
+        fr = synthclip_frame(w, h, bd, seed, t)
         out.append(b"".join(p.astype(dt).tobytes() for p in fr))
     return b"".join(out)
 

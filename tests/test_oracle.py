@@ -312,3 +312,18 @@ def test_synthclip_scene_cut_and_motion(oracle):
     assert (c[0] == d[0]).all()
     ten = oracle.synthclip_frame(128, 64, 10, seed=9, t=0)
     assert ten[0].max() > 255 and ten[0].max() <= 1023
+
+
+def test_bench_synthclip_equals_the_oracle_generator(oracle):
+    """bench.py synthesises its input with its own numpy `synthclip v1` (so the benchmark's product leg needs nothing from
+    oracle/): it must be the same clip, byte for byte, as the C generator the parity tests use."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for (w, h, bd, seed, t) in [(200, 120, 8, 1080, 0), (72, 56, 10, 1083, 5), (328, 248, 8, 7, 13), (640, 360, 10, 1080, 59)]:
+        a = bench.synthclip_frame(w, h, bd, seed, t)
+        b = oracle.synthclip_frame(w, h, bd, seed=seed, t=t)
+        assert all((a[i] == b[i]).all() for i in range(3)), (w, h, bd, seed, t)
