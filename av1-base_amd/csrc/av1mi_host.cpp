@@ -367,7 +367,7 @@ struct av1mi_ctx {
   std::string err;
   // workspace (device)
   size_t cap_frames = 0;
-  int cap_scale = 1;   // per-tile symbol-stream / bitstream-slot capacity multiplier (1, 2, 4, 8, 16)
+  int cap_scale = 1;   // per-tile symbol-stream / bitstream-slot capacity multiplier (1, 2, 4, ... 64)
   int ws_scale = 0;    // the multiplier the workspace was allocated with
   Resolved res = {};
   void *d_src = nullptr, *d_rec = nullptr, *d_fin = nullptr;
@@ -429,12 +429,13 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   const size_t frame_samples = (size_t)p.width * p.height * 3 / 2;
   const size_t nsb = (size_t)r.sb_cols * r.sb_rows;
   const size_t ntile = (size_t)r.tile_cols * r.tile_rows;
-  // Per-tile capacities.  The x1 sizes hold any tile of ordinary content at the supported CQ range; a
-  // tile that outgrows them is detected on the device and the chunk is re-run at the next multiplier.
-  // x16 is the true worst case of a 64x64 4:2:0 tile (6144 coefficients x <= 37 stream entries:
-  // base + 4 range + sign + 31 Golomb bits; <= 10 output bytes per coefficient), so the retry ends.
-  const int slot = (bps == 1 ? 8192 : 16384) * c->cap_scale * r.tile_sb * r.tile_sb;
-  const int stream_cap = 16384 * c->cap_scale * r.tile_sb * r.tile_sb;
+  // Per-tile capacities (per superblock of the tile): 8192 symbol-stream entries and 4096 output bytes hold any tile of
+  // ordinary content down to about CQ 20 (1080p clip at CQ 30: longest tile 4826 entries, ~1.2 KB); a tile that outgrows
+  // them is detected on the device and the chunk is re-run at the next multiplier, which the context then keeps.
+  // x32 / x64 reach the true worst case of a 64x64 4:2:0 tile (6144 coefficients x <= 37 stream entries: base + 4
+  // range + sign + 31 Golomb bits; <= 10 output bytes per coefficient), so the retry ends.
+  const int slot = 4096 * c->cap_scale * r.tile_sb * r.tile_sb;
+  const int stream_cap = 8192 * c->cap_scale * r.tile_sb * r.tile_sb;
   if (!same) {
     free_workspace(c);
     const size_t nf = n_frames;
@@ -648,7 +649,7 @@ int av1mi_encode_chunk(av1mi_ctx *c, const av1mi_params *params, const void *fra
   if (!c || !frames || !out || n_frames == 0) return AV1MI_E_INVALID_ARG;
   for (;;) {
     const int rc = encode_chunk_once(c, params, frames, n_frames, frames_on_device, out, frame_sizes, recon, report);
-    if (rc != AV1MI_E_OVERFLOW || c->cap_scale >= 16) return rc;
+    if (rc != AV1MI_E_OVERFLOW || c->cap_scale >= 64) return rc;
     c->cap_scale *= 2;  // stays raised for the following chunks of this context (same content)
   }
 }
