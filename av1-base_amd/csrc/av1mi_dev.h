@@ -65,6 +65,17 @@ struct Av1miBlkInfo {
 static_assert(sizeof(Av1miBlkInfo) == 16, "block info is one 16-byte record");
 
 #define AV1MI_SB_LEVELS 6144  // int16 levels per superblock: 64*64 + 2*32*32
+// Offset of a block's levels inside its superblock's 6144: blocks are stored in Morton (Z) order of their origin's
+// 8x8 unit - a block of n x n samples at a quadtree-aligned origin covers (n/8)^2 consecutive Morton indices, so its
+// n*n levels are contiguous and blocks of any mix of sizes never overlap.  Luma 64 levels per unit, then U and V with
+// 16 per unit.  (bx, by): luma sample position of the block inside the superblock.
+AV1MI_HD inline int av1mi_morton8(int ux, int uy) {
+  return (ux & 1) | ((uy & 1) << 1) | ((ux & 2) << 1) | ((uy & 2) << 2) | ((ux & 4) << 2) | ((uy & 4) << 3);
+}
+AV1MI_HD inline int av1mi_levels_off(int plane, int bx, int by) {
+  const int m = av1mi_morton8(bx >> 3, by >> 3);
+  return plane == 0 ? m * 64 : 4096 + (plane - 1) * 1024 + m * 16;
+}
 
 // Default-CDF blob layout (uint16 inverted CDFs, each row n+1 entries: n-1 values, 0, counter)
 // for one q context; offsets in uint16 units.  Mirrors the per-tile adaptive state.

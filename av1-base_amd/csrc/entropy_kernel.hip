@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
         } else {
           for (int pl = 0; pl < 3; pl++) {
             const int l2 = pl ? log2c : bsl;
-            const int16_t *lvp = pl == 0 ? sb_levels + by * 64 + bx * n : sb_levels + 4096 + (pl - 1) * 1024 + (by >> 1) * 32 + (bx >> 1) * (n >> 1);
+            const int16_t *lvp = sb_levels + av1mi_levels_off(pl, bx, by);
             sym_coeffs<FULL, TSB>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, is_inter, lvp);
           }
         }

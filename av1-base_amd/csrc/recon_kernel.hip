@@ -512,8 +512,8 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
       ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
       ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
     }
-    int16_t *lv_y = sb_levels + by * 64 + bx * n;
-    int16_t *lv_u = sb_levels + 4096 + (by >> 1) * 32 + (bx >> 1) * (n >> 1), *lv_v = lv_u + 1024;
+    int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
+    int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
     // luma (mode decision inside), then U and V together
     switch (bsl) {
       case 5: tx_item<PIX, 5, 1, INTER, TSB>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;

@@ -65,7 +65,10 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
 
 @pytest.mark.parametrize("w,h,bd,n,bs,cdf", [
     (64, 64, 8, 1, 5, 1), (64, 64, 10, 3, 4, 1), (8, 8, 8, 2, 5, 1), (72, 56, 8, 2, 3, 1), (200, 120, 8, 4, 5, 0),
-    (328, 248, 10, 2, 5, 1), (136, 136, 8, 3, 4, 1), (640, 360, 8, 2, 5, 1)])
+    (328, 248, 10, 2, 5, 1), (136, 136, 8, 3, 4, 1), (640, 360, 8, 2, 5, 1),
+    # widths whose remainder modulo 64 mixes block sizes side by side (24 = 16 + 8, 40, 48, 56): regression for the
+    # level-buffer layout, which let horizontally adjacent blocks of different sizes overlap
+    (216, 72, 8, 1, 5, 1), (232, 120, 10, 2, 5, 1), (248, 88, 8, 1, 4, 1), (120, 184, 8, 2, 5, 0)])
 def test_chunk_bitstream_and_recon_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, cdf):
     frames = [oracle.synthclip_frame(w, h, bd, seed=1000 + w, t=t, scene_len=2) for t in range(n)]
     p = av1mi.default_params(w, h, bd, block_log2=bs, cdf_update=cdf)
@@ -461,3 +464,44 @@ def test_encode_file_ragged_and_empty_inputs(av1mi, oracle, tmp_path):
     out = tmp_path / "one.ivf"
     rep = av1mi.run_mi355x(av1mi.EncodeParams(one, out, tmp_path, av1mi.derive_plan(8), chunk_frames=0))
     assert rep.frames == 1 and rep.chunks == 1 and out.stat().st_size > 32
+
+
+def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
+    """Seeded sweep over combinations of the operating point (frame size, bit depth, block size, CQ, candidate modes,
+    static/adaptive CDFs, key-frame interval, search range, loop restoration, film grain, tile size): every stream and
+    every reconstruction bit-exact against the oracle."""
+    rng = np.random.default_rng(2026)
+    for it in range(14):
+        w, h = int(rng.integers(1, 30)) * 8, int(rng.integers(1, 22)) * 8
+        bd = int(rng.choice([8, 10]))
+        bs = int(rng.choice([3, 4, 5]))
+        cq = int(rng.choice([12, 24, 30, 40, 55]))
+        mask = int(rng.choice([0x7, 0x1, 0x1FFF, 0x1E07, 0x0015]))
+        cdf = int(rng.integers(0, 2))
+        keyint = int(rng.choice([1, 2, 3, 240]))
+        me = int(rng.choice([8, 16]))
+        lr = int(rng.integers(0, 2))
+        fg = int(rng.choice([0, 0, 20]))
+        tsb = int(rng.choice([1, 1, 2]))
+        n = int(rng.integers(1, 4))
+        frames = [oracle.synthclip_frame(w, h, bd, seed=3000 + it, t=t) for t in range(n)]
+        p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
+                                 enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb)
+        data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+        cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq), mode_mask=mask,
+                                    disable_cdf_update=0 if cdf else 1, me_range=me, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb,
+                                    film_grain=1 if fg else 0, fg_y_scaling=2 * fg, fg_c_scaling=fg)
+        tus, recs, ref, prev = [], [], None, None
+        for t, f in enumerate(frames):
+            key = t % keyint == 0
+            cfg.fg_seed = (7391 + 173 * (5 + t)) & 0xFFFF
+            tu, rec, st = oracle.encode_frame(cfg, f, with_seq_hdr=key, ref=None if key else ref, prev_src=None if key else prev)
+            tus.append(tu)
+            recs.append(rec)
+            ref, prev = rec, f
+        desc = dict(it=it, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n)
+        assert list(sizes) == [len(t) for t in tus], desc
+        assert data == b"".join(tus), desc
+        fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+        for i, rec in enumerate(recs):
+            assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), (desc, i)
