@@ -470,8 +470,9 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
     """Seeded sweep over combinations of the operating point (frame size, bit depth, block size, CQ, candidate modes,
     static/adaptive CDFs, key-frame interval, search range, loop restoration, film grain, tile size): every stream and
     every reconstruction bit-exact against the oracle."""
-    rng = np.random.default_rng(2026)
-    for it in range(14):
+    # AV1MI_SWEEP_ITERS / AV1MI_SWEEP_SEED: longer hunts during bring-up (the default sweep found the level-buffer overlap)
+    rng = np.random.default_rng(int(os.environ.get("AV1MI_SWEEP_SEED", "2026")))
+    for it in range(int(os.environ.get("AV1MI_SWEEP_ITERS", "14"))):
         w, h = int(rng.integers(1, 30)) * 8, int(rng.integers(1, 22)) * 8
         bd = int(rng.choice([8, 10]))
         bs = int(rng.choice([3, 4, 5]))
