@@ -12,7 +12,8 @@
 
 // Uniform kernel parameters of one chunk (all frames of a chunk share them).
 struct Av1miDevParams {
-  int width, height, bit_depth;
+  int width, height, bit_depth;   // CODED size: the signalled size rounded up to multiples of 8 (the source is edge-extended)
+  int true_w, true_h;             // signalled size: what the decoder crops to, clamps references to and restores within
   int mi_rows, mi_cols;     // 4x4 units
   int sb_rows, sb_cols;     // 64x64 superblocks
   int tile_sb;              // tile size in superblocks, both ways: 1, or 2 when the frame has more than 64 superblock rows/columns

@@ -30,6 +30,7 @@ hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *re
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
                                       int count, hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
+hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop, hipStream_t s);
 hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
@@ -73,6 +74,7 @@ int bits_for(unsigned v) { int n = 0; while (v) { n++; v >>= 1; } return n ? n :
 struct Resolved {
   av1mi_params p;
   int qidx;
+  int cw, ch;                         // coded size: p.width / p.height rounded up to multiples of 8
   int sb_cols, sb_rows;
   int tile_sb, tile_cols, tile_rows;  // tiles of tile_sb x tile_sb superblocks (1, or 2 beyond 64 superblocks either way)
 };
@@ -86,7 +88,8 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (!in) return AV1MI_E_INVALID_ARG;
   r->p = *in;
   av1mi_params &p = r->p;
-  if (p.width < 8 || p.height < 8 || (p.width & 7) || (p.height & 7) || p.width > 65536 || p.height > 65536) return AV1MI_E_INVALID_ARG;
+  if (p.width < 8 || p.height < 8 || (p.width & 1) || (p.height & 1) || p.width > 65536 || p.height > 65536) return AV1MI_E_INVALID_ARG;
+  r->cw = (int)((p.width + 7) & ~7u); r->ch = (int)((p.height + 7) & ~7u);
   if (p.bit_depth != 8 && p.bit_depth != 10) return AV1MI_E_INVALID_ARG;
   if (p.cq_level > 63 || p.film_grain > 50) return AV1MI_E_INVALID_ARG;
   if (p.keyint == 0) p.keyint = 1;
@@ -97,8 +100,8 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
-  r->sb_cols = (p.width + 63) / 64;
-  r->sb_rows = (p.height + 63) / 64;
+  r->sb_cols = (r->cw + 63) / 64;
+  r->sb_rows = (r->ch + 63) / 64;
   // AV1 allows at most 64 x 64 tiles: frames beyond 64 superblocks either way (8K) use tiles of 2 x 2 superblocks
   if (p.tile_sb > 2) return AV1MI_E_INVALID_ARG;
   r->tile_sb = p.tile_sb ? (int)p.tile_sb : ((r->sb_cols > 64 || r->sb_rows > 64) ? 2 : 1);
@@ -380,6 +383,7 @@ struct av1mi_ctx {
   unsigned long long *d_frame_off = nullptr, *d_sse = nullptr;
   int *d_overflow = nullptr;
   unsigned long long *d_me = nullptr;  // motion search results per 8x8 unit per frame
+  void *d_stage = nullptr;             // sizes that are not multiples of 8: frames in the caller's tight layout (input / reconstruction out)
   void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
   uint8_t *d_lrc = nullptr;            // per restoration unit: 0 = off, k = candidate k-1
   size_t out_cap = 0;
@@ -411,11 +415,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -426,7 +430,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   bool same = c->cap_frames >= n_frames && c->res.p.width == p.width && c->res.p.height == p.height && c->res.p.bit_depth == p.bit_depth &&
               c->ws_scale == c->cap_scale;
   const int bps = p.bit_depth > 8 ? 2 : 1;
-  const size_t frame_samples = (size_t)p.width * p.height * 3 / 2;
+  const size_t frame_samples = (size_t)r.cw * r.ch * 3 / 2;   // coded size
   const size_t nsb = (size_t)r.sb_cols * r.sb_rows;
   const size_t ntile = (size_t)r.tile_cols * r.tile_rows;
   // Per-tile capacities (per superblock of the tile): 8192 symbol-stream entries and 4096 output bytes hold any tile of
@@ -443,7 +447,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc(&c->d_rec, nf * frame_samples * bps));
     HIPCHK(c, hipMalloc(&c->d_fin, nf * frame_samples * bps));
     HIPCHK(c, hipMalloc((void **)&c->d_levels, nf * nsb * AV1MI_SB_LEVELS * sizeof(int16_t)));
-    const size_t nb8 = (size_t)(p.width / 8) * (p.height / 8);
+    const size_t nb8 = (size_t)(r.cw / 8) * (r.ch / 8);
     HIPCHK(c, hipMalloc((void **)&c->d_blk, nf * nb8 * sizeof(Av1miBlkInfo)));
     // on the context's own stream: hipMemset would run on the null stream, which a non-blocking stream does not wait
     // for - the fill could land after the first reconstruction kernel had written its block info
@@ -467,6 +471,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     c->cap_frames = n_frames;
     c->ws_scale = c->cap_scale;
   }
+  if ((r.cw != (int)p.width || r.ch != (int)p.height) && !c->d_stage)
+    HIPCHK(c, hipMalloc(&c->d_stage, c->cap_frames * (size_t)p.width * p.height * 3 / 2 * bps));
   if (p.enable_lr && !c->d_cd) {
     const size_t nf = c->cap_frames;
     HIPCHK(c, hipMalloc(&c->d_cd, nf * frame_samples * bps));
@@ -475,11 +481,12 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   c->res = r;
   Av1miDevParams &P = c->P;
   memset(&P, 0, sizeof(P));
-  P.width = p.width; P.height = p.height; P.bit_depth = p.bit_depth;
-  P.mi_rows = p.height / 4; P.mi_cols = p.width / 4;
+  P.width = r.cw; P.height = r.ch; P.bit_depth = p.bit_depth;
+  P.true_w = (int)p.width; P.true_h = (int)p.height;
+  P.mi_rows = r.ch / 4; P.mi_cols = r.cw / 4;
   P.sb_rows = r.sb_rows; P.sb_cols = r.sb_cols;
   P.tile_sb = r.tile_sb; P.tile_rows = r.tile_rows; P.tile_cols = r.tile_cols;
-  P.b8_rows = p.height / 8; P.b8_cols = p.width / 8;
+  P.b8_rows = r.ch / 8; P.b8_cols = r.cw / 8;
   P.n_frames = (int)n_frames;
   P.base_q_idx = r.qidx;
   P.qctx = r.qidx <= 20 ? 0 : (r.qidx <= 60 ? 1 : (r.qidx <= 120 ? 2 : 3));
@@ -493,9 +500,9 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.cdef_y_pri = p.cdef_y_pri; P.cdef_y_sec = p.cdef_y_sec; P.cdef_uv_pri = p.cdef_uv_pri; P.cdef_uv_sec = p.cdef_uv_sec;
   P.cdef_damping = p.cdef_damping;
   P.disable_cdf_update = p.cdf_update ? 0 : 1;
-  P.stride_y = p.width; P.stride_c = p.width / 2;
-  P.plane_off_u = (long)p.width * p.height;
-  P.plane_off_v = P.plane_off_u + (long)(p.width / 2) * (p.height / 2);
+  P.stride_y = r.cw; P.stride_c = r.cw / 2;
+  P.plane_off_u = (long)r.cw * r.ch;
+  P.plane_off_v = P.plane_off_u + (long)(r.cw / 2) * (r.ch / 2);
   P.frame_samples = (long)frame_samples;
   P.tile_slot_bytes = slot;
   P.stream_cap = stream_cap;
@@ -604,7 +611,8 @@ int av1mi_scene_cuts(av1mi_ctx *c, const av1mi_params *params, const void *frame
   const size_t frame_bytes = (size_t)r.p.width * r.p.height * 3 / 2 * bps;
   Av1miDevParams P;
   memset(&P, 0, sizeof(P));
-  P.width = r.p.width; P.height = r.p.height; P.bit_depth = r.p.bit_depth; P.n_frames = (int)n_frames;
+  P.width = r.p.width; P.height = r.p.height; P.bit_depth = r.p.bit_depth; P.n_frames = (int)n_frames;  // tight input layout
+  P.true_w = P.width; P.true_h = P.height;
   P.frame_samples = (long)(frame_bytes / bps);
   hipStream_t s = c->stream;
   // host input: stage [prev | frames] contiguously on the device (frame_bytes is a multiple of 32)
@@ -665,7 +673,9 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   if (rc) return rc;
   Av1miDevParams &P = c->P;
   const int bps = P.bit_depth > 8 ? 2 : 1;
-  const size_t chunk_bytes = (size_t)n_frames * P.frame_samples * bps;
+  const bool padded = r.cw != (int)r.p.width || r.ch != (int)r.p.height;
+  const size_t chunk_bytes = (size_t)n_frames * P.frame_samples * bps;                       // coded layout
+  const size_t user_bytes = (size_t)n_frames * r.p.width * r.p.height * 3 / 2 * bps;         // the caller's tight layout
   hipStream_t s = c->stream;
   // headers + CDFs
   // header blob: sequence header OBU, then one fixed-size slot per frame with that frame's header (key and inter
@@ -690,8 +700,19 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   HIPCHK(c, hipMemsetAsync(c->d_sse, 0, (size_t)n_frames * 24, s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   const void *d_src = frames;
-  if (!frames_on_device) {
-    HIPCHK(c, hipMemcpyAsync(c->d_src, frames, chunk_bytes, hipMemcpyHostToDevice, s));
+  if (!padded) {
+    if (!frames_on_device) {
+      HIPCHK(c, hipMemcpyAsync(c->d_src, frames, chunk_bytes, hipMemcpyHostToDevice, s));
+      d_src = c->d_src;
+    }
+  } else {
+    // not a multiple of 8: edge-extend every frame to the coded size (the signalled size stays exact)
+    const void *tight = frames;
+    if (!frames_on_device) {
+      HIPCHK(c, hipMemcpyAsync(c->d_stage, frames, user_bytes, hipMemcpyHostToDevice, s));
+      tight = c->d_stage;
+    }
+    HIPCHK(c, av1mi_launch_pad(tight, c->d_src, (int)r.p.width, (int)r.p.height, r.cw, r.ch, P.bit_depth, (int)n_frames, 0, s));
     d_src = c->d_src;
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -742,7 +763,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       }
       HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, s));
       if (lr) {
-        const int upf = ((P.height + 32) / 64 > 0 ? (P.height + 32) / 64 : 1) * ((P.width + 32) / 64 > 0 ? (P.width + 32) / 64 : 1);
+        const int upf = ((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
         HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, s));
       }
     }
@@ -790,7 +811,12 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   hipError_t e1 = hipMemcpyAsync(dst, c->d_out, total, hipMemcpyDeviceToHost, s);
   hipError_t e2 = hipEventRecord(c->ev[6], s);
   if (e1 == hipSuccess && e2 == hipSuccess && recon) {
-    e1 = hipMemcpyAsync(recon, c->d_fin, chunk_bytes, frames_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s);
+    const void *fin = c->d_fin;
+    if (padded) {  // crop to the signalled size, in the caller's tight layout
+      e1 = av1mi_launch_pad(c->d_fin, c->d_stage, (int)r.p.width, (int)r.p.height, r.cw, r.ch, P.bit_depth, (int)n_frames, 1, s);
+      fin = c->d_stage;
+    }
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(recon, fin, padded ? user_bytes : chunk_bytes, frames_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s);
   }
   std::vector<unsigned long long> sse(n_frames * 3);
   std::vector<uint32_t> syms;

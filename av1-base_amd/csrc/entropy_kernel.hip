@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     // read_lr (§5.11.57): the luma restoration unit whose origin lies in this superblock (units = 64x64, offset by 8
     // rows, so unit (r, c) starts in superblock (r, c)); its coefficients are coded against RefLrWiener, which starts
     // every tile at Wiener_Taps_Mid and follows the units coded with a filter
-    const int urows = imax((P.height + 32) / 64, 1), ucols = imax((P.width + 32) / 64, 1);
+    const int urows = imax((P.true_h + 32) / 64, 1), ucols = imax((P.true_w + 32) / 64, 1);  // from the signalled size
     if (sbr < urows && sbc < ucols) {
       const int ch = uni(lr_choice[(size_t)f * urows * ucols + sbr * ucols + sbc]);
       sym_wide(y, lane, adapt, ch != 0, CL::USE_WIENER, 2);

@@ -26,7 +26,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 template <typename PIX>
 __device__ __forceinline__ void wiener_h(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int x, int ya, int yb, int s0, int s1,
                                          const int *f, bool active, int lane) {
-  const int W = P.width, H = P.height, bd = P.bit_depth;
+  const int W = P.true_w, H = P.true_h, bd = P.bit_depth;  // PlaneEndX + 1, PlaneEndY + 1 (§7.17.6): the signalled size
   const int offset = 1 << (bd + 7 - 3 - 1), limit = (1 << (bd + 1 + 7 - 3)) - 1;
   for (int r = ya - 3; r < yb + 3; r++) {
     int yy = clampi(r, 0, H - 1);
@@ -61,14 +61,16 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 template <typename PIX>
 __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX *__restrict__ pre, const PIX *__restrict__ cdef,
                                                     const PIX *__restrict__ src, PIX *__restrict__ out, uint8_t *__restrict__ choice) {
-  const int urows = (P.height + 32) / 64 > 0 ? (P.height + 32) / 64 : 1, ucols = (P.width + 32) / 64 > 0 ? (P.width + 32) / 64 : 1;
+  // units and stripes follow the signalled size; the last unit of a row/column also carries the padding up to the coded
+  // size (copied, never filtered), so the whole frame buffer is defined
+  const int urows = (P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1, ucols = (P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1;
   const int per_frame = urows * ucols;
   const int f = blockIdx.x / per_frame, u = blockIdx.x % per_frame, ur = u / ucols, uc = u % ucols;
   const int lane = threadIdx.x;
   const size_t fo = (size_t)f * P.frame_samples;
   pre += fo; cdef += fo; src += fo; out += fo;
-  const int y0 = ur ? ur * 64 - 8 : 0, y1 = ur == urows - 1 ? P.height : ur * 64 + 56;
-  const int x0 = uc * 64, x1 = uc == ucols - 1 ? P.width : x0 + 64;
+  const int y0 = ur ? ur * 64 - 8 : 0, y1 = ur == urows - 1 ? P.true_h : ur * 64 + 56;
+  const int x0 = uc * 64, x1 = uc == ucols - 1 ? P.true_w : x0 + 64;
   const int maxv = (1 << P.bit_depth) - 1;
   // ---- SSE without restoration and with each candidate
   unsigned long long sse[4] = { 0, 0, 0, 0 };
@@ -127,7 +129,12 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
     }
   }
   {
-    const int cy0 = y0 >> 1, cy1 = y1 >> 1, cx0 = x0 >> 1, cx1 = x1 >> 1;
+    // padding between the signalled and the coded size (< 8 samples): copied with the last unit of the row / column
+    const int py1 = ur == urows - 1 ? P.height : y1, px1 = uc == ucols - 1 ? P.width : x1;
+    for (int y = y0; y < py1; y++)
+      for (int x = x0 + lane; x < px1; x += 64)
+        if (y >= y1 || x >= x1) out[(size_t)y * P.stride_y + x] = cdef[(size_t)y * P.stride_y + x];
+    const int cy0 = y0 >> 1, cy1 = py1 >> 1, cx0 = x0 >> 1, cx1 = px1 >> 1;
     for (int pl = 0; pl < 2; pl++) {
       const size_t po = pl ? P.plane_off_v : P.plane_off_u;
       for (int y = cy0; y < cy1; y++)
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
 
 extern "C" hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice,
                                       hipStream_t stream) {
-  const int urows = (P->height + 32) / 64 > 0 ? (P->height + 32) / 64 : 1, ucols = (P->width + 32) / 64 > 0 ? (P->width + 32) / 64 : 1;
+  const int urows = (P->true_h + 32) / 64 > 0 ? (P->true_h + 32) / 64 : 1, ucols = (P->true_w + 32) / 64 > 0 ? (P->true_w + 32) / 64 : 1;
   const int grid = P->n_frames * urows * ucols;
   if (P->bit_depth == 8)
     hipLaunchKernelGGL(lr_unit_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice);

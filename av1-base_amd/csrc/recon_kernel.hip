@@ -351,7 +351,8 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
       if (INTER && final_trip && ii.is_inter) {
         const int ss = plane0 > 0;
         const PIX *rp = static_cast<const PIX *>(ii.ref) + poff;
-        pv = mc_sample<PIX>(rp, gs, (ss ? P->width >> 1 : P->width) - 1, (ss ? P->height >> 1 : P->height) - 1,
+        // lastX / lastY of §7.11.3.3: the reference is clamped to the SIGNALLED frame size
+        pv = mc_sample<PIX>(rp, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
                             ((gx + c) << 4) + ((2 * ii.mv_col) >> ss), ((gy + r) << 4) + ((2 * ii.mv_row) >> ss), (1 << bd) - 1);
       } else {
         pv = pred_pixel<LOG2N>(mode, r, c, dcv, ang, dx, dy, eo);

@@ -35,15 +35,71 @@ __global__ void __launch_bounds__(256) luma_sad_kernel(const uint8_t *__restrict
   const uint8_t *cur = frames + (size_t)t * frame_bytes;
   const uint8_t *prv = t ? cur - frame_bytes : prev0;
   if (!prv) return;
-  const size_t nvec = luma_bytes >> 4;  // luma_bytes is a multiple of 64 (width, height multiples of 8)
-  const uint4 *c4 = reinterpret_cast<const uint4 *>(cur), *p4 = reinterpret_cast<const uint4 *>(prv);
   unsigned long long acc = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) acc += sad16<BPS>(c4[i], p4[i]);
+  if (((frame_bytes | luma_bytes) & 15) == 0) {  // sizes that are multiples of 8 both ways: 16-byte loads
+    const size_t nvec = luma_bytes >> 4;
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(cur), *p4 = reinterpret_cast<const uint4 *>(prv);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) acc += sad16<BPS>(c4[i], p4[i]);
+  } else {                                       // any other (even) size: sample by sample
+    const size_t ns = luma_bytes / BPS;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < ns; i += (size_t)gridDim.x * 256) {
+      const int a = BPS == 1 ? (int)cur[i] : (int)reinterpret_cast<const uint16_t *>(cur)[i];
+      const int b = BPS == 1 ? (int)prv[i] : (int)reinterpret_cast<const uint16_t *>(prv)[i];
+      acc += (unsigned long long)(a < b ? b - a : a - b);
+    }
+  }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&sad[t], acc);
 }
 
+// ---- frame sizes that are not multiples of 8: the encoder works on frames edge-extended to the next multiple of 8.
+// pad: tight planar I420 frames of w x h -> frames of cw x ch, last column / row replicated; crop: the reverse.
+template <typename PIX>
+__global__ void __launch_bounds__(256) pad_frames_kernel(const PIX *__restrict__ in, PIX *__restrict__ out, int w, int h, int cw, int ch) {
+  const size_t in_frame = (size_t)w * h * 3 / 2, out_frame = (size_t)cw * ch * 3 / 2;
+  const PIX *fi = in + (size_t)blockIdx.y * in_frame;
+  PIX *fo = out + (size_t)blockIdx.y * out_frame;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < out_frame; i += (size_t)gridDim.x * 256) {
+    const size_t ny = (size_t)cw * ch, nc = ny >> 2;
+    const int pl = i < ny ? 0 : (i < ny + nc ? 1 : 2);
+    const size_t o = i - (pl == 0 ? 0 : (pl == 1 ? ny : ny + nc));
+    const int pcw = pl ? cw >> 1 : cw, pw = pl ? w >> 1 : w, ph = pl ? h >> 1 : h;
+    int y = (int)(o / pcw), x = (int)(o % pcw);
+    y = y < ph ? y : ph - 1; x = x < pw ? x : pw - 1;
+    const size_t ioff = pl == 0 ? 0 : (pl == 1 ? (size_t)w * h : (size_t)w * h + (size_t)(w >> 1) * (h >> 1));
+    fo[i] = fi[ioff + (size_t)y * pw + x];
+  }
+}
+template <typename PIX>
+__global__ void __launch_bounds__(256) crop_frames_kernel(const PIX *__restrict__ in, PIX *__restrict__ out, int w, int h, int cw, int ch) {
+  const size_t in_frame = (size_t)cw * ch * 3 / 2, out_frame = (size_t)w * h * 3 / 2;
+  const PIX *fi = in + (size_t)blockIdx.y * in_frame;
+  PIX *fo = out + (size_t)blockIdx.y * out_frame;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < out_frame; i += (size_t)gridDim.x * 256) {
+    const size_t ny = (size_t)w * h, nc = ny >> 2;
+    const int pl = i < ny ? 0 : (i < ny + nc ? 1 : 2);
+    const size_t o = i - (pl == 0 ? 0 : (pl == 1 ? ny : ny + nc));
+    const int pw = pl ? w >> 1 : w, pcw = pl ? cw >> 1 : cw;
+    const int y = (int)(o / pw), x = (int)(o % pw);
+    const size_t ioff = pl == 0 ? 0 : (pl == 1 ? (size_t)cw * ch : (size_t)cw * ch + (size_t)(cw >> 1) * (ch >> 1));
+    fo[i] = fi[ioff + (size_t)y * pcw + x];
+  }
+}
+
 }  // namespace
+
+extern "C" hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop,
+                                       hipStream_t stream) {
+  dim3 grid(256, n_frames);
+  if (bit_depth == 8) {
+    if (crop) hipLaunchKernelGGL(crop_frames_kernel<uint8_t>, grid, dim3(256), 0, stream, (const uint8_t *)in, (uint8_t *)out, w, h, cw, ch);
+    else hipLaunchKernelGGL(pad_frames_kernel<uint8_t>, grid, dim3(256), 0, stream, (const uint8_t *)in, (uint8_t *)out, w, h, cw, ch);
+  } else {
+    if (crop) hipLaunchKernelGGL(crop_frames_kernel<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t *)in, (uint16_t *)out, w, h, cw, ch);
+    else hipLaunchKernelGGL(pad_frames_kernel<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t *)in, (uint16_t *)out, w, h, cw, ch);
+  }
+  return hipGetLastError();
+}
 
 // `frames`/`prev0` must be 16-byte aligned device pointers (checked by the caller); sad[] zeroed by the caller.
 extern "C" hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad,

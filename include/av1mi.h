@@ -40,7 +40,8 @@ typedef struct av1mi_ctx av1mi_ctx;
  *   SVT_PARAMS = "--crf 8 --preset 3 --film-grain 20 ... --keyint 240 --lookahead 40"
  * (crates/daemon/src/encode/av1an.rs:14) and `--pix-format yuv420p10le` (av1an.rs:90). */
 typedef struct {
-  uint32_t width, height;   /* luma size, multiples of 8, yuv 4:2:0 */
+  uint32_t width, height;   /* luma size, even, >= 8, yuv 4:2:0.  Sizes that are not multiples of 8 are coded at the next
+                               multiple of 8 (source edge-extended on the device) and signalled exactly, as any AV1 encoder does */
   uint32_t bit_depth;       /* 8 or 10 (samples: uint8_t / little-endian uint16_t) */
   uint32_t cq_level;        /* "--crf N": 0..63, mapped to base_q_idx like aom (30 -> 120) */
   uint32_t keyint;          /* "--keyint": 1 = every frame a key frame; N > 1 = a key frame every N frames of a chunk, the

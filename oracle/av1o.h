@@ -39,7 +39,8 @@ enum { TX_4X4, TX_8X8, TX_16X16, TX_32X32, TX_64X64 };
 
 /* ---- encoder configuration ------------------------------------------------------------- */
 typedef struct {
-  int width, height;      /* luma; multiples of 8 */
+  int width, height;      /* luma; even, >= 8.  Sizes that are not multiples of 8 are coded at the next multiple of 8
+                             (the source is extended by replicating its last column/row) and signalled exactly */
   int bit_depth;          /* 8 or 10 */
   int base_q_idx;         /* CQ 30 <-> 120 */
   int tile_w_sb, tile_h_sb; /* tile size in 64x64 superblocks */
@@ -55,6 +56,7 @@ typedef struct {
   int fg_y_scaling, fg_c_scaling; /* 0..255 scaling value of both points */
   int fg_seed;            /* grain_seed of this frame (16 bits) */
   int enable_lr;          /* 1: loop restoration on luma: Wiener, 64x64 units, per-unit choice among {off, 3 filters} */
+  int true_width, true_height; /* internal: set by the encoder when it runs at the padded size (0 = same as width/height) */
   int me_range;           /* inter frames: integer-pel full search, |dx|,|dy| <= me_range (default 8) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */

@@ -121,6 +121,11 @@ void av1o_frame_free(Av1oFrame *f) {
   free(f);
 }
 
+/* frame size as signalled (and as the decoder crops / clamps references / restores): the true size when the encoder
+ * runs on a source padded to multiples of 8 */
+static int true_w(const Av1oConfig *cfg) { return cfg->true_width ? cfg->true_width : cfg->width; }
+static int true_h(const Av1oConfig *cfg) { return cfg->true_height ? cfg->true_height : cfg->height; }
+
 /* ------------------------------------------------------------------ sequence header §5.5 */
 static void write_color_config(BitW *b, const Av1oConfig *cfg) {
   bw_put(b, cfg->bit_depth > 8, 1); /* high_bitdepth (profile 0: no twelve_bit) */
@@ -133,7 +138,7 @@ static void write_color_config(BitW *b, const Av1oConfig *cfg) {
 
 static size_t seq_header_payload(const Av1oConfig *cfg, uint8_t *buf, size_t cap) {
   BitW b = { buf, cap, 0 };
-  int wbits = floor_log2((unsigned)(cfg->width - 1) | 1) + 1, hbits = floor_log2((unsigned)(cfg->height - 1) | 1) + 1;
+  int wbits = floor_log2((unsigned)(true_w(cfg) - 1) | 1) + 1, hbits = floor_log2((unsigned)(true_h(cfg) - 1) | 1) + 1;
   bw_put(&b, 0, 3);                   /* seq_profile */
   bw_put(&b, cfg->still_picture, 1);  /* still_picture */
   bw_put(&b, cfg->still_picture, 1);  /* reduced_still_picture_header */
@@ -149,8 +154,8 @@ static size_t seq_header_payload(const Av1oConfig *cfg, uint8_t *buf, size_t cap
   }
   bw_put(&b, (uint32_t)(wbits - 1), 4);
   bw_put(&b, (uint32_t)(hbits - 1), 4);
-  bw_put(&b, (uint32_t)(cfg->width - 1), wbits);
-  bw_put(&b, (uint32_t)(cfg->height - 1), hbits);
+  bw_put(&b, (uint32_t)(true_w(cfg) - 1), wbits);
+  bw_put(&b, (uint32_t)(true_h(cfg) - 1), hbits);
   if (!cfg->still_picture) bw_put(&b, 0, 1); /* frame_id_numbers_present_flag */
   bw_put(&b, 0, 1); /* use_128x128_superblock */
   bw_put(&b, 0, 1); /* enable_filter_intra */
@@ -797,7 +802,8 @@ typedef struct { int row, col; } Mv; /* 1/8 luma samples */
 static void predict_inter(const Enc *e, int plane, int x0, int y0, int n, Mv mv, uint16_t *dst, int dstride) {
   const Av1oFrame *ref = e->ref;
   const int ss = plane > 0;
-  const int last_x = (ss ? e->cfg->width / 2 : e->cfg->width) - 1, last_y = (ss ? e->cfg->height / 2 : e->cfg->height) - 1;
+  /* lastX / lastY of §7.11.3.3: the reference is clamped to the SIGNALLED frame size */
+  const int last_x = ((true_w(e->cfg) + ss) >> ss) - 1, last_y = ((true_h(e->cfg) + ss) >> ss) - 1;
   const int mvq_r = (2 * mv.row) >> ss, mvq_c = (2 * mv.col) >> ss;
   const int py = (y0 << 4) + mvq_r, px = (x0 << 4) + mvq_c;
   const int iy = py >> 4, fy = py & 15, ix = px >> 4, fx = px & 15;
@@ -1322,7 +1328,7 @@ static void write_signed_subexp_ref(Enc *e, int low, int high, int k, int r, int
 /* read_lr (§5.11.57) for the 64x64 superblock at (mi_r, mi_c): luma units whose origin lies in it */
 static void write_lr(Enc *e, int mi_r, int mi_c) {
   static const int tmin[3] = { -5, -23, -17 }, tmax[3] = { 10, 8, 46 }, tk[3] = { 1, 2, 3 };
-  const int urows = av1o_lr_units(e->cfg->height), ucols = av1o_lr_units(e->cfg->width);
+  const int urows = av1o_lr_units(true_h(e->cfg)), ucols = av1o_lr_units(true_w(e->cfg));
   int r0 = (mi_r * 4 + 63) / 64, r1 = ((mi_r + 16) * 4 + 63) / 64, c0 = (mi_c * 4 + 63) / 64, c1 = ((mi_c + 16) * 4 + 63) / 64, ur, uc, pass, j;
   if (!e->cfg->enable_lr || !e->lr_units) return;
   if (r1 > urows) r1 = urows;
@@ -1446,8 +1452,42 @@ long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq
   return av1o_encode_frame2(cfg, src, NULL, NULL, with_seq_hdr, out, out_cap, recon, stats);
 }
 
+/* copy `in` (iw x ih luma) into a new frame of ow x oh, replicating the last column / row */
+static Av1oFrame *pad_frame(const Av1oFrame *in, int iw, int ih, int ow, int oh) {
+  Av1oFrame *o = av1o_frame_alloc(ow, oh);
+  int p, x, y;
+  for (p = 0; p < 3; p++) {
+    int ss = p > 0, piw = iw >> ss, pih = ih >> ss, pow_ = ow >> ss, poh = oh >> ss;
+    for (y = 0; y < poh; y++)
+      for (x = 0; x < pow_; x++)
+        o->p[p][(size_t)y * o->stride[p] + x] = in->p[p][(size_t)(y < pih ? y : pih - 1) * in->stride[p] + (x < piw ? x : piw - 1)];
+  }
+  return o;
+}
+
 long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, const Av1oFrame *prev_src, int with_seq_hdr,
                         uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats) {
+  if (!cfg->true_width && ((cfg->width & 7) || (cfg->height & 7))) {
+    /* not a multiple of 8: run at the padded size, signal the true one; frames at this interface keep the true size */
+    const int w = cfg->width, h = cfg->height, cw = (w + 7) & ~7, ch = (h + 7) & ~7;
+    Av1oConfig c2 = *cfg;
+    Av1oFrame *s2, *r2 = NULL, *p2 = NULL, *o2 = NULL;
+    long n;
+    int p, y;
+    if ((w & 1) || (h & 1) || w < 8 || h < 8) return -2;
+    c2.width = cw; c2.height = ch; c2.true_width = w; c2.true_height = h;
+    s2 = pad_frame(src, w, h, cw, ch);
+    if (ref) r2 = pad_frame(ref, w, h, cw, ch);
+    if (prev_src) p2 = pad_frame(prev_src, w, h, cw, ch);
+    if (recon) o2 = av1o_frame_alloc(cw, ch);
+    n = av1o_encode_frame2(&c2, s2, r2, p2, with_seq_hdr, out, out_cap, o2, stats);
+    if (recon && n >= 0)
+      for (p = 0; p < 3; p++)
+        for (y = 0; y < (h >> (p > 0)); y++)
+          memcpy(recon->p[p] + (size_t)y * recon->stride[p], o2->p[p] + (size_t)y * o2->stride[p], sizeof(uint16_t) * (size_t)(w >> (p > 0)));
+    av1o_frame_free(s2); av1o_frame_free(r2); av1o_frame_free(p2); av1o_frame_free(o2);
+    return n;
+  }
   Geom g;
   Enc *e;
   Av1oLrUnit *lr_units = NULL;
@@ -1509,7 +1549,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
       for (tc = 0; tc < g.tile_cols; tc++)
         if (encode_tile(e, tr, tc, tilebuf, payload_cap) == (size_t)-1) { av1o_frame_free(cd); goto done; }
     av1o_cdef_frame(cfg, e->rec, cd, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
-    lr_units = (Av1oLrUnit *)calloc((size_t)av1o_lr_units(cfg->width) * av1o_lr_units(cfg->height), sizeof(Av1oLrUnit));
+    lr_units = (Av1oLrUnit *)calloc((size_t)av1o_lr_units(true_w(cfg)) * av1o_lr_units(true_h(cfg)), sizeof(Av1oLrUnit));
     lr_out = av1o_frame_alloc(cfg->width, cfg->height);
     av1o_lr_frame(cfg, e->rec, cd, src, lr_out, lr_units, cfg->fuzz_modes ? (unsigned)cfg->fuzz_modes + 77u : 0u);
     av1o_frame_free(cd);

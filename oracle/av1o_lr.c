@@ -16,8 +16,8 @@ int av1o_lr_units(int size) { /* count_units_in_frame(64, size) */
 }
 
 /* one sample of the Wiener-filtered luma plane.  cdef = UpscaledCdefFrame, pre = UpscaledCurrFrame (pre-CDEF). */
-static int wiener_sample(const Av1oFrame *cdef, const Av1oFrame *pre, int bd, int x, int y, const int *vf, const int *hf) {
-  const int W = cdef->w, H = cdef->h;
+static int wiener_sample(const Av1oFrame *cdef, const Av1oFrame *pre, int W, int H, int bd, int x, int y, const int *vf, const int *hf) {
+  /* W, H: the signalled frame size (PlaneEndX + 1, PlaneEndY + 1 of §7.17.6) */
   const int stripe = (y + 8) / 64, s0 = -8 + stripe * 64, s1 = s0 + 63;
   const int round0 = 3, round1 = 11;
   const int offset = 1 << (bd + 7 - round0 - 1), limit = (1 << (bd + 1 + 7 - round0)) - 1;
@@ -50,13 +50,15 @@ static void taps_of(const int8_t *c, int *f) {
  * coef[pass][3] (pass 0 vertical, 1 horizontal).  `fuzz` != 0: pseudo-random types and coefficients (dav1d fuzzing). */
 void av1o_lr_frame(const Av1oConfig *cfg, const Av1oFrame *pre, const Av1oFrame *cdef, const Av1oFrame *src, Av1oFrame *out,
                    Av1oLrUnit *units, unsigned fuzz) {
-  const int W = cfg->width, H = cfg->height, bd = cfg->bit_depth;
+  /* units, stripes and sample clamps follow the SIGNALLED frame size; the frames themselves hold the padded size */
+  const int W = cfg->true_width ? cfg->true_width : cfg->width, H = cfg->true_height ? cfg->true_height : cfg->height, bd = cfg->bit_depth;
+  const int CW = cfg->width, CH = cfg->height;
   const int urows = av1o_lr_units(H), ucols = av1o_lr_units(W);
   static const int8_t tmin[3] = { -5, -23, -17 }, tmax[3] = { 10, 8, 46 };
   int ur, uc, p, x, y, k;
   unsigned rng = fuzz * 2654435761u + 12345u;
-  for (p = 1; p < 3; p++) /* chroma: FrameRestorationType = NONE */
-    for (y = 0; y < H / 2; y++) memcpy(out->p[p] + (size_t)y * out->stride[p], cdef->p[p] + (size_t)y * cdef->stride[p], sizeof(uint16_t) * (size_t)(W / 2));
+  for (p = 0; p < 3; p++) /* chroma: FrameRestorationType = NONE; luma: overwritten inside the signalled area below */
+    for (y = 0; y < (CH >> (p > 0)); y++) memcpy(out->p[p] + (size_t)y * out->stride[p], cdef->p[p] + (size_t)y * cdef->stride[p], sizeof(uint16_t) * (size_t)(CW >> (p > 0)));
   for (ur = 0; ur < urows; ur++)
     for (uc = 0; uc < ucols; uc++) {
       /* unit rows are offset by 8 luma rows (§7.17.3): rows [64*ur - 8, 64*ur + 56), the last unit to the frame end */
@@ -85,7 +87,7 @@ void av1o_lr_frame(const Av1oConfig *cfg, const Av1oFrame *pre, const Av1oFrame 
           taps_of(av1o_wiener_candidates[k], vf);
           for (y = y0; y < y1; y++)
             for (x = x0; x < x1; x++) {
-              int d = wiener_sample(cdef, pre, bd, x, y, vf, vf) - (int)src->p[0][(size_t)y * src->stride[0] + x];
+              int d = wiener_sample(cdef, pre, W, H, bd, x, y, vf, vf) - (int)src->p[0][(size_t)y * src->stride[0] + x];
               sse += (uint64_t)(d * d);
             }
           if (sse < best_sse) { best_sse = sse; u->type = 1; memcpy(u->coef[0], av1o_wiener_candidates[k], 3); memcpy(u->coef[1], av1o_wiener_candidates[k], 3); }
@@ -94,7 +96,7 @@ void av1o_lr_frame(const Av1oConfig *cfg, const Av1oFrame *pre, const Av1oFrame 
       if (u->type) { taps_of(u->coef[0], vf); taps_of(u->coef[1], hf); }
       for (y = y0; y < y1; y++)
         for (x = x0; x < x1; x++)
-          out->p[0][(size_t)y * out->stride[0] + x] = u->type ? (uint16_t)wiener_sample(cdef, pre, bd, x, y, vf, hf)
+          out->p[0][(size_t)y * out->stride[0] + x] = u->type ? (uint16_t)wiener_sample(cdef, pre, W, H, bd, x, y, vf, hf)
                                                               : cdef->p[0][(size_t)y * cdef->stride[0] + x];
     }
 }

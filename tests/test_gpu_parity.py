@@ -445,12 +445,12 @@ def test_8k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):
 
 def test_encode_file_ragged_and_empty_inputs(av1mi, oracle, tmp_path):
     """Edge cases at the file boundary: a Y4M with a header but no frames, a truncated last frame, a frame size that
-    is not a multiple of 8 - each a clean encoder failure (-> EncodeError::Av1anFailed in the reference's taxonomy),
+    is odd - each a clean encoder failure (-> EncodeError::Av1anFailed in the reference's taxonomy),
     no output file and no temporary file left behind; a one-frame clip encodes."""
     w, h = 72, 56
     fr = raw_of(oracle.synthclip_frame(w, h, 8, seed=81, t=0), 8)
     hdr = b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h)
-    cases = {"empty": hdr, "truncated": hdr + b"FRAME\n" + fr + b"FRAME\n" + fr[:100], "odd_size": b"YUV4MPEG2 W70 H56 F30:1 C420jpeg\nFRAME\n" + bytes(70 * 56 * 3 // 2)}
+    cases = {"empty": hdr, "truncated": hdr + b"FRAME\n" + fr + b"FRAME\n" + fr[:100], "odd_size": b"YUV4MPEG2 W71 H56 F30:1 C420jpeg\nFRAME\n" + bytes(71 * 56 + 2 * 36 * 28)}
     for name, blob in cases.items():
         src = tmp_path / (name + ".y4m")
         src.write_bytes(blob)
@@ -506,3 +506,21 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
         fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
         for i, rec in enumerate(recs):
             assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), (desc, i)
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint,lr,tsb", [(70, 58, 8, 1, 5, 1, 0, 1), (202, 122, 10, 3, 5, 240, 0, 1), (130, 66, 8, 3, 4, 2, 1, 1),
+                                                      (90, 100, 8, 3, 3, 240, 0, 1), (134, 70, 10, 2, 5, 2, 1, 2), (1366, 768 - 2, 8, 2, 5, 2, 0, 1)])
+def test_sizes_that_are_not_multiples_of_8(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, lr, tsb):
+    """Any even frame size: coded at the next multiple of 8 (source edge-extended on the device), signalled exactly;
+    references are clamped and restoration runs within the signalled size.  Frames in and reconstruction out use the
+    caller's tight w x h layout.  Bit-exact against the oracle (pinned by dav1d for such sizes: tests/golden/*odd*)."""
+    big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=1200 + w, t=t) for t in range(n)]
+    frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, enable_lr=lr, tile_sb=tsb)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert data == b"".join(tus)
+    fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+    for i, rec in enumerate(recs):
+        assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i

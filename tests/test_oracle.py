@@ -299,8 +299,10 @@ def test_properties_linearity_of_sse_and_determinism(oracle):
 
 
 def test_rejects_bad_geometry(oracle):
-    with pytest.raises(RuntimeError):
-        oracle.encode_frame(oracle.default_config(60, 64, 8), [np.zeros((64, 60), np.uint16), np.zeros((32, 30), np.uint16), np.zeros((32, 30), np.uint16)])
+    with pytest.raises(RuntimeError):   # odd width: 4:2:0 planes need even sizes (multiples of 8 are not required)
+        oracle.encode_frame(oracle.default_config(61, 64, 8), [np.zeros((64, 61), np.uint16), np.zeros((32, 30), np.uint16), np.zeros((32, 30), np.uint16)])
+    tu, rec, _ = oracle.encode_frame(oracle.default_config(60, 66, 8), [np.full((66, 60), 90, np.uint16), np.full((33, 30), 128, np.uint16), np.full((33, 30), 128, np.uint16)])
+    assert rec[0].shape == (66, 60) and rec[1].shape == (33, 30) and int(np.abs(rec[0].astype(int) - 90).max()) <= 2
 
 
 def test_synthclip_scene_cut_and_motion(oracle):

@@ -55,6 +55,9 @@ CASES = [
     ("k328x248_lr_10b", 328, 248, 10, 7, 1, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
     ("fuzz_lr", 200, 120, 8, 31, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1, fuzz_modes=3)),
     ("fuzz_lr_10b_onetile", 264, 200, 10, 32, 0, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=1, fuzz_modes=5, tile_w_sb=64, tile_h_sb=64)),
+    # frame sizes that are not multiples of 8 (coded at the padded size, signalled exactly)
+    ("k70x58_odd", 70, 58, 8, 41, 0, dict(min_bs_log2=5, max_bs_log2=5)),
+    ("k202x122_odd_lr_10b", 202, 122, 10, 42, 1, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -80,6 +83,8 @@ SEQ_CASES = [
                                                         fg_c_scaling=0, fg_seed=99)),
     ("p200x120_lr", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=1)),
     ("pfuzz_lr_10b", 200, 120, 10, 26, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1, fuzz_modes=12)),
+    ("p130x66_odd_lr", 130, 66, 8, 43, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
+    ("pfuzz_90x100_odd_me16", 90, 100, 8, 44, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=5, me_range=16)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
