@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--keyint", type=int, default=1, help="1 = all key frames (the headline config); N > 1 = IPPP, key frame every N frames")
     ap.add_argument("--me-range", type=int, default=8)
+    ap.add_argument("--chunks-per-gpu", type=int, default=1,
+                    help="independent full chunks encoded concurrently on their own contexts per GPU (the reference's `--workers`); "
+                         "a step then processes chunks-per-gpu x frames frames")
     ap.add_argument("--chunks-in-flight", type=int, default=1,
                     help="split the chunk's frames into this many pseudo-chunks encoded concurrently on their own contexts "
                          "(the reference's `--workers`); all-key-frame only")
@@ -167,10 +170,13 @@ def main():
                                   me_range=args.me_range)
     params.intra_mode_mask = args.mode_mask
     C_ = max(1, args.chunks_in_flight) if args.keyint <= 1 else 1
+    W_ = max(1, args.chunks_per_gpu)
+    if W_ > 1:
+        C_ = W_
     ctxs = [av1mi.Context(local_rank) for _ in range(C_)]
     ctx = ctxs[0]
     fbytes = w * h * 3 // 2 * (2 if bd > 8 else 1)
-    parts = [(i * n // C_, (i + 1) * n // C_) for i in range(C_)]
+    parts = [(i * n // C_, (i + 1) * n // C_) for i in range(C_)] if W_ == 1 else [(0, n)] * W_
 
     def step():
         if C_ == 1:
@@ -244,14 +250,14 @@ def main():
         except OSError:
             pass
         out = {
-            "metric": "encoded frames/sec at CQ=30 (1080p intra-only)", "value": round(world * n * k / elapsed, 2), "unit": "frames/s",
+            "metric": "encoded frames/sec at CQ=30 (1080p intra-only)", "value": round(world * W_ * n * k / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(elapsed / k * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": "%dx%d %d-frame %s synthclip v1 chunk per GPU, %d-bit 4:2:0, CQ=30 (base_q_idx 120), "
                                    "%dx%d blocks, 64x64 tiles, %s CDFs, CDEF on" % (
                                        w, h, n, "all-key-frame" if args.keyint <= 1 else "IPPP (keyint %d, 1 reference, +-%d full search)" % (args.keyint, args.me_range),
                                        bd, 1 << args.block_log2, 1 << args.block_log2, "static" if args.static_cdf else "adaptive"),
-                       "frames_per_chunk": n, "chunks_per_gpu": 1, "pseudo_chunks_in_flight": C_,
+                       "frames_per_chunk": n, "chunks_per_gpu": W_, "pseudo_chunks_in_flight": C_ if W_ == 1 else 1,
                        "parallelism": "chunk-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
