@@ -46,7 +46,10 @@ pub fn run_mi355x(params: &Av1anEncodeParams, cq_level: u32) -> Result<(), Encod
     let (i, o, t) = (c(&params.input_path)?, c(&params.output_path)?, c(&params.temp_chunks_dir)?);
     let mut p = Av1miParams::default();
     unsafe { av1mi_default_params(&mut p, 8, 8, 8) };   // geometry comes from the Y4M header
-    p.cq_level = cq_level;                               // the reference's "--crf" (av1an.rs:14)
+    // the reference's operating point, SVT_PARAMS (av1an.rs:14): "--crf 8 ... --film-grain 20 ... --keyint 240"
+    p.cq_level = cq_level;                               // "--crf" (8 in production; 30 is the benchmark's operating point)
+    p.keyint = 240;                                      // "--keyint 240": IPPP inside a chunk, chunks start at scene cuts
+    p.film_grain = 20;                                   // "--film-grain 20": film-grain table in every frame header
     let job = Av1miJob { input_path: i.as_ptr(), output_path: o.as_ptr(), temp_dir: t.as_ptr(),
                          workers: params.concurrency.av1an_workers, chunk_frames: 0 /* scene-cut chunks */, gpu_mask: 0, params: p };
     let mut rep = Av1miReport::default();
