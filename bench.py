@@ -136,17 +136,16 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--keyint", type=int, default=1, help="1 = all key frames (the headline config); N > 1 = IPPP, key frame every N frames")
     ap.add_argument("--me-range", type=int, default=8)
+    ap.add_argument("--cq", type=int, default=30, help="CQ level (the headline metric is quoted at 30; the reference's production string uses 8)")
+    ap.add_argument("--film-grain", type=int, default=0)
     ap.add_argument("--chunks-per-gpu", type=int, default=1,
                     help="independent full chunks encoded concurrently on their own contexts per GPU (the reference's `--workers`); "
                          "a step then processes chunks-per-gpu x frames frames")
-    ap.add_argument("--chunks-in-flight", type=int, default=1,
-                    help="split the chunk's frames into this many pseudo-chunks encoded concurrently on their own contexts "
-                         "(the reference's `--workers`); all-key-frame only")
     ap.add_argument("--bit-depth", type=int, default=10)
     ap.add_argument("--block-log2", type=int, default=5)
     ap.add_argument("--static-cdf", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode-mask", type=int, default=0, help="experiment: intra mode candidate mask (0 = all 13)")
+    ap.add_argument("--mode-mask", type=int, default=0, help="experiment: intra mode candidate mask (0 = default {DC, V, H})")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,16 +166,14 @@ def main():
     d_frames = torch.frombuffer(bytearray(clip), dtype=torch.uint8).to(dev)  # HBM-resident input
     torch.cuda.synchronize(dev)
     params = av1mi.default_params(w, h, bd, block_log2=args.block_log2, cdf_update=0 if args.static_cdf else 1, keyint=args.keyint,
-                                  me_range=args.me_range)
+                                  me_range=args.me_range, cq_level=args.cq, film_grain=args.film_grain)
     params.intra_mode_mask = args.mode_mask
-    C_ = max(1, args.chunks_in_flight) if args.keyint <= 1 else 1
     W_ = max(1, args.chunks_per_gpu)
-    if W_ > 1:
-        C_ = W_
+    C_ = W_
     ctxs = [av1mi.Context(local_rank) for _ in range(C_)]
     ctx = ctxs[0]
     fbytes = w * h * 3 // 2 * (2 if bd > 8 else 1)
-    parts = [(i * n // C_, (i + 1) * n // C_) for i in range(C_)] if W_ == 1 else [(0, n)] * W_
+    parts = [(0, n)] * W_   # every context encodes the whole chunk (its own copy of the work)
 
     def step():
         if C_ == 1:
@@ -243,7 +240,7 @@ def main():
         traffic = traffic_raw = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")))
-            if (w, h, n, bd, args.block_log2, args.static_cdf, args.keyint) == (1920, 1080, 60, 10, 5, False, 1) and dom in pm["kernels"]:
+            if (w, h, n, bd, args.block_log2, args.static_cdf, args.keyint, args.cq) == (1920, 1080, 60, 10, 5, False, 1, 30) and dom in pm["kernels"]:
                 kk = pm["kernels"][dom]
                 traffic_raw = (kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024
                 traffic = (2 * kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024
@@ -253,11 +250,12 @@ def main():
             "metric": "encoded frames/sec at CQ=30 (1080p intra-only)", "value": round(world * W_ * n * k / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(elapsed / k * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-            "config": {"workload": "%dx%d %d-frame %s synthclip v1 chunk per GPU, %d-bit 4:2:0, CQ=30 (base_q_idx 120), "
+            "config": {"workload": "%dx%d %d-frame %s synthclip v1 chunk per GPU, %d-bit 4:2:0, CQ=%d (base_q_idx %d), "
                                    "%dx%d blocks, 64x64 tiles, %s CDFs, CDEF on" % (
                                        w, h, n, "all-key-frame" if args.keyint <= 1 else "IPPP (keyint %d, 1 reference, +-%d full search)" % (args.keyint, args.me_range),
-                                       bd, 1 << args.block_log2, 1 << args.block_log2, "static" if args.static_cdf else "adaptive"),
-                       "frames_per_chunk": n, "chunks_per_gpu": W_, "pseudo_chunks_in_flight": C_ if W_ == 1 else 1,
+                                       bd, args.cq, av1mi.cq_to_qindex(args.cq), 1 << args.block_log2, 1 << args.block_log2,
+                                       "static" if args.static_cdf else "adaptive"),
+                       "frames_per_chunk": n, "chunks_per_gpu": W_,
                        "parallelism": "chunk-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
