@@ -55,6 +55,9 @@ typedef struct {
   int film_grain;         /* 1: film_grain_params_present + apply_grain */
   int fg_y_scaling, fg_c_scaling; /* 0..255 scaling value of both points */
   int fg_seed;            /* grain_seed of this frame (16 bits) */
+  int deblock;            /* 1: deblocking filter on, levels picked from the quantiser; 2: levels given below */
+  int lf_level[4];        /* loop_filter_level[0..3]: luma vertical edges, luma horizontal, U, V (deblock == 2) */
+  int lf_sharpness;
   int enable_lr;          /* 1: loop restoration on luma: Wiener, 64x64 units, per-unit choice among {off, 3 filters} */
   int true_width, true_height; /* internal: set by the encoder when it runs at the padded size (0 = same as width/height) */
   int me_range;           /* inter frames: integer-pel full search, |dx|,|dy| <= me_range (default 8) */
@@ -118,6 +121,11 @@ void av1o_predict_intra(uint16_t *dst, int stride, int log2n, int mode, int angl
 
 void av1o_cdef_frame(const Av1oConfig *cfg, const Av1oFrame *in, Av1oFrame *out,
                      const uint8_t *skip_mi, int mi_stride, const int8_t *cdef_idx_sb);
+
+/* ---- deblocking filter (av1o_deblock.c) */
+void av1o_deblock_levels(const Av1oConfig *cfg, int is_key, int *levels /* [4] */);
+void av1o_deblock_frame(const Av1oConfig *cfg, Av1oFrame *f, const uint8_t *mi_bsl, const uint8_t *mi_skip, const uint8_t *mi_is_inter,
+                        int mi_stride, const int *levels, int sharpness);
 
 /* ---- loop restoration (av1o_lr.c) */
 typedef struct {

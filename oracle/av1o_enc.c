@@ -288,11 +288,16 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, int is_int
   bw_put(&b, 0, 1); /* using_qmatrix */
   bw_put(&b, 0, 1); /* segmentation_enabled */
   if (cfg->base_q_idx > 0) bw_put(&b, 0, 1); /* delta_q_present */
-  /* loop_filter_params(): levels 0 => deblocking off */
-  bw_put(&b, 0, 6);
-  bw_put(&b, 0, 6);
-  bw_put(&b, 0, 3); /* loop_filter_sharpness */
-  bw_put(&b, 0, 1); /* loop_filter_delta_enabled */
+  /* loop_filter_params() §5.9.11: levels 0 = deblocking off */
+  {
+    int lv[4];
+    av1o_deblock_levels(cfg, !is_inter, lv);
+    bw_put(&b, (uint32_t)lv[0], 6);
+    bw_put(&b, (uint32_t)lv[1], 6);
+    if (lv[0] || lv[1]) { bw_put(&b, (uint32_t)lv[2], 6); bw_put(&b, (uint32_t)lv[3], 6); }
+    bw_put(&b, (uint32_t)(cfg->deblock == 2 ? cfg->lf_sharpness : 0), 3); /* loop_filter_sharpness */
+    bw_put(&b, 0, 1); /* loop_filter_delta_enabled */
+  }
   /* cdef_params() */
   if (cfg->enable_cdef) {
     bw_put(&b, (uint32_t)(cfg->cdef_damping - 3), 2);
@@ -1548,6 +1553,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
     for (tr = 0; tr < g.tile_rows; tr++)
       for (tc = 0; tc < g.tile_cols; tc++)
         if (encode_tile(e, tr, tc, tilebuf, payload_cap) == (size_t)-1) { av1o_frame_free(cd); goto done; }
+    { int lv[4]; av1o_deblock_levels(cfg, ref == NULL, lv); av1o_deblock_frame(cfg, e->rec, e->mi_bsl, e->mi_skip, e->mi_is_inter, g.mi_cols, lv, cfg->deblock == 2 ? cfg->lf_sharpness : 0); }
     av1o_cdef_frame(cfg, e->rec, cd, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
     lr_units = (Av1oLrUnit *)calloc((size_t)av1o_lr_units(true_w(cfg)) * av1o_lr_units(true_h(cfg)), sizeof(Av1oLrUnit));
     lr_out = av1o_frame_alloc(cfg->width, cfg->height);
@@ -1599,7 +1605,12 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
         int pw = p ? cfg->width / 2 : cfg->width, ph = p ? cfg->height / 2 : cfg->height, y;
         for (y = 0; y < ph; y++) memcpy(fin->p[p] + (size_t)y * fin->stride[p], lr_out->p[p] + (size_t)y * lr_out->stride[p], sizeof(uint16_t) * (size_t)pw);
       }
-    } else av1o_cdef_frame(cfg, e->rec, fin, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
+    } else {
+      int lv[4];
+      av1o_deblock_levels(cfg, ref == NULL, lv);
+      av1o_deblock_frame(cfg, e->rec, e->mi_bsl, e->mi_skip, e->mi_is_inter, g.mi_cols, lv, cfg->deblock == 2 ? cfg->lf_sharpness : 0);
+      av1o_cdef_frame(cfg, e->rec, fin, e->mi_skip, g.mi_cols, e->cdef_idx_sb);
+    }
     if (stats) {
       for (p = 0; p < 3; p++) {
         int pw = p ? cfg->width / 2 : cfg->width, ph = p ? cfg->height / 2 : cfg->height, x, y;

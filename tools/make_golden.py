@@ -58,6 +58,10 @@ CASES = [
     # frame sizes that are not multiples of 8 (coded at the padded size, signalled exactly)
     ("k70x58_odd", 70, 58, 8, 41, 0, dict(min_bs_log2=5, max_bs_log2=5)),
     ("k202x122_odd_lr_10b", 202, 122, 10, 42, 1, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
+    # deblocking filter: levels picked from q, and explicit levels / sharpness
+    ("k200x120_deblock", 200, 120, 8, 1080, 2, dict(min_bs_log2=5, max_bs_log2=5, deblock=1)),
+    ("k216x88_deblock_lr_10b", 216, 88, 10, 51, 0, dict(min_bs_log2=4, max_bs_log2=4, deblock=1, enable_lr=1)),
+    ("fuzz_deblock_bs3", 136, 72, 8, 52, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=6, deblock=2, lf_level=(63, 40, 17, 5), lf_sharpness=3)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -85,6 +89,8 @@ SEQ_CASES = [
     ("pfuzz_lr_10b", 200, 120, 10, 26, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1, fuzz_modes=12)),
     ("p130x66_odd_lr", 130, 66, 8, 43, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
     ("pfuzz_90x100_odd_me16", 90, 100, 8, 44, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=5, me_range=16)),
+    ("p200x120_deblock", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, deblock=1)),
+    ("pfuzz_deblock_bs6_odd", 130, 134, 10, 53, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=4, deblock=2, lf_level=(30, 30, 30, 30), lf_sharpness=0)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
