@@ -31,6 +31,7 @@ hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frame
                                       int count, hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
 hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop, hipStream_t s);
+hipError_t av1mi_launch_deblock(const Av1miDevParams *P, void *rec, const Av1miBlkInfo *blk, hipStream_t s);
 hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
@@ -109,6 +110,15 @@ int resolve(const av1mi_params *in, Resolved *r) {
   r->tile_rows = (r->sb_rows + r->tile_sb - 1) / r->tile_sb;
   if (r->tile_cols > 64 || r->tile_rows > 64) return AV1MI_E_UNSUPPORTED;
   return AV1MI_OK;
+}
+
+// deblocking level of a frame (the same for all four filters): libaom's "pick from q" rule; 0 = filter off
+int deblock_level(const Resolved &r, bool key) {
+  if (!r.p.deblock) return 0;
+  const int q = r.p.bit_depth == 8 ? av1_ac_q8[r.qidx] : av1_ac_q10[r.qidx];
+  int g = r.p.bit_depth == 8 ? (q * 20723 + 1015158) >> 18 : (q * 20723 + 4060632) >> 20;
+  if (key) g -= 4;
+  return g < 0 ? 0 : (g > 63 ? 63 : g);
 }
 
 // sequence_header_obu (AV1 spec §5.5), complete OBU incl. header and size
@@ -220,7 +230,11 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
   b.put(0, 1);  // using_qmatrix
   b.put(0, 1);  // segmentation_enabled
   if (r.qidx > 0) b.put(0, 1);  // delta_q_present
-  b.put(0, 6); b.put(0, 6);  // loop_filter_level[0..1] = 0: deblocking off
+  {  // loop_filter_params (§5.9.11): level 0 = deblocking off
+    const uint32_t lv = (uint32_t)deblock_level(r, !inter);
+    b.put(lv, 6); b.put(lv, 6);          // loop_filter_level[0..1]
+    if (lv) { b.put(lv, 6); b.put(lv, 6); }  // [2..3] (U, V)
+  }
   b.put(0, 3);  // loop_filter_sharpness
   b.put(0, 1);  // loop_filter_delta_enabled
   if (p.enable_cdef) {
@@ -510,6 +524,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.keyint = (int)p.keyint;
   P.me_range = (int)p.me_range;
   P.hdr_slot_bytes = 512;
+  for (int i = 0; i < 4; i++) { P.lf_level[i] = deblock_level(r, true); P.lf_level_inter[i] = deblock_level(r, false); }
+  P.lf_sharpness = 0;
   P.enable_lr = p.enable_lr ? 1 : 0;
   for (int rf = 0; rf < 4; rf++)
     for (int k = 0; k < 3; k++) { const BitString b = lr_code_of(rf, k); P.lr_code_len[rf][k] = b.len; P.lr_code_bits[rf][k] = b.bits; }
@@ -722,6 +738,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   if (!inter_chunk) {
     HIPCHK(c, av1mi_launch_recon(&P, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
     if (lr) {  // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
+      if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
       HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, s));
       HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, s));
     }
@@ -761,6 +778,9 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         HIPCHK(c, hipStreamWaitEvent(s, c->me_ev[f], 0));
         HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, reff, mef, s));
       }
+      if (!av1mi_frame_is_inter(P, (int)f)) { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level[i]; }
+      else { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level_inter[i]; }
+      if (P1.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P1, recf, blkf, s));
       HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, s));
       if (lr) {
         const int upf = ((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
@@ -776,6 +796,10 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc, s, c->ev[7]));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
+  if (!inter_chunk && !lr && P.lf_level[0]) {  // deblocking reads only the reconstruction and block info: beside symbolize
+    HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));
+    HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s2));
+  }
   HIPCHK(c, hipStreamWaitEvent(s2, c->ev[7], 0));  // ev[7]: recorded between symbolize and range-code (measured: starting CDEF
                                                    // right after the reconstruction, beside symbolize, costs 8 % overall)
   HIPCHK(c, hipEventRecord(c->ev[8], s2));

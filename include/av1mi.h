@@ -61,7 +61,9 @@ typedef struct {
                                default 0: the decision needs the CDEF output, which serialises CDEF before entropy coding */
   uint32_t tile_sb;         /* tile size in 64x64 superblocks, both ways: 0 = automatic (1; 2 when the frame has more than 64
                                superblock rows or columns, e.g. 8K - AV1 allows at most 64 x 64 tiles), or force 1 / 2 */
-  uint32_t reserved[2];
+  uint32_t deblock;         /* 1 = deblocking filter on (default 0: `loop_filter_level` = 0); the level follows the quantiser:
+                               (ac_q * 20723 + 1015158) >> 18 at 8-bit scale, 4 less on key frames, all four filters alike */
+  uint32_t reserved[1];
 } av1mi_params;
 
 typedef struct {

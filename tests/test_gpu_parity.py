@@ -52,6 +52,9 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         p.intra_mode_mask = cfgk.get("mode_mask", 0)
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         p.enable_lr = cfgk.get("enable_lr", 0)
+        if cfgk.get("deblock", 0) == 2:
+            continue   # explicit levels: oracle-only test hook
+        p.deblock = cfgk.get("deblock", 0)
         for k in ("cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping"):
             if k in cfgk:
                 setattr(p, k, cfgk[k])
@@ -257,8 +260,10 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
         bs = cfgk.get("min_bs_log2", 4)
         if any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("film_grain") or bs > 5:
             continue
+        if m["width"] % 8 or m["height"] % 8:
+            continue   # (covered by test_sizes_that_are_not_multiples_of_8: fixtures here are generated full-size)
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, keyint=240, me_range=cfgk.get("me_range", 8),
-                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0))
+                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0), deblock=cfgk.get("deblock", 0))
         frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, m["bit_depth"]) for f in frames), m["frames"], want_recon=True)
         assert data == m["obu"], m["name"]
@@ -487,12 +492,13 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
         fg = int(rng.choice([0, 0, 20]))
         tsb = int(rng.choice([1, 1, 2]))
         n = int(rng.integers(1, 4))
+        db = int(rng.integers(0, 2))
         big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=3000 + it, t=t) for t in range(n)]
         frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
         p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
-                                 enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb)
+                                 enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb, deblock=db)
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
-        cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq), mode_mask=mask,
+        cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq), mode_mask=mask, deblock=db,
                                     disable_cdf_update=0 if cdf else 1, me_range=me, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb,
                                     film_grain=1 if fg else 0, fg_y_scaling=2 * fg, fg_c_scaling=fg)
         tus, recs, ref, prev = [], [], None, None
@@ -503,7 +509,7 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
             tus.append(tu)
             recs.append(rec)
             ref, prev = rec, f
-        desc = dict(it=it, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n)
+        desc = dict(it=it, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db)
         assert list(sizes) == [len(t) for t in tus], desc
         assert data == b"".join(tus), desc
         fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
@@ -522,6 +528,24 @@ def test_sizes_that_are_not_multiples_of_8(av1mi, ctx, oracle, w, h, bd, n, bs, 
     p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, enable_lr=lr, tile_sb=tsb)
     data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
     cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert data == b"".join(tus)
+    fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+    for i, rec in enumerate(recs):
+        assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint,lr,cq", [(200, 120, 8, 2, 5, 1, 0, 30), (216, 88, 10, 3, 4, 2, 1, 40), (136, 72, 8, 3, 3, 240, 0, 20),
+                                                     (130, 134, 10, 2, 5, 2, 0, 55), (640, 360, 8, 3, 5, 240, 1, 30)])
+def test_deblocking_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, lr, cq):
+    """deblock = 1: the deblocking filter runs on the reconstruction before CDEF - and, being the
+    "pre-CDEF" frame, feeds the restoration filter's stripe edges; levels follow the quantiser (key frames 4 lower).
+    Streams (the header carries the levels) and reconstructions bit-exact against the oracle (dav1d-pinned)."""
+    big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=1500 + w, t=t) for t in range(n)]
+    frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, enable_lr=lr, cq_level=cq, deblock=1)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, enable_lr=lr, base_q_idx=av1mi.cq_to_qindex(cq), deblock=1)
     tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
     assert data == b"".join(tus)
     fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
