@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--me-range", type=int, default=8)
     ap.add_argument("--cq", type=int, default=30, help="CQ level (the headline metric is quoted at 30; the reference's production string uses 8)")
     ap.add_argument("--film-grain", type=int, default=0)
+    ap.add_argument("--deblock", action="store_true", help="deblocking filter on (default off: loop_filter_level 0, SURVEY.md §8a a19)")
+    ap.add_argument("--lr", action="store_true", help="loop restoration on (default off)")
     ap.add_argument("--chunks-per-gpu", type=int, default=1,
                     help="independent full chunks encoded concurrently on their own contexts per GPU (the reference's `--workers`); "
                          "a step then processes chunks-per-gpu x frames frames")
@@ -166,7 +168,8 @@ def main():
     d_frames = torch.frombuffer(bytearray(clip), dtype=torch.uint8).to(dev)  # HBM-resident input
     torch.cuda.synchronize(dev)
     params = av1mi.default_params(w, h, bd, block_log2=args.block_log2, cdf_update=0 if args.static_cdf else 1, keyint=args.keyint,
-                                  me_range=args.me_range, cq_level=args.cq, film_grain=args.film_grain)
+                                  me_range=args.me_range, cq_level=args.cq, film_grain=args.film_grain,
+                                  deblock=1 if args.deblock else 0, enable_lr=1 if args.lr else 0)
     params.intra_mode_mask = args.mode_mask
     W_ = max(1, args.chunks_per_gpu)
     C_ = W_
@@ -254,7 +257,8 @@ def main():
                                    "%dx%d blocks, 64x64 tiles, %s CDFs, CDEF on" % (
                                        w, h, n, "all-key-frame" if args.keyint <= 1 else "IPPP (keyint %d, 1 reference, +-%d full search)" % (args.keyint, args.me_range),
                                        bd, args.cq, av1mi.cq_to_qindex(args.cq), 1 << args.block_log2, 1 << args.block_log2,
-                                       "static" if args.static_cdf else "adaptive"),
+                                       "static" if args.static_cdf else "adaptive") + (", deblocking on" if args.deblock else "") + (
+                                           ", loop restoration on" if args.lr else ""),
                        "frames_per_chunk": n, "chunks_per_gpu": W_,
                        "parallelism": "chunk-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
