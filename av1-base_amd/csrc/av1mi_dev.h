@@ -11,6 +11,14 @@
 #endif
 
 // Uniform kernel parameters of one chunk (all frames of a chunk share them).
+#define AV1MI_QM_4X4 0
+#define AV1MI_QM_8X8 16
+#define AV1MI_QM_16X16 80
+#define AV1MI_QM_32X32 336
+#define AV1MI_QM_PLANE 1360   /* entries per plane type */
+
+struct Av1miQmEntry { uint32_t q, recip; };
+
 struct Av1miDevParams {
   int width, height, bit_depth;   // CODED size: the signalled size rounded up to multiples of 8 (the source is edge-extended)
   int true_w, true_h;             // signalled size: what the decoder crops to, clamps references to and restores within
@@ -23,6 +31,11 @@ struct Av1miDevParams {
   int base_q_idx, qctx;
   int dc_q, ac_q;
   uint32_t dc_recip, ac_recip;  // ceil(2^32 / q)
+  // quantiser matrices (using_qmatrix): null, or per plane type (luma | chroma) and square transform size the dequantiser
+  // step of every coefficient position, {q2 = Round2(q * Quantizer_Matrix[level][plane > 0][pos], 5), ceil(2^32 / q2)};
+  // a plane whose level is 15 (flat) holds q itself.  Offsets AV1MI_QM_*; header fields using_qm, qm_y, qm_uv.
+  const Av1miQmEntry *qm_tab;
+  int using_qm, qm_y, qm_uv;
   int min_bs_log2, max_bs_log2;
   uint32_t mode_mask;
   int enable_cdef, cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping;

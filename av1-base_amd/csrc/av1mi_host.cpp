@@ -78,6 +78,7 @@ struct Resolved {
   int cw, ch;                         // coded size: p.width / p.height rounded up to multiples of 8
   int sb_cols, sb_rows;
   int tile_sb, tile_cols, tile_rows;  // tiles of tile_sb x tile_sb superblocks (1, or 2 beyond 64 superblocks either way)
+  int qm_level;                       // quantiser-matrix level of all planes (15 = flat); only meaningful with p.enable_qm
 };
 
 // aom's quantizer_to_qindex[] (CQ level -> base_q_idx); 30 -> 120
@@ -101,6 +102,9 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
+  if (p.enable_qm > 1 || p.qm_min > 15 || p.qm_max > 15 || (p.enable_qm && p.qm_min > p.qm_max)) return AV1MI_E_INVALID_ARG;
+  // level from the quantiser index, as SVT-AV1 / libaom derive it ("--qm-min", "--qm-max")
+  r->qm_level = p.enable_qm ? (int)(p.qm_min + (uint32_t)r->qidx * (p.qm_max + 1 - p.qm_min) / 256) : 15;
   r->sb_cols = (r->cw + 63) / 64;
   r->sb_rows = (r->ch + 63) / 64;
   // AV1 allows at most 64 x 64 tiles: frames beyond 64 superblocks either way (8K) use tiles of 2 x 2 superblocks
@@ -227,7 +231,8 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
   b.put(0, 1);  // DeltaQYDc
   b.put(0, 1);  // DeltaQUDc
   b.put(0, 1);  // DeltaQUAc
-  b.put(0, 1);  // using_qmatrix
+  b.put(r.p.enable_qm ? 1 : 0, 1);  // using_qmatrix
+  if (r.p.enable_qm) { b.put((uint32_t)r.qm_level, 4); b.put((uint32_t)r.qm_level, 4); }  // qm_y, qm_u (= qm_v: separate_uv_delta_q = 0)
   b.put(0, 1);  // segmentation_enabled
   if (r.qidx > 0) b.put(0, 1);  // delta_q_present
   {  // loop_filter_params (§5.9.11): level 0 = deblocking off
@@ -399,6 +404,9 @@ struct av1mi_ctx {
   unsigned long long *d_me = nullptr;  // motion search results per 8x8 unit per frame
   void *d_stage = nullptr;             // sizes that are not multiples of 8: frames in the caller's tight layout (input / reconstruction out)
   void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
+  Av1miQmEntry *d_qm = nullptr;        // quantiser-matrix steps (Av1miDevParams::qm_tab), valid for qm_key = (level, qidx, bit depth)
+  std::vector<Av1miQmEntry> h_qm;
+  int qm_key = -1;
   uint8_t *d_lrc = nullptr;            // per restoration unit: 0 = off, k = candidate k-1
   size_t out_cap = 0;
   // host staging (pinned)
@@ -429,11 +437,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -508,6 +516,26 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.ac_q = p.bit_depth == 8 ? av1_ac_q8[r.qidx] : av1_ac_q10[r.qidx];
   P.dc_recip = (uint32_t)((((uint64_t)1 << 32) + P.dc_q - 1) / P.dc_q);
   P.ac_recip = (uint32_t)((((uint64_t)1 << 32) + P.ac_q - 1) / P.ac_q);
+  P.using_qm = p.enable_qm ? 1 : 0; P.qm_y = P.qm_uv = r.qm_level;
+  P.qm_tab = nullptr;
+  if (p.enable_qm && r.qm_level < 15) {
+    // dequantiser step per coefficient position (§7.12.3) and its reciprocal, for the square transform sizes 4..32
+    if (!c->d_qm) HIPCHK(c, hipMalloc((void **)&c->d_qm, 2 * AV1MI_QM_PLANE * sizeof(Av1miQmEntry)));
+    if (c->qm_key != ((r.qm_level << 16) | (r.qidx << 4) | (int)p.bit_depth)) {
+      static const int off[4] = { AV1MI_QM_4X4, AV1MI_QM_8X8, AV1MI_QM_16X16, AV1MI_QM_32X32 };
+      c->h_qm.resize(2 * AV1MI_QM_PLANE);
+      for (int pt = 0; pt < 2; pt++)
+        for (int l2 = 2; l2 <= 5; l2++)
+          for (int i = 0; i < (1 << (2 * l2)); i++) {
+            const uint32_t q = (uint32_t)(i ? P.ac_q : P.dc_q);
+            const uint32_t q2 = (q * av1_qm_iwt[r.qm_level][pt][off[l2 - 2] + i] + 16) >> 5;
+            c->h_qm[pt * AV1MI_QM_PLANE + off[l2 - 2] + i] = { q2, (uint32_t)((((uint64_t)1 << 32) + q2 - 1) / q2) };
+          }
+      HIPCHK(c, hipMemcpyAsync(c->d_qm, c->h_qm.data(), c->h_qm.size() * sizeof(Av1miQmEntry), hipMemcpyHostToDevice, c->stream));
+      c->qm_key = (r.qm_level << 16) | (r.qidx << 4) | (int)p.bit_depth;
+    }
+    P.qm_tab = c->d_qm;
+  }
   P.min_bs_log2 = P.max_bs_log2 = (int)p.block_log2;
   P.mode_mask = p.intra_mode_mask ? (p.intra_mode_mask & 0x1FFF) : 0x0007;  // default candidates: DC, V, H
   P.enable_cdef = p.enable_cdef ? 1 : 0;
@@ -544,6 +572,7 @@ void av1mi_default_params(av1mi_params *p, uint32_t w, uint32_t h, uint32_t bd) 
   p->width = w; p->height = h; p->bit_depth = bd;
   p->cq_level = 30; p->keyint = 1; p->block_log2 = 5; p->cdf_update = 1; p->enable_cdef = 1;
   p->cdef_y_pri = 2; p->cdef_y_sec = 0; p->cdef_uv_pri = 1; p->cdef_uv_sec = 0; p->cdef_damping = 5;
+  p->qm_min = 8; p->qm_max = 15;  // used when enable_qm = 1
 }
 
 int av1mi_write_headers(const av1mi_params *p, uint8_t *seq_hdr, size_t *seq_len, uint8_t *frame_hdr, size_t *frame_hdr_bits) {

@@ -16,6 +16,7 @@
 // Algorithmic HBM traffic per superblock: source read once, reconstruction written once, levels
 // written once (SURVEY.md §8d "stage A").
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "av1mi_dev.h"
 #define AV1_TXFM_FN static __device__ __forceinline__
 #include "txfm_gen.h"
@@ -391,17 +392,26 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   __syncthreads();
   int my_key = -1;  // (anti-diagonal << 6 | position inside it) of the last nonzero level in scan order
   int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk) + po;  // source block is dead: reuse for the levels
-  if (tx_lane) {
+  // dead-zone quantiser + normative dequantiser (§7.12.3) of this lane's coefficient row.  QM: the step of every position
+  // comes from the context's quantiser-matrix table {Round2(q * Quantizer_Matrix, 5), ceil(2^32 / that)}; the matrices are
+  // symmetric, so lanes read entry [j][row] (consecutive addresses across the wave).
+  auto quant_row = [&](auto qm_tag) {
+    constexpr bool QM = decltype(qm_tag)::value;
     const int row = sl;
-#pragma unroll
-    for (int j = 0; j < N; j++) x[j] = S->scratch[so + row * ST + j];
-    Tx1d<LOG2N>::fwd(x, ht);
+    constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
+    const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row : nullptr;
 #pragma unroll
     for (int j = 0; j < N; j++) {
       const int v = x[j];
-      const bool dc = (row | j) == 0;
-      const uint32_t q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
-      const uint32_t recip = dc ? P->dc_recip : P->ac_recip;
+      uint32_t q, recip;
+      if constexpr (QM) {
+        const Av1miQmEntry e = tab[j * N];
+        q = e.q; recip = e.recip;
+      } else {
+        const bool dc = (row | j) == 0;
+        q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
+        recip = dc ? P->dc_recip : P->ac_recip;
+      }
       // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above
       const int d0 = row + j;
       const uint32_t rnd = d0 < (N >> 2) ? (3 * q) >> 3 : (d0 < (N >> 1) ? (q >> 2) : (q >> 3));
@@ -421,6 +431,13 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
       }
       x[j] = d;
     }
+  };
+  if (tx_lane) {
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = S->scratch[so + sl * ST + j];
+    Tx1d<LOG2N>::fwd(x, ht);
+    if (P->qm_tab) quant_row(std::true_type{});
+    else quant_row(std::false_type{});
   }
   for (int o = G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(my_key, o, 64); my_key = t > my_key ? t : my_key; }
   int eob = 0;

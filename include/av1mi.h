@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AV1MI_ABI_VERSION 2
+#define AV1MI_ABI_VERSION 3
 
 /* positive failure codes (-> Av1anFailed(code)) */
 enum {
@@ -63,6 +63,11 @@ typedef struct {
                                superblock rows or columns, e.g. 8K - AV1 allows at most 64 x 64 tiles), or force 1 / 2 */
   uint32_t deblock;         /* 1 = deblocking filter on (default 0: `loop_filter_level` = 0); the level follows the quantiser:
                                (ac_q * 20723 + 1015158) >> 18 at 8-bit scale, 4 less on key frames, all four filters alike */
+  uint32_t enable_qm;       /* "--enable-qm 1" (av1an.rs:14): quantiser matrices (using_qmatrix).  The level of all three planes
+                               follows the quantiser as in SVT-AV1/libaom: qm_min + base_q_idx * (qm_max + 1 - qm_min) / 256
+                               (0 = steepest matrix ... 14; 15 = flat).  Default 0 */
+  uint32_t qm_min, qm_max;  /* "--qm-min" / "--qm-max": 0..15, qm_min <= qm_max; av1mi_default_params sets 8 / 15 (the encoder's
+                               defaults); the reference's production string uses 1 / 15 */
   uint32_t reserved[1];
 } av1mi_params;
 

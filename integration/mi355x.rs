@@ -11,8 +11,9 @@ pub struct Av1miParams {            // include/av1mi.h: av1mi_params
     pub width: u32, pub height: u32, pub bit_depth: u32,
     pub cq_level: u32, pub keyint: u32, pub block_log2: u32, pub cdf_update: u32, pub enable_cdef: u32,
     pub cdef_y_pri: u32, pub cdef_y_sec: u32, pub cdef_uv_pri: u32, pub cdef_uv_sec: u32, pub cdef_damping: u32,
-    pub intra_mode_mask: u32, pub film_grain: u32, pub first_frame: u32, pub me_range: u32, pub enable_lr: u32, pub tile_sb: u32,
-    pub reserved: [u32; 2],
+    pub intra_mode_mask: u32, pub film_grain: u32, pub first_frame: u32, pub me_range: u32, pub enable_lr: u32, pub tile_sb: u32, pub deblock: u32,
+    pub enable_qm: u32, pub qm_min: u32, pub qm_max: u32,
+    pub reserved: [u32; 1],
 }
 #[repr(C)]
 pub struct Av1miJob {               // include/av1mi.h: av1mi_job  <->  Av1anEncodeParams (av1an.rs:36-45)
@@ -50,6 +51,7 @@ pub fn run_mi355x(params: &Av1anEncodeParams, cq_level: u32) -> Result<(), Encod
     p.cq_level = cq_level;                               // "--crf" (8 in production; 30 is the benchmark's operating point)
     p.keyint = 240;                                      // "--keyint 240": IPPP inside a chunk, chunks start at scene cuts
     p.film_grain = 20;                                   // "--film-grain 20": film-grain table in every frame header
+    p.enable_qm = 1; p.qm_min = 1; p.qm_max = 15;        // "--enable-qm 1 --qm-min 1 --qm-max 15": quantiser matrices
     let job = Av1miJob { input_path: i.as_ptr(), output_path: o.as_ptr(), temp_dir: t.as_ptr(),
                          workers: params.concurrency.av1an_workers, chunk_frames: 0 /* scene-cut chunks */, gpu_mask: 0, params: p };
     let mut rep = Av1miReport::default();

@@ -61,6 +61,10 @@ typedef struct {
   int enable_lr;          /* 1: loop restoration on luma: Wiener, 64x64 units, per-unit choice among {off, 3 filters} */
   int true_width, true_height; /* internal: set by the encoder when it runs at the padded size (0 = same as width/height) */
   int me_range;           /* inter frames: integer-pel full search, |dx|,|dy| <= me_range (default 8) */
+  /* quantiser matrices (§5.9.12 using_qmatrix, §7.12.3; the reference runs `--enable-qm 1
+   * --qm-min 1 --qm-max 15`, av1an.rs:14): level 0 (steepest) .. 14, 15 = flat (no matrix for that plane) */
+  int enable_qm;          /* 1: using_qmatrix */
+  int qm_y, qm_uv;        /* qm_y; qm_u = qm_v (separate_uv_delta_q is 0) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */
@@ -103,6 +107,8 @@ long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq
  * SURVEY.md §8a rows a13 (motion estimation) and a14 (motion compensation). */
 long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oFrame *ref, const Av1oFrame *prev_src, int with_seq_hdr,
                         uint8_t *out, size_t out_cap, Av1oFrame *recon, Av1oStats *stats);
+
+int av1o_qm_level(int base_q_idx, int qm_min, int qm_max);
 
 /* size of the sequence header OBU etc. helpers used by the tests */
 long av1o_write_sequence_header(const Av1oConfig *cfg, uint8_t *out, size_t cap);

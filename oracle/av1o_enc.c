@@ -97,6 +97,8 @@ void av1o_default_config(Av1oConfig *c, int w, int h, int bit_depth) {
   c->cdef_damping = 5;
   c->mode_mask = 0x0007; /* DC, V, H */
   c->me_range = 8;
+  c->enable_qm = 0;
+  c->qm_y = c->qm_uv = 15;
   c->fuzz_density = 8;
   c->fuzz_maxlevel = 40;
 }
@@ -285,7 +287,11 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, int is_int
   bw_put(&b, 0, 1); /* DeltaQYDc delta_coded */
   bw_put(&b, 0, 1); /* DeltaQUDc */
   bw_put(&b, 0, 1); /* DeltaQUAc */
-  bw_put(&b, 0, 1); /* using_qmatrix */
+  bw_put(&b, cfg->enable_qm ? 1 : 0, 1); /* using_qmatrix */
+  if (cfg->enable_qm) {
+    bw_put(&b, (uint32_t)cfg->qm_y, 4);  /* qm_y */
+    bw_put(&b, (uint32_t)cfg->qm_uv, 4); /* qm_u; qm_v = qm_u because separate_uv_delta_q = 0 */
+  }
   bw_put(&b, 0, 1); /* segmentation_enabled */
   if (cfg->base_q_idx > 0) bw_put(&b, 0, 1); /* delta_q_present */
   /* loop_filter_params() §5.9.11: levels 0 = deblocking off */
@@ -729,6 +735,21 @@ static void prepare_edges(const Enc *e, int plane, int x, int y, int n, int have
 /* ------------------------------------------------------------------ quantiser */
 static int tx_scale_shift(int log2n) { return log2n >= 6 ? 2 : (log2n == 5 ? 1 : 0); }
 
+/* Quantiser-matrix level from the quantiser index, as SVT-AV1 and libaom derive it from "--qm-min" / "--qm-max"
+ * (the reference runs `--enable-qm 1 --qm-min 1 --qm-max 15`, av1an.rs:14). */
+int av1o_qm_level(int base_q_idx, int qm_min, int qm_max) { return qm_min + base_q_idx * (qm_max + 1 - qm_min) / 256; }
+
+/* §7.12.3: the dequantiser step at coefficient (i, j): q, or with a quantiser matrix Round2(q * Quantizer_Matrix[..], 5).
+ * All transforms here are 2-D DCT/ADST (PlaneTxType < IDTX), so the matrix applies whenever the plane's level is < 15. */
+static uint32_t qstep_at(const Enc *e, int plane, int log2n, int i, int j) {
+  static const int off[4] = { AV1_QM_4X4, AV1_QM_8X8, AV1_QM_16X16, AV1_QM_32X32 };
+  const uint32_t q = (uint32_t)((i | j) ? e->ac_q : e->dc_q);
+  const int lvl = e->cfg->enable_qm ? (plane ? e->cfg->qm_uv : e->cfg->qm_y) : 15;
+  const int l2 = log2n > 5 ? 5 : log2n;
+  if (lvl >= 15) return q;
+  return (q * av1_qm_iwt[lvl][plane > 0][off[l2 - 2] + (i << l2) + j] + 16) >> 5;
+}
+
 /* forward transform + dead-zone quantise -> levels; dequantise + inverse -> recon in place.
  * Returns eob.  DESIGN.md §3.5: level = ((|coef| << s) + rnd) * ceil(2^32/q) >> 32 with the
  * frequency-dependent dead zone rnd = 3q/8 (row+col < n/4), q/4 (< n/2), q/8 (else). */
@@ -761,7 +782,7 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
     for (i = 0; i < cw; i++)
       for (j = 0; j < cw; j++) {
         int32_t v = coef[i * n + j];
-        uint32_t q = (uint32_t)((i | j) ? e->ac_q : e->dc_q);
+        uint32_t q = qstep_at(e, plane, log2n, i, j);
         uint32_t recip = (uint32_t)((((uint64_t)1 << 32) + q - 1) / q);
         uint32_t rnd = (i + j) < (cw >> 2) ? (3 * q) >> 3 : ((i + j) < (cw >> 1) ? (q >> 2) : (q >> 3));
         uint32_t a = ((uint32_t)abs(v) << sh) + rnd;
@@ -781,7 +802,7 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
       for (j = 0; j < cw; j++) {
         int32_t lv = t->level[(i << bwl) + j];
         if (lv) {
-          uint32_t q = (uint32_t)((i | j) ? e->ac_q : e->dc_q);
+          uint32_t q = qstep_at(e, plane, log2n, i, j);
           int64_t d = ((int64_t)abs(lv) * q) & 0xFFFFFF;
           int64_t lim = (int64_t)1 << (7 + bd);
           d >>= sh;

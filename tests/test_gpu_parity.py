@@ -55,6 +55,10 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         if cfgk.get("deblock", 0) == 2:
             continue   # explicit levels: oracle-only test hook
         p.deblock = cfgk.get("deblock", 0)
+        if cfgk.get("enable_qm"):
+            if cfgk["qm_y"] != cfgk["qm_uv"]:
+                continue   # the HIP path derives one level for all planes
+            p.enable_qm, p.qm_min, p.qm_max = 1, cfgk["qm_y"], cfgk["qm_y"]   # min == max: that level at any quantiser
         for k in ("cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping"):
             if k in cfgk:
                 setattr(p, k, cfgk[k])
@@ -264,6 +268,8 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
             continue   # (covered by test_sizes_that_are_not_multiples_of_8: fixtures here are generated full-size)
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, keyint=240, me_range=cfgk.get("me_range", 8),
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0), deblock=cfgk.get("deblock", 0))
+        if cfgk.get("enable_qm"):
+            p.enable_qm, p.qm_min, p.qm_max = 1, cfgk["qm_y"], cfgk["qm_y"]
         frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, m["bit_depth"]) for f in frames), m["frames"], want_recon=True)
         assert data == m["obu"], m["name"]
@@ -272,6 +278,44 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
             assert sha(split_planes(recon.tobytes()[t * fb:(t + 1) * fb], m["width"], m["height"], m["bit_depth"])) == m["dav1d_sha256"][t], (m["name"], t)
         n += 1
     assert n >= 4
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,cq,qmin,qmax,extra", [
+    (200, 120, 10, 4, 5, 8, 1, 15, dict(film_grain=20)),      # the reference's production string (av1an.rs:14)
+    (328, 248, 8, 3, 4, 30, 8, 15, dict(deblock=1)),          # the encoder's default range at the benchmark's quantiser
+    (136, 136, 10, 3, 3, 50, 0, 15, dict(enable_lr=1)),
+    (232, 120, 8, 2, 5, 63, 0, 14, dict()),
+    (72, 56, 8, 2, 5, 20, 15, 15, dict())])                   # using_qmatrix with flat matrices
+def test_quantiser_matrices_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, cq, qmin, qmax, extra):
+    """enable_qm: level from the quantiser index, per-position dequantiser steps in the quantiser and the
+    dequantiser, using_qmatrix / qm_y / qm_u in every frame header - IPPP chunk bit-exact against the oracle."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=900 + w, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=240, cq_level=cq, enable_qm=1, qm_min=qmin, qm_max=qmax, **extra)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    qidx = av1mi.cq_to_qindex(cq)
+    lvl = oracle.qm_level(qidx, qmin, qmax)
+    assert 0 <= lvl <= 15
+    kw = dict(min_bs_log2=bs, max_bs_log2=bs, base_q_idx=qidx, enable_qm=1, qm_y=lvl, qm_uv=lvl, deblock=extra.get("deblock", 0), enable_lr=extra.get("enable_lr", 0))
+    tus, recs = [], []
+    ref = prev = None
+    for t, f in enumerate(frames):
+        if extra.get("film_grain"):
+            kw.update(film_grain=1, fg_y_scaling=2 * extra["film_grain"], fg_c_scaling=extra["film_grain"], fg_seed=(7391 + 173 * t) & 0xFFFF)   # first_frame 0
+        cfg = oracle.default_config(w, h, bd, **kw)
+        tu, rec, st = oracle.encode_frame(cfg, f, with_seq_hdr=(t == 0), ref=ref, prev_src=prev)
+        tus.append(tu)
+        recs.append(rec)
+        ref, prev = rec, f
+    assert list(sizes) == [len(t) for t in tus]
+    assert data == b"".join(tus)
+    assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
+
+
+def test_qm_is_validated(av1mi, ctx):
+    for bad in (dict(qm_min=9, qm_max=8), dict(qm_min=16, qm_max=16), dict(qm_max=16)):
+        p = av1mi.default_params(64, 64, 8, enable_qm=1, **bad)
+        with pytest.raises(av1mi.EncodeFailed):
+            ctx.encode_chunk(p, bytes(64 * 64 * 3 // 2), 1)
 
 
 def test_4k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):

@@ -329,3 +329,19 @@ def test_bench_synthclip_equals_the_oracle_generator(oracle):
         a = bench.synthclip_frame(w, h, bd, seed, t)
         b = oracle.synthclip_frame(w, h, bd, seed=seed, t=t)
         assert all((a[i] == b[i]).all() for i in range(3)), (w, h, bd, seed, t)
+
+
+def test_quantiser_matrix_level_rule_and_effect(oracle):
+    """`enable_qm`: level = qm_min + q * (qm_max + 1 - qm_min) / 256 (SVT-AV1 / libaom); a steep matrix coarsens the high
+    frequencies (fewer bytes), level 15 is the flat quantiser with using_qmatrix still signalled (5 more header bits)."""
+    assert oracle.qm_level(32, 1, 15) == 2 and oracle.qm_level(120, 1, 15) == 8 and oracle.qm_level(255, 8, 15) == 15
+    assert oracle.qm_level(0, 3, 9) == 3 and oracle.qm_level(255, 0, 14) == 14 and oracle.qm_level(200, 7, 7) == 7
+    src = oracle.synthclip_frame(136, 72, 8, seed=5, t=0)
+    plain, rec0, _ = oracle.encode_frame(oracle.default_config(136, 72, 8, min_bs_log2=5, max_bs_log2=5), src)
+    sizes = []
+    for lvl in (0, 6, 12, 15):
+        tu, rec, _ = oracle.encode_frame(oracle.default_config(136, 72, 8, min_bs_log2=5, max_bs_log2=5, enable_qm=1, qm_y=lvl, qm_uv=lvl), src)
+        sizes.append(len(tu))
+        if lvl == 15:
+            assert all((a == b).all() for a, b in zip(rec, rec0)) and tu != plain and abs(len(tu) - len(plain)) <= 1
+    assert sizes[0] < sizes[1] < sizes[2] <= sizes[3]

@@ -302,6 +302,21 @@ def main():
         inter += [Q["dc_q8"][i], Q["ac_q8"][i]]
     assert blob.find_all(struct.pack("<16H", *inter)), "dav1d dq_tbl does not match libaom qlookup"
 
+    # ---- quantiser matrices (spec 'Quantizer matrix tables'; libaom iwt_matrix_ref[15][2][3344]) ------
+    # Per level and plane type the 3344 bytes hold, in order, the 4x4, 8x8, 16x16 and 32x32 matrices (offsets 0, 16, 80,
+    # 336) and then the rectangular ones; this build codes square transforms only, so the first 1360 bytes are kept.
+    qm_anchor = bytes([32, 43, 73, 97, 43, 67, 94, 110, 73, 94, 137, 150, 97, 110, 150, 200])
+    offs = blob.find_all(qm_anchor)
+    assert len(offs) == 1, offs
+    qm = blob.a[offs[0]:offs[0] + 15 * 2 * 3344].reshape(15, 2, 3344).astype(np.int64)
+    assert qm.min() >= 16 and qm.max() < 256
+    for (o, n_) in ((0, 4), (16, 8), (80, 16), (336, 32)):
+        m = qm[:, :, o:o + n_ * n_].reshape(15, 2, n_, n_)
+        assert (m == m.transpose(0, 1, 3, 2)).all(), "square matrices are symmetric"
+        assert (np.abs(m[:, :, 0, 0] - 32) <= 3).all(), "DC weights are near 32 (= 1.0)"
+    assert (np.diff(qm[:, 0, 336 + 1023]) <= 0).all(), "higher levels are flatter"
+    QM = qm[:, :, :1360]
+
     # ---- emit ---------------------------------------------------------------------------
     out = []
     w = out.append
@@ -338,6 +353,24 @@ def main():
             w("  " + ", ".join("%d" % x for x in v[i:i + 16]) + ",")
         w("};")
         w("")
+    w("/* Quantizer_Matrix[level 0..14][plane > 0][4x4 | 8x8 | 16x16 | 32x32] (level 15 = flat, no table) */")
+    w("#define AV1_QM_4X4 0")
+    w("#define AV1_QM_8X8 16")
+    w("#define AV1_QM_16X16 80")
+    w("#define AV1_QM_32X32 336")
+    w("#define AV1_QM_SQUARE_TOTAL 1360")
+    w("static const uint8_t av1_qm_iwt[15][2][1360] = {")
+    for lv in range(15):
+        w("  {")
+        for c in range(2):
+            w("    {")
+            v = [int(x) for x in QM[lv, c]]
+            for i in range(0, 1360, 32):
+                w("      " + ", ".join("%d" % x for x in v[i:i + 32]) + ",")
+            w("    },")
+        w("  },")
+    w("};")
+    w("")
     w("#endif")
     with open(args.out, "w") as f:
         f.write("\n".join(out) + "\n")

@@ -62,6 +62,13 @@ CASES = [
     ("k200x120_deblock", 200, 120, 8, 1080, 2, dict(min_bs_log2=5, max_bs_log2=5, deblock=1)),
     ("k216x88_deblock_lr_10b", 216, 88, 10, 51, 0, dict(min_bs_log2=4, max_bs_log2=4, deblock=1, enable_lr=1)),
     ("fuzz_deblock_bs3", 136, 72, 8, 52, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=6, deblock=2, lf_level=(63, 40, 17, 5), lf_sharpness=3)),
+    # quantiser matrices (using_qmatrix): one level for all planes as the HIP path derives it, and split / fuzzed levels
+    ("k200x120_qm4", 200, 120, 8, 1080, 1, dict(min_bs_log2=5, max_bs_log2=5, enable_qm=1, qm_y=4, qm_uv=4)),
+    ("k232x120_qm9_deblock_10b", 232, 120, 10, 61, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_qm=1, qm_y=9, qm_uv=9, deblock=1)),
+    ("k136x72_qm0_bs3", 136, 72, 8, 62, 0, dict(min_bs_log2=3, max_bs_log2=3, enable_qm=1, qm_y=0, qm_uv=0)),
+    ("k72x56_qm15_flat", 72, 56, 8, 11, 0, dict(min_bs_log2=5, max_bs_log2=5, enable_qm=1, qm_y=15, qm_uv=15)),
+    ("fuzz_qm_y3_uv11_bs6_10b", 136, 136, 10, 63, 0, dict(min_bs_log2=6, max_bs_log2=6, enable_qm=1, qm_y=3, qm_uv=11, fuzz_coeffs=63, fuzz_density=6, fuzz_maxlevel=12, fuzz_modes=2)),
+    ("fuzz_qm_y14_uv0_bs4", 136, 72, 8, 64, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_qm=1, qm_y=14, qm_uv=0, fuzz_coeffs=64, fuzz_density=3, fuzz_maxlevel=20, mode_mask=0x1FFF)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -91,6 +98,8 @@ SEQ_CASES = [
     ("pfuzz_90x100_odd_me16", 90, 100, 8, 44, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=5, me_range=16)),
     ("p200x120_deblock", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, deblock=1)),
     ("pfuzz_deblock_bs6_odd", 130, 134, 10, 53, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=4, deblock=2, lf_level=(30, 30, 30, 30), lf_sharpness=0)),
+    ("p200x120_qm6", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, enable_qm=1, qm_y=6, qm_uv=6)),
+    ("pfuzz_qm_y2_uv12_bs4_10b", 200, 120, 10, 27, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_qm=1, qm_y=2, qm_uv=12, fuzz_modes=8)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
