@@ -54,6 +54,7 @@ struct Av1miDevParams {
   int tile_size_bytes;
   // inter coding: key frame every `keyint` frames of the chunk (1 = all key frames); motion search range
   int keyint, me_range;
+  int subpel;                     // inter frames: 1 = quarter-sample vectors (refined search) + EIGHTTAP filter; 0 = whole-sample vectors, BILINEAR
   // deblocking filter: loop_filter_level[0..3] (luma vertical edges, luma horizontal, U, V) of key / inter frames and sharpness
   int lf_level[4], lf_level_inter[4], lf_sharpness;
   // loop restoration (luma Wiener, 64x64 units): literal bits that code candidate k's coefficients against the

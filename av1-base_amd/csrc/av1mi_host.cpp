@@ -27,6 +27,8 @@
 extern "C" {
 hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
                               const unsigned long long *me_best, hipStream_t s);
+hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
+                                      int count, hipStream_t stream);
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
                                       int count, hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
@@ -102,6 +104,7 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
+  if (p.subpel > 1) return AV1MI_E_INVALID_ARG;
   if (p.enable_qm > 1 || p.qm_min > 15 || p.qm_max > 15 || (p.enable_qm && p.qm_min > p.qm_max)) return AV1MI_E_INVALID_ARG;
   // level from the quantiser index, as SVT-AV1 / libaom derive it ("--qm-min", "--qm-max")
   r->qm_level = p.enable_qm ? (int)(p.qm_min + (uint32_t)r->qidx * (p.qm_max + 1 - p.qm_min) / 256) : 15;
@@ -193,7 +196,7 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
   if (inter) {
     b.put(0, 1);  // allow_high_precision_mv
     b.put(0, 1);  // is_filter_switchable
-    b.put(3, 2);  // interpolation_filter BILINEAR
+    b.put(r.p.subpel ? 0 : 3, 2);  // interpolation_filter: EIGHTTAP with sub-sample vectors, else BILINEAR
     b.put(0, 1);  // is_motion_mode_switchable
   }
   if (p.cdf_update) b.put(1, 1);  // disable_frame_end_update_cdf
@@ -551,6 +554,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.tile_size_bytes = 4;
   P.keyint = (int)p.keyint;
   P.me_range = (int)p.me_range;
+  P.subpel = p.subpel ? 1 : 0;
   P.hdr_slot_bytes = 512;
   for (int i = 0; i < 4; i++) { P.lf_level[i] = deblock_level(r, true); P.lf_level_inter[i] = deblock_level(r, false); }
   P.lf_sharpness = 0;
@@ -792,6 +796,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     for (uint32_t f = 0; f < n_frames; f++) {
       if (!av1mi_frame_is_inter(P, (int)f)) continue;
       HIPCHK(c, av1mi_launch_motion_search(&P, d_src, c->d_me, P.me_range, (int)f, 1, c->stream2));
+      if (P.subpel) HIPCHK(c, av1mi_launch_subpel_refine(&P, d_src, c->d_me, P.me_range, (int)f, 1, c->stream2));
       HIPCHK(c, hipEventRecord(c->me_ev[f], c->stream2));
     }
     for (uint32_t f = 0; f < n_frames; f++) {

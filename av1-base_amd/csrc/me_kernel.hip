@@ -20,6 +20,7 @@
 // the (2R+1)-fold re-reads of the reference by the dy waves of a cell are L2 hits.
 #include <hip/hip_runtime.h>
 #include "av1mi_dev.h"
+#include "av1_tables.h"
 
 namespace {
 
@@ -133,7 +134,100 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sub-sample refinement (subpel = 1; oracle/av1o_enc.c motion_search, second half).
+// Around the full search's winner: the 8 half-sample neighbours, then the 8 quarter-sample neighbours of that stage's
+// best.  A candidate is the block interpolated from the previous SOURCE frame with the prediction's own filter
+// (EIGHTTAP, Round2 by 3 after the horizontal pass, by 11 and a clamp after the vertical one); cost = SAD +
+// (n * (|mv.row| + |mv.col|) >> 3); it replaces the best only when strictly cheaper, candidates in (row, col) raster
+// order; the displaced block stays within 16 samples of the frame.
+// One wave per 8x8 unit that is the origin of a leaf block (the others leave at once).  The wave stages the
+// (n + 8)^2 window of the reference around the integer winner in LDS once (coordinates clamped to the frame), then
+// per candidate: horizontal pass window -> mid ((n + 7) x n, 16-bit), vertical pass mid -> sample, SAD against the
+// source block in LDS, wave sum.  The result replaces the search's key: (SAD << 32) | (u16 mv.row << 16) | u16 mv.col.
+__constant__ int16_t c_subpel_me[2][16][8] = AV1_SUBPEL_FILTERS_INIT;
+
+template <typename PIX>
+__global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, const PIX *__restrict__ frames,
+                                                          unsigned long long *__restrict__ best_all, int frame0, int R) {
+  __shared__ uint16_t win[40 * 40];
+  __shared__ int16_t mid[39 * 32];
+  __shared__ uint16_t srcb[32 * 32];
+  const int f = frame0 + blockIdx.z;
+  if (!av1mi_frame_is_inter(P, f)) return;
+  const int ux = blockIdx.x, uy = blockIdx.y;   // 8x8 unit of the frame
+  const int bsl = leaf_bsl_cell(P, (ux >> 2) * 32, (uy >> 2) * 32, ux & 3, uy & 3);
+  if (!bsl) return;
+  const PIX *src = frames + (size_t)f * P.frame_samples, *ref = src - P.frame_samples;
+  unsigned long long *slot = best_all + (size_t)f * P.b8_rows * P.b8_cols + (size_t)uy * P.b8_cols + ux;
+  const int lane = threadIdx.x;
+  const int n = 1 << bsl, x = ux * 8, y = uy * 8, W = P.width, H = P.height;
+  const int NC = 2 * R + 1;
+  const unsigned long long key = *slot;
+  const int cand = (int)(key & 0xFFFF), dy0 = cand / NC - R, dx0 = cand % NC - R;
+  int best_row = dy0 * 8, best_col = dx0 * 8;
+  long best_cost = (long)(key >> 16);
+  int best_sad = (int)best_cost - n * (iabs(dx0) + iabs(dy0));
+  // window: reference samples (x + dx0 - 4 + j, y + dy0 - 4 + i), i, j < n + 8
+  const int wx = x + dx0 - 4, wy = y + dy0 - 4, ww = n + 8;
+  for (int p = lane; p < ww * ww; p += 64) {
+    const int i = p / ww, j = p - i * ww;
+    int yy = wy + i, xx = wx + j;
+    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+    xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+    win[i * 40 + j] = (uint16_t)ref[(size_t)yy * P.stride_y + xx];
+  }
+  for (int p = lane; p < n * n; p += 64) srcb[p] = (uint16_t)src[(size_t)(y + p / n) * P.stride_y + x + (p & (n - 1))];
+  __syncthreads();
+  const int maxv = (1 << P.bit_depth) - 1;
+  for (int step = 4; step >= 2; step >>= 1) {
+    const int base_row = best_row, base_col = best_col;
+    for (int k = 0; k < 9; k++) {
+      if (k == 4) continue;
+      const int mr = base_row + (k / 3 - 1) * step, mc = base_col + (k % 3 - 1) * step;
+      if (x * 8 + mc < -128 || (x + n) * 8 + mc > (W + 16) * 8 || y * 8 + mr < -128 || (y + n) * 8 + mr > (H + 16) * 8) continue;
+      // position of the block's first sample in 1/16 samples; integer part relative to the window origin
+      const int px = (x << 4) + 2 * mc, py = (y << 4) + 2 * mr;
+      const int ix = (px >> 4) - 3 - wx, iy = (py >> 4) - 3 - wy, fx = px & 15, fy = py & 15;   // 0 <= ix, iy <= 1
+      const int16_t *fh = c_subpel_me[0][fx], *fv = c_subpel_me[0][fy];
+      for (int p = lane; p < (n + 7) * n; p += 64) {
+        const int r = p / n, c = p - r * n;
+        const uint16_t *wp = win + (iy + r) * 40 + ix + c;
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += fh[t] * (int)wp[t];
+        mid[p] = (int16_t)((sum + 4) >> 3);
+      }
+      __syncthreads();
+      int sad = 0;
+      for (int p = lane; p < n * n; p += 64) {
+        const int r = p / n, c = p - r * n;
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += fv[t] * (int)mid[(r + t) * n + c];
+        int v = (sum + 1024) >> 11;
+        v = v < 0 ? 0 : (v > maxv ? maxv : v);
+        sad += iabs((int)srcb[p] - v);
+      }
+      for (int o = 32; o > 0; o >>= 1) sad += __shfl_xor(sad, o, 64);
+      __syncthreads();
+      const long cost = (long)sad + (((long)n * (iabs(mr) + iabs(mc))) >> 3);
+      if (cost < best_cost) { best_cost = cost; best_sad = sad; best_row = mr; best_col = mc; }
+    }
+  }
+  if (lane == 0) *slot = ((unsigned long long)(uint32_t)best_sad << 32) | ((unsigned long long)(uint16_t)(int16_t)best_row << 16) | (uint16_t)(int16_t)best_col;
+}
+
 }  // namespace
+
+// Refines the vectors of frames [frame0, frame0 + count) in place (after av1mi_launch_motion_search on the same stream).
+extern "C" hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range,
+                                                 int frame0, int count, hipStream_t stream) {
+  dim3 grid(P->b8_cols, P->b8_rows, count);
+  if (P->bit_depth == 8) hipLaunchKernelGGL((subpel_refine_kernel<uint8_t>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, me_range);
+  else hipLaunchKernelGGL((subpel_refine_kernel<uint16_t>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, me_range);
+  return hipGetLastError();
+}
 
 // best[] (n_frames x 8x8 units) must be filled with 0xFF bytes before the launch.  `frames`: the chunk's source frames
 // (P->n_frames of them); every inter frame is searched against the source frame before it.  R must be 8 or 16.

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "av1mi_dev.h"
+#include "av1_tables.h"
 #define AV1_TXFM_FN static __device__ __forceinline__
 #include "txfm_gen.h"
 
@@ -73,6 +74,13 @@ struct SbLds {
 };
 __shared__ SbLds g_sb;
 #define S (&g_sb)
+// motion compensation at sub-sample positions (inter instantiations only): reference window and horizontal-pass output
+struct McLds {
+  uint16_t win[39 * 39 + 7];
+  int16_t mid[39 * 32];
+};
+__shared__ McLds g_mc;
+__constant__ int16_t c_subpel[2][16][8] = AV1_SUBPEL_FILTERS_INIT;  // EIGHTTAP, and its 4-tap form for 4-sample blocks
 
 __device__ __forceinline__ int wave_sum(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -219,6 +227,46 @@ __device__ __forceinline__ int mc_sample(const PIX *plane, int stride, int last_
   return v < 0 ? 0 : (v > maxv ? maxv : v);
 }
 
+// Motion-compensated block at a sub-sample position with the EIGHTTAP filter (subpel = 1; spec §7.11.3.4, unscaled
+// reference, not compound): the (N + 7)^2 reference window (coordinates clamped to the signalled frame) is staged in
+// LDS once, horizontal pass -> Round2 by 3 -> 16-bit intermediate, vertical pass -> Round2 by 11 -> clamp.  Writes the
+// prediction of lane group `grp` into dst[0 .. N*N).  px0 / py0: position of the block's first sample in 1/16 samples.
+template <typename PIX, int LOG2N, int NPL>
+__device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int last_x, int last_y, int px0, int py0, int maxv,
+                                              int grp, int sl, uint16_t *dst) {
+  constexpr int N = 1 << LOG2N, WN = N + 7, G = 64 / NPL;
+  uint16_t *win = g_mc.win + grp * (NPL == 1 ? 0 : 23 * 23 + 3);
+  int16_t *mid = g_mc.mid + grp * (NPL == 1 ? 0 : 23 * 16);
+  const int ix0 = (px0 >> 4) - 3, iy0 = (py0 >> 4) - 3;
+  const int16_t *fh = c_subpel[N <= 4][px0 & 15], *fv = c_subpel[N <= 4][py0 & 15];
+  for (int p = sl; p < WN * WN; p += G) {
+    const int i = p / WN, j = p - i * WN;
+    int yy = iy0 + i, xx = ix0 + j;
+    yy = yy < 0 ? 0 : (yy > last_y ? last_y : yy);
+    xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
+    win[p] = (uint16_t)rp[(size_t)yy * stride + xx];
+  }
+  __syncthreads();
+  for (int p = sl; p < WN * N; p += G) {
+    const int r = p >> LOG2N, c = p & (N - 1);
+    const uint16_t *wp = win + r * WN + c;
+    int sum = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) sum += fh[t] * (int)wp[t];
+    mid[p] = (int16_t)((sum + 4) >> 3);
+  }
+  __syncthreads();
+  for (int p = sl; p < N * N; p += G) {
+    const int r = p >> LOG2N, c = p & (N - 1);
+    int sum = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) sum += fv[t] * (int)mid[(r + t) * N + c];
+    const int v = (sum + 1024) >> 11;
+    dst[p] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+  }
+  __syncthreads();
+}
+
 // One transform block per lane GROUP.  NPL = 1: the whole wave works on one block of `plane0` (luma,
 // with the mode decision).  NPL = 2: lanes 0-31 work on the U block and lanes 32-63 on the V block of
 // the same position at the same time (same mode, independent data) - chroma transforms are at most
@@ -337,6 +385,18 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     }
     const int mode = final_trip ? best_mode : m;
     if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
+    bool mc_in_lds = false;  // the motion-compensated prediction already sits in blkpix (sub-sample position, EIGHTTAP)
+    if constexpr (INTER) {
+      if (final_trip && ii.is_inter && P->subpel) {
+        const int ss = plane0 > 0;
+        const int px0 = (gx << 4) + ((2 * ii.mv_col) >> ss), py0 = (gy << 4) + ((2 * ii.mv_row) >> ss);
+        if ((px0 | py0) & 15) {
+          mc_block_8tap<PIX, LOG2N, NPL>(static_cast<const PIX *>(ii.ref) + poff, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
+                                         px0, py0, (1 << bd) - 1, grp, sl, S->blkpix + po);
+          mc_in_lds = true;
+        }
+      }
+    }
     int ang = 0, dx = 0, dy = 0;
     if (mode >= V_PRED && mode <= D67_PRED) {
       ang = c_mode_angle[mode];
@@ -349,7 +409,9 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     for (int p = sl; p < N * N; p += G) {
       const int r = p >> LOG2N, c = p & (N - 1);
       int pv;
-      if (INTER && final_trip && ii.is_inter) {
+      if (INTER && final_trip && ii.is_inter && mc_in_lds) {
+        pv = S->blkpix[po + p];
+      } else if (INTER && final_trip && ii.is_inter) {
         const int ss = plane0 > 0;
         const PIX *rp = static_cast<const PIX *>(ii.ref) + poff;
         // lastX / lastY of §7.11.3.3: the reference is clamped to the SIGNALLED frame size
@@ -525,10 +587,15 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     if (INTER) {
       // motion search result of this leaf: (cost << 16) | candidate index, cost = SAD + n * (|dx| + |dy|)
       const unsigned long long key = me_best[(by >> 3) * b8_stride + (bx >> 3)];
-      const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
-      const int dyv = idx / nc - R, dxv = idx % nc - R;
-      ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
-      ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
+      if (P.subpel) {  // refined: (SAD << 32) | (u16 mv.row << 16) | u16 mv.col, 1/8 samples
+        ii.mv_row = (int16_t)(key >> 16); ii.mv_col = (int16_t)key;
+        ii.sad_inter = (int)(key >> 32);
+      } else {
+        const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
+        const int dyv = idx / nc - R, dxv = idx % nc - R;
+        ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
+        ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
+      }
     }
     int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
     int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);

@@ -68,7 +68,10 @@ typedef struct {
                                (0 = steepest matrix ... 14; 15 = flat).  Default 0 */
   uint32_t qm_min, qm_max;  /* "--qm-min" / "--qm-max": 0..15, qm_min <= qm_max; av1mi_default_params sets 8 / 15 (the encoder's
                                defaults); the reference's production string uses 1 / 15 */
-  uint32_t reserved[1];
+  uint32_t subpel;          /* inter frames: 1 = quarter-sample motion vectors (the full search's winner refined over its half- and then
+                               quarter-sample neighbours) predicted with the 8-tap EIGHTTAP filter; 0 (default) = whole-sample
+                               vectors, frame filter BILINEAR */
+  uint32_t reserved[2];
 } av1mi_params;
 
 typedef struct {

@@ -61,6 +61,9 @@ typedef struct {
   int enable_lr;          /* 1: loop restoration on luma: Wiener, 64x64 units, per-unit choice among {off, 3 filters} */
   int true_width, true_height; /* internal: set by the encoder when it runs at the padded size (0 = same as width/height) */
   int me_range;           /* inter frames: integer-pel full search, |dx|,|dy| <= me_range (default 8) */
+  int subpel;             /* inter frames: 0 = whole-sample vectors, frame filter BILINEAR (chroma of odd vectors only); 1 = quarter-sample
+                             vectors (half- then quarter-sample refinement of the full search) and the EIGHTTAP filter
+                              */
   /* quantiser matrices (§5.9.12 using_qmatrix, §7.12.3; the reference runs `--enable-qm 1
    * --qm-min 1 --qm-max 15`, av1an.rs:14): level 0 (steepest) .. 14, 15 = flat (no matrix for that plane) */
   int enable_qm;          /* 1: using_qmatrix */

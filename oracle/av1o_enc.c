@@ -97,6 +97,7 @@ void av1o_default_config(Av1oConfig *c, int w, int h, int bit_depth) {
   c->cdef_damping = 5;
   c->mode_mask = 0x0007; /* DC, V, H */
   c->me_range = 8;
+  c->subpel = 0;
   c->enable_qm = 0;
   c->qm_y = c->qm_uv = 15;
   c->fuzz_density = 8;
@@ -242,7 +243,7 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, int is_int
   if (is_inter) {
     bw_put(&b, 0, 1); /* allow_high_precision_mv */
     bw_put(&b, 0, 1); /* is_filter_switchable */
-    bw_put(&b, 3, 2); /* interpolation_filter = BILINEAR */
+    bw_put(&b, cfg->subpel ? 0 : 3, 2); /* interpolation_filter: EIGHTTAP (0) with sub-sample vectors, else BILINEAR (3) */
     bw_put(&b, 0, 1); /* is_motion_mode_switchable */
     /* use_ref_frame_mvs: not coded (enable_ref_frame_mvs = 0) */
   }
@@ -821,52 +822,66 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
 /* ------------------------------------------------------------------ inter prediction §7.11.3 */
 typedef struct { int row, col; } Mv; /* 1/8 luma samples */
 
-/* Block inter prediction (§7.11.3.4) for an unscaled single reference with the frame-level BILINEAR filter
- * (Subpel_Filters[3][p] = {0,0,0,128-8p,8p,0,0,0}), rounding InterRound0 = 3, InterRound1 = 11 (8/10 bit,
- * not compound).  Position of sample (i, j) in 1/16 plane samples: ((x0 + j) << 4) + mv_q4, mv_q4 =
- * (2*mv) >> subsampling (§7.11.3.3 with xScale = 1 << 14).  Reference samples are clamped to the frame. */
-static void predict_inter(const Enc *e, int plane, int x0, int y0, int n, Mv mv, uint16_t *dst, int dstride) {
-  const Av1oFrame *ref = e->ref;
+/* Block inter prediction (§7.11.3.4) for an unscaled single reference, frame-level interpolation filter:
+ * BILINEAR (Subpel_Filters[3][p] = {0,0,0,128-8p,8p,0,0,0}) when cfg->subpel == 0, EIGHTTAP (Subpel_Filters[0], and
+ * Subpel_Filters[4] - four taps - along a dimension of at most 4 samples) when cfg->subpel == 1.  Rounding InterRound0 = 3,
+ * InterRound1 = 11 (8/10 bit, not compound).  Position of sample (i, j) in 1/16 plane samples: ((x0 + j) << 4) + mv_q4,
+ * mv_q4 = (2*mv) >> subsampling (§7.11.3.3 with xScale = 1 << 14).  Reference samples are clamped to [0, last]. */
+static void filter_taps(int eighttap, int n, int phase, int *f) {
+  int t;
+  if (eighttap) for (t = 0; t < 8; t++) f[t] = av1_subpel_filters[n <= 4][phase][t];
+  else for (t = 0; t < 8; t++) f[t] = t == 3 ? 128 - 8 * phase : (t == 4 ? 8 * phase : 0);
+}
+
+static void interp_block(const Av1oFrame *ref, int plane, int last_x, int last_y, int x0, int y0, int n, Mv mv, int eighttap, int bd,
+                         uint16_t *dst, int dstride) {
   const int ss = plane > 0;
-  /* lastX / lastY of §7.11.3.3: the reference is clamped to the SIGNALLED frame size */
-  const int last_x = ((true_w(e->cfg) + ss) >> ss) - 1, last_y = ((true_h(e->cfg) + ss) >> ss) - 1;
   const int mvq_r = (2 * mv.row) >> ss, mvq_c = (2 * mv.col) >> ss;
   const int py = (y0 << 4) + mvq_r, px = (x0 << 4) + mvq_c;
   const int iy = py >> 4, fy = py & 15, ix = px >> 4, fx = px & 15;
-  const int bd = e->cfg->bit_depth;
   int32_t *mid = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 7) * n);
+  int fh[8], fv[8];
   int r, c, t;
+  filter_taps(eighttap, n, fx, fh);
+  filter_taps(eighttap, n, fy, fv);
   for (r = 0; r < n + 7; r++)
     for (c = 0; c < n; c++) {
       int yy = iy + r - 3, sum = 0;
       yy = yy < 0 ? 0 : (yy > last_y ? last_y : yy);
       for (t = 0; t < 8; t++) {
-        int f = t == 3 ? 128 - 8 * fx : (t == 4 ? 8 * fx : 0);
         int xx = ix + c + t - 3;
         xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
-        sum += f * (int)ref->p[plane][(size_t)yy * ref->stride[plane] + xx];
+        sum += fh[t] * (int)ref->p[plane][(size_t)yy * ref->stride[plane] + xx];
       }
       mid[r * n + c] = (sum + 4) >> 3; /* Round2(sum, InterRound0) */
     }
   for (r = 0; r < n; r++)
     for (c = 0; c < n; c++) {
       int sum = 0, v;
-      for (t = 0; t < 8; t++) {
-        int f = t == 3 ? 128 - 8 * fy : (t == 4 ? 8 * fy : 0);
-        sum += f * mid[(r + t) * n + c];
-      }
+      for (t = 0; t < 8; t++) sum += fv[t] * mid[(r + t) * n + c];
       v = (sum + 1024) >> 11; /* Round2(sum, InterRound1) */
       dst[r * dstride + c] = (uint16_t)(v < 0 ? 0 : (v > (1 << bd) - 1 ? (1 << bd) - 1 : v));
     }
   free(mid);
 }
 
-/* Integer-pel full search on luma, encoder-side, OPEN LOOP: the search compares the source block
+static void predict_inter(const Enc *e, int plane, int x0, int y0, int n, Mv mv, uint16_t *dst, int dstride) {
+  const int ss = plane > 0;
+  /* lastX / lastY of §7.11.3.3: the reference is clamped to the SIGNALLED frame size */
+  interp_block(e->ref, plane, ((true_w(e->cfg) + ss) >> ss) - 1, ((true_h(e->cfg) + ss) >> ss) - 1, x0, y0, n, mv, e->cfg->subpel,
+               e->cfg->bit_depth, dst, dstride);
+}
+
+/* Full search on luma, encoder-side, OPEN LOOP: the search compares the source block
  * with the previous SOURCE frame (e->prev_src), not with the reconstruction it will be predicted from - the vectors of
  * a whole chunk can then be searched up front, off the frame-by-frame reconstruction chain; its SAD
- * is also what the inter/intra decision uses.  cost = SAD(source, previous source displaced) +
+ * is also what the inter/intra decision uses.  Integer stage: cost = SAD(source, previous source displaced) +
  * n * (|dx| + |dy|); candidates keep the reference block within 16 samples of the frame (so no motion
  * vector ever needs the clamping of §7.10.2.14); ties go to the first candidate in (dy, dx) raster order.
+ * cfg->subpel: two refinement stages around the winner, the 8 half-sample neighbours and then the 8 quarter-sample
+ * neighbours of the stage's best, each interpolated from the previous source with the prediction's own filter
+ * (EIGHTTAP, both roundings); cost = SAD + (n * (|mv.row| + |mv.col|) >> 3) (the same penalty in 1/8 units); a candidate
+ * replaces the best only when strictly cheaper, visited in (row, col) raster order; same 16-sample bound.
  * Returns the SAD of the chosen vector. */
 static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
   const int R = e->cfg->me_range, W = e->cfg->width, H = e->cfg->height;
@@ -893,6 +908,29 @@ static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
       cost = (long)sad + (long)n * (abs(dx) + abs(dy));
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_sad = sad; best->row = dy * 8; best->col = dx * 8; }
     }
+  if (e->cfg->subpel) {
+    uint16_t *pred = (uint16_t *)malloc(sizeof(uint16_t) * n * n);
+    int step;
+    for (step = 4; step >= 2; step >>= 1) {
+      const Mv base = *best;
+      int dr, dc;
+      for (dr = -step; dr <= step; dr += step)
+        for (dc = -step; dc <= step; dc += step) {
+          Mv mv;
+          int sad = 0;
+          long cost;
+          if (!dr && !dc) continue;
+          mv.row = base.row + dr; mv.col = base.col + dc;
+          if (x * 8 + mv.col < -128 || (x + n) * 8 + mv.col > (W + 16) * 8 || y * 8 + mv.row < -128 || (y + n) * 8 + mv.row > (H + 16) * 8) continue;
+          interp_block(e->prev_src, 0, W - 1, H - 1, x, y, n, mv, 1, e->cfg->bit_depth, pred, n);
+          for (i = 0; i < n; i++)
+            for (j = 0; j < n; j++) sad += abs((int)src[i * sstr + j] - (int)pred[i * n + j]);
+          cost = (long)sad + (((long)n * (abs(mv.row) + abs(mv.col))) >> 3);
+          if (cost < best_cost) { best_cost = cost; best_sad = sad; *best = mv; }
+        }
+    }
+    free(pred);
+  }
   return best_sad;
 }
 
@@ -1172,6 +1210,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
           default: {
             int R = cfg->me_range, dx = (int)(fuzz_rand(e) % (unsigned)(2 * R + 1)) - R, dy = (int)(fuzz_rand(e) % (unsigned)(2 * R + 1)) - R;
             mv.row = dy * 8; mv.col = dx * 8;
+            if (cfg->subpel) { unsigned q = fuzz_rand(e); mv.row += 2 * (int)(q & 3); mv.col += 2 * (int)((q >> 2) & 3); }
           }
         }
       } else {

@@ -267,7 +267,8 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
         if m["width"] % 8 or m["height"] % 8:
             continue   # (covered by test_sizes_that_are_not_multiples_of_8: fixtures here are generated full-size)
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, keyint=240, me_range=cfgk.get("me_range", 8),
-                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0), deblock=cfgk.get("deblock", 0))
+                                 cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0), deblock=cfgk.get("deblock", 0),
+                                 subpel=cfgk.get("subpel", 0))
         if cfgk.get("enable_qm"):
             p.enable_qm, p.qm_min, p.qm_max = 1, cfgk["qm_y"], cfgk["qm_y"]
         frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
@@ -308,6 +309,30 @@ def test_quantiser_matrices_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, cq
         ref, prev = rec, f
     assert list(sizes) == [len(t) for t in tus]
     assert data == b"".join(tus)
+    assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,me,extra", [
+    (64, 64, 8, 3, 5, 8, dict()), (200, 120, 8, 4, 5, 8, dict()), (200, 120, 10, 3, 4, 8, dict(deblock=1)), (136, 136, 8, 3, 3, 8, dict()),
+    (328, 248, 10, 3, 5, 16, dict(enable_lr=1)), (130, 66, 8, 3, 4, 8, dict()), (648, 360, 10, 3, 5, 8, dict(enable_qm=1, qm_min=4, qm_max=4))])
+def test_subsample_motion_vectors_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, me, extra):
+    """subpel = 1: half- then quarter-sample refinement of the full search (EIGHTTAP-interpolated previous source),
+    8-tap motion compensation of luma and chroma, fractional vectors in the candidate list and the NEWMV syntax,
+    interpolation_filter = EIGHTTAP in the frame header - IPPP chunk bit-exact against the oracle."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=700 + w, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=240, me_range=me, subpel=1, **extra)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    kw = dict(min_bs_log2=bs, max_bs_log2=bs, me_range=me, subpel=1, deblock=extra.get("deblock", 0), enable_lr=extra.get("enable_lr", 0))
+    if extra.get("enable_qm"):
+        kw.update(enable_qm=1, qm_y=extra["qm_min"], qm_uv=extra["qm_min"])
+    cfg = oracle.default_config(w, h, bd, **kw)
+    tus, recs = oracle_chunk(oracle, cfg, frames, 240)
+    frac = 0
+    assert list(sizes) == [len(t) for t in tus]
+    off = 0
+    for i, tu in enumerate(tus):
+        assert data[off:off + sizes[i]] == tu, "frame %d" % i
+        off += sizes[i]
     assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
 
 

@@ -317,6 +317,17 @@ def main():
     assert (np.diff(qm[:, 0, 336 + 1023]) <= 0).all(), "higher levels are flatter"
     QM = qm[:, :, :1360]
 
+    # ---- interpolation filters (spec Subpel_Filters[0] = EIGHTTAP regular and [4] = its 4-tap form for w <= 4) ----
+    SUBPEL = []
+    for second in ((0, 2, -6, 126, 8, -2, 0, 0), (0, 0, -4, 126, 8, -2, 0, 0)):
+        offs = blob.find_all(struct.pack("<16h", 0, 0, 0, 128, 0, 0, 0, 0, *second))
+        assert offs, second
+        tabs = [blob.s16(o, 128).reshape(16, 8) for o in offs]
+        assert all((t == tabs[0]).all() for t in tabs), "all copies agree"
+        t = tabs[0]
+        assert (t.sum(axis=1) == 128).all() and (t[1:] == t[1:][::-1, ::-1]).all(), "taps sum to 128, phase p mirrors 16 - p"
+        SUBPEL.append(t)
+
     # ---- emit ---------------------------------------------------------------------------
     out = []
     w = out.append
@@ -353,6 +364,16 @@ def main():
             w("  " + ", ".join("%d" % x for x in v[i:i + 16]) + ",")
         w("};")
         w("")
+    w("/* Subpel_Filters: [0] = EIGHTTAP (regular), [1] = the 4-tap filter used for block widths/heights <= 4; [phase 1/16][tap] */")
+    w("#define AV1_SUBPEL_FILTERS_INIT { \\")
+    for t in SUBPEL:
+        w("  { \\")
+        for row in t:
+            w("    { " + ", ".join("%d" % int(x) for x in row) + " }, \\")
+        w("  }, \\")
+    w("}")
+    w("static const int16_t av1_subpel_filters[2][16][8] = AV1_SUBPEL_FILTERS_INIT;")
+    w("")
     w("/* Quantizer_Matrix[level 0..14][plane > 0][4x4 | 8x8 | 16x16 | 32x32] (level 15 = flat, no table) */")
     w("#define AV1_QM_4X4 0")
     w("#define AV1_QM_8X8 16")

@@ -100,6 +100,12 @@ SEQ_CASES = [
     ("pfuzz_deblock_bs6_odd", 130, 134, 10, 53, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=4, deblock=2, lf_level=(30, 30, 30, 30), lf_sharpness=0)),
     ("p200x120_qm6", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, enable_qm=1, qm_y=6, qm_uv=6)),
     ("pfuzz_qm_y2_uv12_bs4_10b", 200, 120, 10, 27, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_qm=1, qm_y=2, qm_uv=12, fuzz_modes=8)),
+    # quarter-sample vectors + EIGHTTAP interpolation (subpel = 1): decision-driven and fuzzed (random fractional vectors)
+    ("p200x120_subpel", 200, 120, 8, 1080, 4, dict(min_bs_log2=5, max_bs_log2=5, subpel=1)),
+    ("p328x248_subpel_bs4_10b_me16", 328, 248, 10, 7, 3, dict(min_bs_log2=4, max_bs_log2=4, subpel=1, me_range=16, deblock=1)),
+    ("pfuzz_subpel_bs3", 200, 120, 8, 28, 3, dict(min_bs_log2=3, max_bs_log2=3, subpel=1, fuzz_modes=9)),
+    ("pfuzz_subpel_bs6_10b_odd", 130, 134, 10, 29, 3, dict(min_bs_log2=6, max_bs_log2=6, subpel=1, fuzz_modes=4)),
+    ("pfuzz_subpel_onetile_bs5", 264, 200, 8, 30, 3, dict(min_bs_log2=5, max_bs_log2=5, subpel=1, fuzz_modes=6, tile_w_sb=64, tile_h_sb=64, enable_lr=1)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
