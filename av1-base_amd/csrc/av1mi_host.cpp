@@ -27,8 +27,8 @@
 extern "C" {
 hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
                               const unsigned long long *me_best, hipStream_t s);
-hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
-                                      int count, hipStream_t stream);
+hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, const unsigned long long *best, unsigned long long *refined,
+                                      int me_range, int frame0, int count, hipStream_t stream);
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
                                       int count, hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
@@ -407,6 +407,7 @@ struct av1mi_ctx {
   unsigned long long *d_me = nullptr;  // motion search results per 8x8 unit per frame
   void *d_stage = nullptr;             // sizes that are not multiples of 8: frames in the caller's tight layout (input / reconstruction out)
   void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
+  unsigned long long *d_me_sub = nullptr;  // sub-sample refinement: refined [frame][8x8 unit] keys (me_kernel.hip)
   Av1miQmEntry *d_qm = nullptr;        // quantiser-matrix steps (Av1miDevParams::qm_tab), valid for qm_key = (level, qidx, bit depth)
   std::vector<Av1miQmEntry> h_qm;
   int qm_key = -1;
@@ -440,11 +441,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -498,6 +499,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   }
   if ((r.cw != (int)p.width || r.ch != (int)p.height) && !c->d_stage)
     HIPCHK(c, hipMalloc(&c->d_stage, c->cap_frames * (size_t)p.width * p.height * 3 / 2 * bps));
+  if (p.subpel && !c->d_me_sub)   // output of the sub-sample refinement
+    HIPCHK(c, hipMalloc((void **)&c->d_me_sub, (size_t)c->cap_frames * (r.cw / 8) * (r.ch / 8) * 8));
   if (p.enable_lr && !c->d_cd) {
     const size_t nf = c->cap_frames;
     HIPCHK(c, hipMalloc(&c->d_cd, nf * frame_samples * bps));
@@ -796,7 +799,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     for (uint32_t f = 0; f < n_frames; f++) {
       if (!av1mi_frame_is_inter(P, (int)f)) continue;
       HIPCHK(c, av1mi_launch_motion_search(&P, d_src, c->d_me, P.me_range, (int)f, 1, c->stream2));
-      if (P.subpel) HIPCHK(c, av1mi_launch_subpel_refine(&P, d_src, c->d_me, P.me_range, (int)f, 1, c->stream2));
+      if (P.subpel) HIPCHK(c, av1mi_launch_subpel_refine(&P, d_src, c->d_me, c->d_me_sub, P.me_range, (int)f, 1, c->stream2));
       HIPCHK(c, hipEventRecord(c->me_ev[f], c->stream2));
     }
     for (uint32_t f = 0; f < n_frames; f++) {
@@ -808,7 +811,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, nullptr, nullptr, s));
       } else {
         const uint8_t *reff = (const uint8_t *)c->d_fin + (f - 1) * fbytes;
-        unsigned long long *mef = c->d_me + f * nb8;
+        unsigned long long *mef = (P.subpel ? c->d_me_sub : c->d_me) + f * nb8;
         HIPCHK(c, hipStreamWaitEvent(s, c->me_ev[f], 0));
         HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, reff, mef, s));
       }

@@ -141,43 +141,41 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
 // (EIGHTTAP, Round2 by 3 after the horizontal pass, by 11 and a clamp after the vertical one); cost = SAD +
 // (n * (|mv.row| + |mv.col|) >> 3); it replaces the best only when strictly cheaper, candidates in (row, col) raster
 // order; the displaced block stays within 16 samples of the frame.
-// One wave per 8x8 unit that is the origin of a leaf block (the others leave at once).  The wave stages the
-// (n + 8)^2 window of the reference around the integer winner in LDS once (coordinates clamped to the frame), then
-// per candidate: horizontal pass window -> mid ((n + 7) x n, 16-bit), vertical pass mid -> sample, SAD against the
-// source block in LDS, wave sum.  The result replaces the search's key: (SAD << 32) | (u16 mv.row << 16) | u16 mv.col.
+// One wave per cell of the largest block size (its leaf; the smaller leaves of a cell that straddles the frame edge in
+// turn).  The (n + 8)^2 reference window
+// around the integer winner - every candidate's taps lie inside it - and the source block are staged in LDS once, all
+// loads in flight together.  Per candidate: horizontal pass, a lane = 8 consecutive outputs of a row from 16 window
+// samples read as two 16-byte words (64 multiply-adds per 2 LDS reads); vertical pass, a lane = n^2/64 consecutive
+// outputs of a column from its (n^2/64 + 7) intermediate values; SAD against the source block, wave sum.
+// Output: (cost << 36) | (u16 mv.row << 16) | u16 mv.col per leaf, which is what the recon kernel reads.
 __constant__ int16_t c_subpel_me[2][16][8] = AV1_SUBPEL_FILTERS_INIT;
 
-template <typename PIX>
-__global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, const PIX *__restrict__ frames,
-                                                          unsigned long long *__restrict__ best_all, int frame0, int R) {
-  __shared__ uint16_t win[40 * 40];
-  __shared__ int16_t mid[39 * 32];
-  __shared__ uint16_t srcb[32 * 32];
-  const int f = frame0 + blockIdx.z;
-  if (!av1mi_frame_is_inter(P, f)) return;
-  const int ux = blockIdx.x, uy = blockIdx.y;   // 8x8 unit of the frame
-  const int bsl = leaf_bsl_cell(P, (ux >> 2) * 32, (uy >> 2) * 32, ux & 3, uy & 3);
-  if (!bsl) return;
-  const PIX *src = frames + (size_t)f * P.frame_samples, *ref = src - P.frame_samples;
-  unsigned long long *slot = best_all + (size_t)f * P.b8_rows * P.b8_cols + (size_t)uy * P.b8_cols + ux;
-  const int lane = threadIdx.x;
-  const int n = 1 << bsl, x = ux * 8, y = uy * 8, W = P.width, H = P.height;
-  const int NC = 2 * R + 1;
-  const unsigned long long key = *slot;
-  const int cand = (int)(key & 0xFFFF), dy0 = cand / NC - R, dx0 = cand % NC - R;
-  int best_row = dy0 * 8, best_col = dx0 * 8;
-  long best_cost = (long)(key >> 16);
-  int best_sad = (int)best_cost - n * (iabs(dx0) + iabs(dy0));
-  // window: reference samples (x + dx0 - 4 + j, y + dy0 - 4 + i), i, j < n + 8
-  const int wx = x + dx0 - 4, wy = y + dy0 - 4, ww = n + 8;
-  for (int p = lane; p < ww * ww; p += 64) {
-    const int i = p / ww, j = p - i * ww;
-    int yy = wy + i, xx = wx + j;
-    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-    xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-    win[i * 40 + j] = (uint16_t)ref[(size_t)yy * P.stride_y + xx];
+template <typename PIX, int LOG2N>
+__device__ __forceinline__ void refine_leaf(const Av1miDevParams &P, const PIX *__restrict__ src, const PIX *__restrict__ ref, int x, int y,
+                                            int &best_row, int &best_col, long &best_cost, uint16_t *win, int16_t *mid, uint16_t *srcb) {
+  constexpr int n = 1 << LOG2N, WW = n + 8, WS = n + 16;   // window width, row stride (rows stay 16-byte aligned)
+  constexpr int RPL = n * n / 64;                            // vertical pass: output rows per lane
+  const int lane = threadIdx.x, W = P.width, H = P.height;
+  const int wx = x + (best_col >> 3) - 4, wy = y + (best_row >> 3) - 4;   // window origin (the integer winner is a multiple of 8)
+  {
+    constexpr int TOT = WW * WW, K = (TOT + 63) / 64;
+    uint16_t v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int p = lane + 64 * k, i = p / WW, j = p - i * WW;
+      int yy = wy + i, xx = wx + j;
+      yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+      xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+      v[k] = p < TOT ? (uint16_t)ref[(size_t)yy * P.stride_y + xx] : 0;
+    }
+    uint16_t sv[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++) { const int p = lane + 64 * k; sv[k] = (uint16_t)src[(size_t)(y + (p >> LOG2N)) * P.stride_y + x + (p & (n - 1))]; }
+#pragma unroll
+    for (int k = 0; k < K; k++) { const int p = lane + 64 * k, i = p / WW, j = p - i * WW; if (p < TOT) win[i * WS + j] = v[k]; }
+#pragma unroll
+    for (int k = 0; k < RPL; k++) srcb[lane + 64 * k] = sv[k];
   }
-  for (int p = lane; p < n * n; p += 64) srcb[p] = (uint16_t)src[(size_t)(y + p / n) * P.stride_y + x + (p & (n - 1))];
   __syncthreads();
   const int maxv = (1 << P.bit_depth) - 1;
   for (int step = 4; step >= 2; step >>= 1) {
@@ -186,46 +184,110 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
       if (k == 4) continue;
       const int mr = base_row + (k / 3 - 1) * step, mc = base_col + (k % 3 - 1) * step;
       if (x * 8 + mc < -128 || (x + n) * 8 + mc > (W + 16) * 8 || y * 8 + mr < -128 || (y + n) * 8 + mr > (H + 16) * 8) continue;
-      // position of the block's first sample in 1/16 samples; integer part relative to the window origin
       const int px = (x << 4) + 2 * mc, py = (y << 4) + 2 * mr;
       const int ix = (px >> 4) - 3 - wx, iy = (py >> 4) - 3 - wy, fx = px & 15, fy = py & 15;   // 0 <= ix, iy <= 1
-      const int16_t *fh = c_subpel_me[0][fx], *fv = c_subpel_me[0][fy];
-      for (int p = lane; p < (n + 7) * n; p += 64) {
-        const int r = p / n, c = p - r * n;
-        const uint16_t *wp = win + (iy + r) * 40 + ix + c;
-        int sum = 0;
+      int fh[8], fv[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) sum += fh[t] * (int)wp[t];
-        mid[p] = (int16_t)((sum + 4) >> 3);
+      for (int t = 0; t < 8; t++) { fh[t] = c_subpel_me[0][fx][t]; fv[t] = c_subpel_me[0][fy][t]; }
+      // horizontal pass: task = (row r of mid, segment of 8 outputs)
+      constexpr int SEGS = n / 8, TASKS = (n + 7) * SEGS;
+      for (int task = lane; task < TASKS; task += 64) {
+        const int r = task / SEGS, sg = task - r * SEGS;
+        const uint4 *wp = reinterpret_cast<const uint4 *>(win + (iy + r) * WS + 8 * sg);
+        const uint4 q0 = wp[0], q1 = wp[1];
+        const uint32_t d[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+        int a[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a[2 * i] = (int)(d[i] & 0xFFFF); a[2 * i + 1] = (int)(d[i] >> 16); }
+        int o[8];
+        if (ix) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) { int sum = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) sum += fh[t] * a[1 + j + t];
+            o[j] = (sum + 4) >> 3; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) { int sum = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) sum += fh[t] * a[j + t];
+            o[j] = (sum + 4) >> 3; }
+        }
+        uint4 w;
+        w.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); w.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+        w.z = (uint32_t)(uint16_t)o[4] | ((uint32_t)(uint16_t)o[5] << 16); w.w = (uint32_t)(uint16_t)o[6] | ((uint32_t)(uint16_t)o[7] << 16);
+        *reinterpret_cast<uint4 *>(mid + r * n + 8 * sg) = w;
       }
       __syncthreads();
+      // vertical pass: lane = column c, rows r0 .. r0 + RPL - 1
       int sad = 0;
-      for (int p = lane; p < n * n; p += 64) {
-        const int r = p / n, c = p - r * n;
-        int sum = 0;
+      {
+        const int c = lane & (n - 1), r0 = (lane >> LOG2N) * RPL;
+        int m[RPL + 7];
 #pragma unroll
-        for (int t = 0; t < 8; t++) sum += fv[t] * (int)mid[(r + t) * n + c];
-        int v = (sum + 1024) >> 11;
-        v = v < 0 ? 0 : (v > maxv ? maxv : v);
-        sad += iabs((int)srcb[p] - v);
+        for (int i = 0; i < RPL + 7; i++) m[i] = mid[(r0 + i) * n + c];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+          int sum = 0;
+#pragma unroll
+          for (int t = 0; t < 8; t++) sum += fv[t] * m[j + t];
+          int v = (sum + 1024) >> 11;
+          v = v < 0 ? 0 : (v > maxv ? maxv : v);
+          sad += iabs((int)srcb[(r0 + j) * n + c] - v);
+        }
       }
       for (int o = 32; o > 0; o >>= 1) sad += __shfl_xor(sad, o, 64);
       __syncthreads();
       const long cost = (long)sad + (((long)n * (iabs(mr) + iabs(mc))) >> 3);
-      if (cost < best_cost) { best_cost = cost; best_sad = sad; best_row = mr; best_col = mc; }
+      if (cost < best_cost) { best_cost = cost; best_row = mr; best_col = mc; }
     }
   }
-  if (lane == 0) *slot = ((unsigned long long)(uint32_t)best_sad << 32) | ((unsigned long long)(uint16_t)(int16_t)best_row << 16) | (uint16_t)(int16_t)best_col;
+}
+
+template <typename PIX>
+__global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, const PIX *__restrict__ frames,
+                                                          const unsigned long long *__restrict__ in_all, unsigned long long *__restrict__ out_all,
+                                                          int frame0, int R, int cell_log2) {
+  __shared__ __attribute__((aligned(16))) uint16_t win[40 * 48];
+  __shared__ __attribute__((aligned(16))) int16_t mid[39 * 32];
+  __shared__ uint16_t srcb[32 * 32];
+  const int f = frame0 + blockIdx.z;
+  if (!av1mi_frame_is_inter(P, f)) return;
+  const PIX *src = frames + (size_t)f * P.frame_samples, *ref = src - P.frame_samples;
+  const int NC = 2 * R + 1;
+  // this wave's cell of the largest block size: one leaf inside the frame, a few smaller ones where it straddles the edge
+  const int u = 1 << (cell_log2 - 3);
+  for (int uy = blockIdx.y * u; uy < (int)(blockIdx.y + 1) * u; uy++)
+    for (int ux = blockIdx.x * u; ux < (int)(blockIdx.x + 1) * u; ux++) {
+      const int bsl = leaf_bsl_cell(P, (ux >> 2) * 32, (uy >> 2) * 32, ux & 3, uy & 3);
+      if (!bsl) continue;
+      const size_t slot = (size_t)f * P.b8_rows * P.b8_cols + (size_t)uy * P.b8_cols + ux;
+      const unsigned long long key = in_all[slot];   // the full search's key: (cost << 16) | candidate index
+      const int cand = (int)(key & 0xFFFF);
+      int best_row = (cand / NC - R) * 8, best_col = (cand % NC - R) * 8;
+      long best_cost = (long)(key >> 16);
+      switch (bsl) {
+        case 5: refine_leaf<PIX, 5>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_cost, win, mid, srcb); break;
+        case 4: refine_leaf<PIX, 4>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_cost, win, mid, srcb); break;
+        default: refine_leaf<PIX, 3>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_cost, win, mid, srcb); break;
+      }
+      if (threadIdx.x == 0)
+        out_all[slot] = ((unsigned long long)best_cost << 36) | ((unsigned long long)(uint16_t)(int16_t)best_row << 16) | (uint16_t)(int16_t)best_col;
+    }
 }
 
 }  // namespace
 
-// Refines the vectors of frames [frame0, frame0 + count) in place (after av1mi_launch_motion_search on the same stream).
-extern "C" hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range,
-                                                 int frame0, int count, hipStream_t stream) {
-  dim3 grid(P->b8_cols, P->b8_rows, count);
-  if (P->bit_depth == 8) hipLaunchKernelGGL((subpel_refine_kernel<uint8_t>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, me_range);
-  else hipLaunchKernelGGL((subpel_refine_kernel<uint16_t>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, me_range);
+// Refines the vectors of frames [frame0, frame0 + count): `best` = the full search's keys (av1mi_launch_motion_search on the
+// same stream before), `refined` = same layout, what the recon kernel reads with subpel = 1.
+extern "C" hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, const unsigned long long *best,
+                                                 unsigned long long *refined, int me_range, int frame0, int count, hipStream_t stream) {
+  // one wave per cell of the largest block size (every wave has work, and consecutive workgroups - which the dispatcher deals
+  // round-robin to the 8 XCDs - are all active: a wave per 8x8 unit left 6 of 8 XCDs without a single leaf)
+  const int g = P->max_bs_log2 > 5 ? 5 : P->max_bs_log2, cell = 1 << g;
+  dim3 grid((P->width + cell - 1) / cell, (P->height + cell - 1) / cell, count);
+  if (P->bit_depth == 8) hipLaunchKernelGGL((subpel_refine_kernel<uint8_t>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, refined, frame0, me_range, g);
+  else hipLaunchKernelGGL((subpel_refine_kernel<uint16_t>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, refined, frame0, me_range, g);
   return hipGetLastError();
 }
 

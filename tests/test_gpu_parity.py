@@ -546,6 +546,7 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
     every reconstruction bit-exact against the oracle."""
     # AV1MI_SWEEP_ITERS / AV1MI_SWEEP_SEED: longer hunts during bring-up (the default sweep found the level-buffer overlap)
     rng = np.random.default_rng(int(os.environ.get("AV1MI_SWEEP_SEED", "2026")))
+    rng2 = np.random.default_rng(int(os.environ.get("AV1MI_SWEEP_SEED", "2026")) + 1)   # later additions: keeps the earlier cases as they were
     for it in range(int(os.environ.get("AV1MI_SWEEP_ITERS", "14"))):
         w, h = int(rng.integers(1, 30)) * 8, int(rng.integers(1, 22)) * 8
         if rng.integers(0, 3) == 0:   # every third case: an even size that is not a multiple of 8
@@ -562,12 +563,18 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
         tsb = int(rng.choice([1, 1, 2]))
         n = int(rng.integers(1, 4))
         db = int(rng.integers(0, 2))
+        sp = int(rng2.integers(0, 2))
+        qm = int(rng2.integers(0, 2))
+        qmin = int(rng2.integers(0, 16))
+        qmax = int(rng2.integers(qmin, 16))
         big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=3000 + it, t=t) for t in range(n)]
         frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
         p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
-                                 enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb, deblock=db)
+                                 enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb, deblock=db, subpel=sp, enable_qm=qm, qm_min=qmin, qm_max=qmax)
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+        qml = oracle.qm_level(av1mi.cq_to_qindex(cq), qmin, qmax)
         cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq), mode_mask=mask, deblock=db,
+                                    subpel=sp, enable_qm=qm, qm_y=qml, qm_uv=qml,
                                     disable_cdf_update=0 if cdf else 1, me_range=me, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb,
                                     film_grain=1 if fg else 0, fg_y_scaling=2 * fg, fg_c_scaling=fg)
         tus, recs, ref, prev = [], [], None, None
@@ -578,7 +585,7 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
             tus.append(tu)
             recs.append(rec)
             ref, prev = rec, f
-        desc = dict(it=it, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db)
+        desc = dict(it=it, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db, sp=sp, qm=qm, qmin=qmin, qmax=qmax)
         assert list(sizes) == [len(t) for t in tus], desc
         assert data == b"".join(tus), desc
         fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
