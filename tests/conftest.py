@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _watchdog():
+    """A test that stops making progress (a deadlocked worker thread, a kernel that never drains) ends the run with every
+    thread's stack on stderr after 5 minutes instead of hanging the box until the runner's own limit."""
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=True)
+    yield
+    faulthandler.cancel_dump_traceback_later()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import av1o
