@@ -138,21 +138,34 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
 // Sub-sample refinement (subpel = 1; oracle/av1o_enc.c motion_search, second half).
 // Around the full search's winner: the 8 half-sample neighbours, then the 8 quarter-sample neighbours of that stage's
 // best.  A candidate is the block interpolated from the previous SOURCE frame with the prediction's own filter
-// (EIGHTTAP, Round2 by 3 after the horizontal pass, by 11 and a clamp after the vertical one); cost = SAD +
-// (n * (|mv.row| + |mv.col|) >> 3); it replaces the best only when strictly cheaper, candidates in (row, col) raster
-// order; the displaced block stays within 16 samples of the frame.
+// (EIGHTTAP, Round2 by 3 after the horizontal pass, by 11 and a clamp after the vertical one); cost = SATD (sum of the
+// absolute 8x8 Hadamard coefficients of the difference, >> 3) + (n * (|mv.row| + |mv.col|) >> 3), the integer winner
+// re-costed the same way first; a candidate replaces the best only when strictly cheaper, candidates in (row, col)
+// raster order; the displaced block stays within 16 samples of the frame.
 // One wave per cell of the largest block size (its leaf; the smaller leaves of a cell that straddles the frame edge in
 // turn).  The (n + 8)^2 reference window
 // around the integer winner - every candidate's taps lie inside it - and the source block are staged in LDS once, all
 // loads in flight together.  Per candidate: horizontal pass, a lane = 8 consecutive outputs of a row from 16 window
 // samples read as two 16-byte words (64 multiply-adds per 2 LDS reads); vertical pass, a lane = n^2/64 consecutive
 // outputs of a column from its (n^2/64 + 7) intermediate values; SAD against the source block, wave sum.
-// Output: (cost << 36) | (u16 mv.row << 16) | u16 mv.col per leaf, which is what the recon kernel reads.
+// The Hadamard transform runs as butterflies (24 additions per 8 values, rows through LDS, then columns): as a dense
+// product H X H^T it would be 2 x 512 multiply-adds per sub-block, and the matrix cores' integer path takes 8-bit operands
+// (the difference has 11 bits), so MFMA has nothing to offer here.
+// Output: (SAD << 36) | (u16 mv.row << 16) | u16 mv.col per leaf, which is what the recon kernel reads.
 __constant__ int16_t c_subpel_me[2][16][8] = AV1_SUBPEL_FILTERS_INIT;
+
+__device__ __forceinline__ void hadamard8(int *v) {
+  int t[8];
+  t[0] = v[0] + v[4]; t[4] = v[0] - v[4]; t[1] = v[1] + v[5]; t[5] = v[1] - v[5]; t[2] = v[2] + v[6]; t[6] = v[2] - v[6]; t[3] = v[3] + v[7]; t[7] = v[3] - v[7];
+  v[0] = t[0] + t[2]; v[2] = t[0] - t[2]; v[1] = t[1] + t[3]; v[3] = t[1] - t[3]; v[4] = t[4] + t[6]; v[6] = t[4] - t[6]; v[5] = t[5] + t[7]; v[7] = t[5] - t[7];
+  t[0] = v[0] + v[1]; t[1] = v[0] - v[1]; t[2] = v[2] + v[3]; t[3] = v[2] - v[3]; t[4] = v[4] + v[5]; t[5] = v[4] - v[5]; t[6] = v[6] + v[7]; t[7] = v[6] - v[7];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = t[i];
+}
 
 template <typename PIX, int LOG2N>
 __device__ __forceinline__ void refine_leaf(const Av1miDevParams &P, const PIX *__restrict__ src, const PIX *__restrict__ ref, int x, int y,
-                                            int &best_row, int &best_col, long &best_cost, uint16_t *win, int16_t *mid, uint16_t *srcb) {
+                                            int &best_row, int &best_col, int &best_sad, uint16_t *win, int16_t *mid, uint16_t *srcb, int16_t *dif) {
   constexpr int n = 1 << LOG2N, WW = n + 8, WS = n + 16;   // window width, row stride (rows stay 16-byte aligned)
   constexpr int RPL = n * n / 64;                            // vertical pass: output rows per lane
   const int lane = threadIdx.x, W = P.width, H = P.height;
@@ -178,11 +191,13 @@ __device__ __forceinline__ void refine_leaf(const Av1miDevParams &P, const PIX *
   }
   __syncthreads();
   const int maxv = (1 << P.bit_depth) - 1;
-  for (int step = 4; step >= 2; step >>= 1) {
+  long best_cost = 0;
+  // step 8 = the integer winner itself, re-costed in SATD (phase 0: the filters copy); then half and quarter samples
+  for (int step = 8; step >= 2; step >>= 1) {
     const int base_row = best_row, base_col = best_col;
     for (int k = 0; k < 9; k++) {
-      if (k == 4) continue;
-      const int mr = base_row + (k / 3 - 1) * step, mc = base_col + (k % 3 - 1) * step;
+      if ((k == 4) != (step == 8)) continue;
+      const int mr = base_row + (step == 8 ? 0 : (k / 3 - 1) * step), mc = base_col + (step == 8 ? 0 : (k % 3 - 1) * step);
       if (x * 8 + mc < -128 || (x + n) * 8 + mc > (W + 16) * 8 || y * 8 + mr < -128 || (y + n) * 8 + mr > (H + 16) * 8) continue;
       const int px = (x << 4) + 2 * mc, py = (y << 4) + 2 * mr;
       const int ix = (px >> 4) - 3 - wx, iy = (py >> 4) - 3 - wy, fx = px & 15, fy = py & 15;   // 0 <= ix, iy <= 1
@@ -233,13 +248,43 @@ __device__ __forceinline__ void refine_leaf(const Av1miDevParams &P, const PIX *
           for (int t = 0; t < 8; t++) sum += fv[t] * m[j + t];
           int v = (sum + 1024) >> 11;
           v = v < 0 ? 0 : (v > maxv ? maxv : v);
-          sad += iabs((int)srcb[(r0 + j) * n + c] - v);
+          const int d = (int)srcb[(r0 + j) * n + c] - v;
+          sad += iabs(d);
+          dif[(r0 + j) * n + c] = (int16_t)d;
         }
       }
-      for (int o = 32; o > 0; o >>= 1) sad += __shfl_xor(sad, o, 64);
       __syncthreads();
-      const long cost = (long)sad + (((long)n * (iabs(mr) + iabs(mc))) >> 3);
-      if (cost < best_cost) { best_cost = cost; best_row = mr; best_col = mc; }
+      // SATD: 8x8 Hadamard of the difference, rows (8 values of a row of a sub-block per task, written back), then
+      // columns (absolute sum); n^2/64 sub-blocks x 8 tasks each
+      constexpr int NB = n / 8, HT = NB * NB * 8;
+      for (int task = lane; task < HT; task += 64) {
+        const int b = task >> 3, i = task & 7;
+        int16_t *rowp = dif + ((b / NB) * 8 + i) * n + (b % NB) * 8;
+        const uint4 q = *reinterpret_cast<const uint4 *>(rowp);
+        int v[8] = { (int16_t)(q.x & 0xFFFF), (int16_t)(q.x >> 16), (int16_t)(q.y & 0xFFFF), (int16_t)(q.y >> 16),
+                     (int16_t)(q.z & 0xFFFF), (int16_t)(q.z >> 16), (int16_t)(q.w & 0xFFFF), (int16_t)(q.w >> 16) };
+        hadamard8(v);
+        uint4 w;
+        w.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16); w.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+        w.z = (uint32_t)(uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16); w.w = (uint32_t)(uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
+        *reinterpret_cast<uint4 *>(rowp) = w;
+      }
+      __syncthreads();
+      int satd = 0;
+      for (int task = lane; task < HT; task += 64) {
+        const int b = task >> 3, j = task & 7;
+        const int16_t *colp = dif + (b / NB) * 8 * n + (b % NB) * 8 + j;
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = colp[i * n];
+        hadamard8(v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) satd += iabs(v[i]);
+      }
+      for (int o = 32; o > 0; o >>= 1) { sad += __shfl_xor(sad, o, 64); satd += __shfl_xor(satd, o, 64); }
+      __syncthreads();
+      const long cost = (long)(satd >> 3) + (((long)n * (iabs(mr) + iabs(mc))) >> 3);
+      if (step == 8 || cost < best_cost) { best_cost = cost; best_sad = sad; best_row = mr; best_col = mc; }
     }
   }
 }
@@ -251,6 +296,7 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
   __shared__ __attribute__((aligned(16))) uint16_t win[40 * 48];
   __shared__ __attribute__((aligned(16))) int16_t mid[39 * 32];
   __shared__ uint16_t srcb[32 * 32];
+  __shared__ __attribute__((aligned(16))) int16_t dif[32 * 32];
   const int f = frame0 + blockIdx.z;
   if (!av1mi_frame_is_inter(P, f)) return;
   const PIX *src = frames + (size_t)f * P.frame_samples, *ref = src - P.frame_samples;
@@ -265,14 +311,14 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
       const unsigned long long key = in_all[slot];   // the full search's key: (cost << 16) | candidate index
       const int cand = (int)(key & 0xFFFF);
       int best_row = (cand / NC - R) * 8, best_col = (cand % NC - R) * 8;
-      long best_cost = (long)(key >> 16);
+      int best_sad = 0;
       switch (bsl) {
-        case 5: refine_leaf<PIX, 5>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_cost, win, mid, srcb); break;
-        case 4: refine_leaf<PIX, 4>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_cost, win, mid, srcb); break;
-        default: refine_leaf<PIX, 3>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_cost, win, mid, srcb); break;
+        case 5: refine_leaf<PIX, 5>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_sad, win, mid, srcb, dif); break;
+        case 4: refine_leaf<PIX, 4>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_sad, win, mid, srcb, dif); break;
+        default: refine_leaf<PIX, 3>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_sad, win, mid, srcb, dif); break;
       }
       if (threadIdx.x == 0)
-        out_all[slot] = ((unsigned long long)best_cost << 36) | ((unsigned long long)(uint16_t)(int16_t)best_row << 16) | (uint16_t)(int16_t)best_col;
+        out_all[slot] = ((unsigned long long)(uint32_t)best_sad << 36) | ((unsigned long long)(uint16_t)(int16_t)best_row << 16) | (uint16_t)(int16_t)best_col;
     }
 }
 

@@ -587,9 +587,9 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     if (INTER) {
       // motion search result of this leaf: (cost << 16) | candidate index, cost = SAD + n * (|dx| + |dy|)
       const unsigned long long key = me_best[(by >> 3) * b8_stride + (bx >> 3)];
-      if (P.subpel) {  // refined (me_kernel.hip): (cost << 36) | (u16 mv.row << 16) | u16 mv.col, 1/8 samples
+      if (P.subpel) {  // refined (me_kernel.hip): (SAD << 36) | (u16 mv.row << 16) | u16 mv.col, 1/8 samples
         ii.mv_row = (int16_t)(key >> 16); ii.mv_col = (int16_t)key;
-        ii.sad_inter = (int)(key >> 36) - ((n * ((ii.mv_row < 0 ? -ii.mv_row : ii.mv_row) + (ii.mv_col < 0 ? -ii.mv_col : ii.mv_col))) >> 3);
+        ii.sad_inter = (int)(key >> 36);
       } else {
         const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
         const int dyv = idx / nc - R, dxv = idx % nc - R;

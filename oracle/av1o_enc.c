@@ -880,9 +880,40 @@ static void predict_inter(const Enc *e, int plane, int x0, int y0, int n, Mv mv,
  * vector ever needs the clamping of §7.10.2.14); ties go to the first candidate in (dy, dx) raster order.
  * cfg->subpel: two refinement stages around the winner, the 8 half-sample neighbours and then the 8 quarter-sample
  * neighbours of the stage's best, each interpolated from the previous source with the prediction's own filter
- * (EIGHTTAP, both roundings); cost = SAD + (n * (|mv.row| + |mv.col|) >> 3) (the same penalty in 1/8 units); a candidate
- * replaces the best only when strictly cheaper, visited in (row, col) raster order; same 16-sample bound.
- * Returns the SAD of the chosen vector. */
+ * (EIGHTTAP, both roundings); cost = SATD (8x8 Hadamard, block_satd8) + (n * (|mv.row| + |mv.col|) >> 3) (the same
+ * penalty in 1/8 units), the integer winner re-costed the same way; a candidate replaces the best only when strictly
+ * cheaper, visited in (row, col) raster order; same 16-sample bound.
+ * Returns the SAD of the chosen vector (what the inter/intra decision compares). */
+static void hadamard8(int *v) {
+  int t[8];
+  t[0] = v[0] + v[4]; t[4] = v[0] - v[4]; t[1] = v[1] + v[5]; t[5] = v[1] - v[5]; t[2] = v[2] + v[6]; t[6] = v[2] - v[6]; t[3] = v[3] + v[7]; t[7] = v[3] - v[7];
+  v[0] = t[0] + t[2]; v[2] = t[0] - t[2]; v[1] = t[1] + t[3]; v[3] = t[1] - t[3]; v[4] = t[4] + t[6]; v[6] = t[4] - t[6]; v[5] = t[5] + t[7]; v[7] = t[5] - t[7];
+  t[0] = v[0] + v[1]; t[1] = v[0] - v[1]; t[2] = v[2] + v[3]; t[3] = v[2] - v[3]; t[4] = v[4] + v[5]; t[5] = v[4] - v[5]; t[6] = v[6] + v[7]; t[7] = v[6] - v[7];
+  memcpy(v, t, sizeof(t));
+}
+
+/* SATD of the n x n block: sum of the absolute 8x8 Hadamard coefficients (H X H^T, H the +-1 matrix of order 8) of
+ * (a - b) over all 8x8 sub-blocks, >> 3 (SURVEY.md §8a a13 "SATD (8x8 Hadamard) refinement"). */
+static int block_satd8(const uint16_t *a, int as, const uint16_t *b, int bs, int n) {
+  long total = 0;
+  int by, bx, i, j;
+  for (by = 0; by < n; by += 8)
+    for (bx = 0; bx < n; bx += 8) {
+      int m[8][8];
+      for (i = 0; i < 8; i++) {
+        for (j = 0; j < 8; j++) m[i][j] = (int)a[(by + i) * as + bx + j] - (int)b[(by + i) * bs + bx + j];
+        hadamard8(m[i]);
+      }
+      for (j = 0; j < 8; j++) {
+        int v[8];
+        for (i = 0; i < 8; i++) v[i] = m[i][j];
+        hadamard8(v);
+        for (i = 0; i < 8; i++) total += abs(v[i]);
+      }
+    }
+  return (int)(total >> 3);
+}
+
 static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
   const int R = e->cfg->me_range, W = e->cfg->width, H = e->cfg->height;
   const uint16_t *src = e->src->p[0] + (size_t)y * e->src->stride[0] + x;
@@ -911,6 +942,9 @@ static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
   if (e->cfg->subpel) {
     uint16_t *pred = (uint16_t *)malloc(sizeof(uint16_t) * n * n);
     int step;
+    /* the refinement compares SATD: the integer winner's first */
+    interp_block(e->prev_src, 0, W - 1, H - 1, x, y, n, *best, 1, e->cfg->bit_depth, pred, n);
+    best_cost = (long)block_satd8(src, sstr, pred, n, n) + (((long)n * (abs(best->row) + abs(best->col))) >> 3);
     for (step = 4; step >= 2; step >>= 1) {
       const Mv base = *best;
       int dr, dc;
@@ -925,7 +959,7 @@ static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
           interp_block(e->prev_src, 0, W - 1, H - 1, x, y, n, mv, 1, e->cfg->bit_depth, pred, n);
           for (i = 0; i < n; i++)
             for (j = 0; j < n; j++) sad += abs((int)src[i * sstr + j] - (int)pred[i * n + j]);
-          cost = (long)sad + (((long)n * (abs(mv.row) + abs(mv.col))) >> 3);
+          cost = (long)block_satd8(src, sstr, pred, n, n) + (((long)n * (abs(mv.row) + abs(mv.col))) >> 3);
           if (cost < best_cost) { best_cost = cost; best_sad = sad; *best = mv; }
         }
     }
