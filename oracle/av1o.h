@@ -58,7 +58,8 @@ typedef struct {
   int deblock;            /* 1: deblocking filter on, levels picked from the quantiser; 2: levels given below */
   int lf_level[4];        /* loop_filter_level[0..3]: luma vertical edges, luma horizontal, U, V (deblock == 2) */
   int lf_sharpness;
-  int enable_lr;          /* 1: loop restoration on luma: Wiener, 64x64 units, per-unit choice among {off, 3 filters} */
+  int enable_lr;          /* 1: loop restoration on luma: Wiener, 64x64 units, per-unit choice among {off, 3 filters};
+                             2: RESTORE_SWITCHABLE - per unit {off, 3 Wiener filters, 3 self-guided filters (set, weights)} */
   int true_width, true_height; /* internal: set by the encoder when it runs at the padded size (0 = same as width/height) */
   int me_range;           /* inter frames: integer-pel full search, |dx|,|dy| <= me_range (default 8) */
   int subpel;             /* inter frames: 0 = whole-sample vectors, frame filter BILINEAR (chroma of odd vectors only); 1 = quarter-sample
@@ -138,9 +139,14 @@ void av1o_deblock_frame(const Av1oConfig *cfg, Av1oFrame *f, const uint8_t *mi_b
 
 /* ---- loop restoration (av1o_lr.c) */
 typedef struct {
-  int8_t type;            /* 0 RESTORE_NONE, 1 RESTORE_WIENER */
-  int8_t coef[2][3];      /* [pass: 0 vertical, 1 horizontal][tap 0..2] */
+  int8_t type;            /* 0 RESTORE_NONE, 1 RESTORE_WIENER, 2 RESTORE_SGRPROJ (enable_lr == 2 only) */
+  int8_t coef[2][3];      /* Wiener: [pass: 0 vertical, 1 horizontal][tap 0..2] */
+  int8_t sgr_set;         /* self-guided: lr_sgr_set 0..15 */
+  int8_t sgr_xqd[2];      /* LrSgrXqd: weights of the two passes' outputs (w2 = 128 - xqd[0] - xqd[1]) */
 } Av1oLrUnit;
+extern const int av1o_sgr_params[16][4];
+extern const int8_t av1o_sgr_candidates[3][3]; /* { set, xqd0, xqd1 } */
+void av1o_sgr_plane(const Av1oConfig *cfg, const Av1oFrame *pre, const Av1oFrame *cdef, Av1oFrame *out, int set, int w0, int w1);
 extern const int8_t av1o_wiener_candidates[3][3];
 int av1o_lr_units(int size);
 void av1o_lr_frame(const Av1oConfig *cfg, const Av1oFrame *pre, const Av1oFrame *cdef, const Av1oFrame *src, Av1oFrame *out,

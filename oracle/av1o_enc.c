@@ -315,7 +315,7 @@ static size_t frame_header_bits(const Av1oConfig *cfg, const Geom *g, int is_int
     bw_put(&b, (uint32_t)cfg->cdef_uv_sec, 2);
   }
   if (cfg->enable_lr) { /* lr_params() §5.9.20: luma RESTORE_WIENER (lr_type 2), chroma RESTORE_NONE, 64x64 units */
-    bw_put(&b, 2, 2);
+    bw_put(&b, cfg->enable_lr == 2 ? 1 : 2, 2); /* lr_type: 1 -> RESTORE_SWITCHABLE, 2 -> RESTORE_WIENER */
     bw_put(&b, 0, 2);
     bw_put(&b, 0, 2);
     bw_put(&b, 0, 1); /* lr_unit_shift = 0: LoopRestorationSize = 256 >> 2 = 64 (no lr_uv_shift: chroma unused) */
@@ -382,6 +382,7 @@ typedef struct {
   uint16_t inter_tx_set1[2][17], inter_tx_set2[13], inter_tx_set3[4][3];
   uint16_t mv_joint[5];
   uint16_t use_wiener[3];
+  uint16_t restoration_type[4];
   struct {
     uint16_t cls[12], class0_fp[2][5], fp[5], sign[3], class0_hp[3], hp[3], class0[3], bits[10][3];
   } mvc[2];
@@ -448,6 +449,7 @@ static void init_cdfs(TileCdfs *c, int qidx) {
   load_cdf(c->inter_tx_set2, av1_default_inter_tx_set2_cdf[0], 12);
   load_cdf(c->mv_joint, av1_default_mv_joint_cdf[0], 4);
   load_cdf(c->use_wiener, av1_default_use_wiener_cdf[0], 2);
+  load_cdf(c->restoration_type, av1_default_switchable_restore_cdf[0], 3);
   for (i = 0; i < 2; i++) {
     load_cdf(c->mvc[i].cls, av1_default_mv_class_cdf[0], 11);
     for (j = 0; j < 2; j++) load_cdf(c->mvc[i].class0_fp[j], av1_default_mv_class0_fp_cdf[j], 4);
@@ -478,6 +480,7 @@ typedef struct Enc_ {
   /* loop restoration: unit decisions of this frame (NULL while they are not known yet: first pass) */
   const Av1oLrUnit *lr_units;
   int ref_lr[2][3];     /* RefLrWiener[0][pass][tap], reset per tile */
+  int ref_sgr[2];       /* RefSgrXqd[0][i], reset per tile */
   int8_t *cdef_idx_sb;
   /* tile state */
   int mi_row_start, mi_row_end, mi_col_start, mi_col_end;
@@ -1435,8 +1438,20 @@ static void write_lr(Enc *e, int mi_r, int mi_c) {
   for (ur = r0; ur < r1; ur++)
     for (uc = c0; uc < c1; uc++) {
       const Av1oLrUnit *u = &e->lr_units[ur * ucols + uc];
-      WRITE_SYM(e, u->type, e->cdf.use_wiener, 2);
+      if (e->cfg->enable_lr == 2) WRITE_SYM(e, u->type, e->cdf.restoration_type, 3); /* restoration_type: NONE, WIENER, SGRPROJ */
+      else WRITE_SYM(e, u->type, e->cdf.use_wiener, 2);
       if (!u->type) continue;
+      if (u->type == 2) { /* §5.11.58 read_lr_unit, RESTORE_SGRPROJ */
+        static const int xmin[2] = { -96, -32 }, xmax[2] = { 31, 95 };
+        int i;
+        write_lit_bits(e, (unsigned)u->sgr_set, 4); /* lr_sgr_set */
+        for (i = 0; i < 2; i++) {
+          if (av1o_sgr_params[u->sgr_set][i * 2]) write_signed_subexp_ref(e, xmin[i], xmax[i] + 1, 4, e->ref_sgr[i], u->sgr_xqd[i]);
+          /* radius 0: not coded; the decoder derives 0 (pass 0) or Clip3(min, max, 128 - RefSgrXqd[0]) (pass 1) */
+          e->ref_sgr[i] = u->sgr_xqd[i];
+        }
+        continue;
+      }
       for (pass = 0; pass < 2; pass++)
         for (j = 0; j < 3; j++) {
           write_signed_subexp_ref(e, tmin[j], tmax[j] + 1, tk[j], e->ref_lr[pass][j], u->coef[pass][j]);
@@ -1524,6 +1539,7 @@ static size_t encode_tile(Enc *e, int tr, int tc, uint8_t *out, size_t cap) {
   e->mi_col_end = g->col_start_sb[tc + 1] * 16 < g->mi_cols ? g->col_start_sb[tc + 1] * 16 : g->mi_cols;
   init_cdfs(&e->cdf, e->cfg->base_q_idx);
   for (p = 0; p < 2; p++) { e->ref_lr[p][0] = 3; e->ref_lr[p][1] = -7; e->ref_lr[p][2] = 15; } /* Wiener_Taps_Mid */
+  e->ref_sgr[0] = -32; e->ref_sgr[1] = 31; /* Sgrproj_Xqd_Mid */
   av1o_ec_init(&e->ec, out, cap);
   for (p = 0; p < 3; p++) {
     memset(e->above_lvl[p], 0, (size_t)g->mi_cols + 16);

@@ -55,6 +55,12 @@ CASES = [
     ("k328x248_lr_10b", 328, 248, 10, 7, 1, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
     ("fuzz_lr", 200, 120, 8, 31, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1, fuzz_modes=3)),
     ("fuzz_lr_10b_onetile", 264, 200, 10, 32, 0, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=1, fuzz_modes=5, tile_w_sb=64, tile_h_sb=64)),
+    # RESTORE_SWITCHABLE (enable_lr = 2): per unit off / Wiener / self-guided (all 16 parameter sets and random weights when fuzzed)
+    ("k200x120_lr2", 200, 120, 8, 1080, 1, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=2)),
+    ("k328x248_lr2_deblock_10b", 328, 248, 10, 7, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=2, deblock=1)),
+    ("k202x122_lr2_odd_q180", 202, 122, 8, 42, 1, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=2, base_q_idx=180)),
+    ("fuzz_lr2", 200, 120, 8, 31, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=2, fuzz_modes=3)),
+    ("fuzz_lr2_10b_onetile", 264, 200, 10, 32, 0, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=2, fuzz_modes=5, tile_w_sb=64, tile_h_sb=64)),
     # frame sizes that are not multiples of 8 (coded at the padded size, signalled exactly)
     ("k70x58_odd", 70, 58, 8, 41, 0, dict(min_bs_log2=5, max_bs_log2=5)),
     ("k202x122_odd_lr_10b", 202, 122, 10, 42, 1, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=1)),
@@ -106,6 +112,8 @@ SEQ_CASES = [
     ("pfuzz_subpel_bs3", 200, 120, 8, 28, 3, dict(min_bs_log2=3, max_bs_log2=3, subpel=1, fuzz_modes=9)),
     ("pfuzz_subpel_bs6_10b_odd", 130, 134, 10, 29, 3, dict(min_bs_log2=6, max_bs_log2=6, subpel=1, fuzz_modes=4)),
     ("pfuzz_subpel_onetile_bs5", 264, 200, 8, 30, 3, dict(min_bs_log2=5, max_bs_log2=5, subpel=1, fuzz_modes=6, tile_w_sb=64, tile_h_sb=64, enable_lr=1)),
+    ("p200x120_lr2", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=2)),
+    ("pfuzz_lr2_10b", 200, 120, 10, 26, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=2, fuzz_modes=12)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
