@@ -62,6 +62,9 @@ struct Av1miDevParams {
   int enable_lr;
   int lr_code_len[4][3];                 // [reference: 0 = Wiener_Taps_Mid, r = candidate r-1][candidate]
   unsigned long long lr_code_bits[4][3];
+  // enable_lr = 2: the same for a self-guided unit (lr_sgr_set + both weights against RefSgrXqd; reference 0 = Sgrproj_Xqd_Mid)
+  int sgr_code_len[4][3];
+  unsigned long long sgr_code_bits[4][3];
 };
 
 // frame f of a chunk is a key frame iff f % keyint == 0
@@ -117,7 +120,8 @@ struct Av1miCdfLayout {
     DC_SIGN = EOB_EXTRA + 90 * 3,          // [2][3][3]
     COEFF_BASE_EOB = DC_SIGN + 6 * 3,      // [5][2][4][4]
     USE_WIENER = COEFF_BASE_EOB + 40 * 4,  // [3]
-    COEFF_BASE = USE_WIENER + 3,           // [5][2][42][5]
+    RESTORE_SW = USE_WIENER + 3,           // [4] restoration_type of RESTORE_SWITCHABLE frames: NONE, WIENER, SGRPROJ
+    COEFF_BASE = RESTORE_SW + 4,           // [5][2][42][5]
     COEFF_BR = COEFF_BASE + 420 * 5,       // [5][2][21][5]
     INTRA_TOTAL = COEFF_BR + 210 * 5,      // everything a key frame needs
     // inter frames

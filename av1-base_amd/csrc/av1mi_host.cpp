@@ -104,7 +104,7 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
-  if (p.subpel > 1) return AV1MI_E_INVALID_ARG;
+  if (p.subpel > 1 || p.enable_lr > 2) return AV1MI_E_INVALID_ARG;
   if (p.enable_qm > 1 || p.qm_min > 15 || p.qm_max > 15 || (p.enable_qm && p.qm_min > p.qm_max)) return AV1MI_E_INVALID_ARG;
   // level from the quantiser index, as SVT-AV1 / libaom derive it ("--qm-min", "--qm-max")
   r->qm_level = p.enable_qm ? (int)(p.qm_min + (uint32_t)r->qidx * (p.qm_max + 1 - p.qm_min) / 256) : 15;
@@ -252,7 +252,7 @@ std::vector<uint8_t> make_frame_header(const Resolved &r, size_t *hdr_bits, uint
     b.put(p.cdef_uv_pri, 4); b.put(p.cdef_uv_sec, 2);
   }
   if (p.enable_lr) {  // lr_params (§5.9.20): luma RESTORE_WIENER (lr_type 2), chroma none, lr_unit_shift 0 = 64x64 units
-    b.put(2, 2); b.put(0, 2); b.put(0, 2);
+    b.put(p.enable_lr == 2 ? 1 : 2, 2); b.put(0, 2); b.put(0, 2);  // luma lr_type: 1 = RESTORE_SWITCHABLE, 2 = RESTORE_WIENER
     b.put(0, 1);
   }
   b.put(0, 1);  // tx_mode_select = 0: TX_MODE_LARGEST
@@ -309,6 +309,17 @@ void lr_put_signed_ref(BitString &b, int low, int high, int k, int r, int v) {
   else lr_put_subexp(b, mx, k, lr_recenter(mx - 1 - rr, mx - 1 - x));
 }
 const int8_t kWienerCand[3][3] = { { 0, 0, -4 }, { 1, -3, -6 }, { 3, -7, 15 } };  // == lr_kernel.hip, oracle/av1o_lr.c
+const int8_t kSgrCand[3][3] = { { 9, 31, 31 }, { 9, 0, 31 }, { 9, 31, 95 } };     // { lr_sgr_set, xqd0, xqd1 }: == lr_kernel.hip, oracle/av1o_lr.c
+// self-guided unit (§5.11.58): lr_sgr_set L(4), then the two weights against RefSgrXqd (ref 0 = Sgrproj_Xqd_Mid at the tile
+// start, r = candidate r-1: the previous self-guided unit of the tile).  Every candidate uses set 9, whose radii are both
+// non-zero, so both weights are always coded.
+BitString sgr_code_of(int ref, int cand) {
+  static const int xmin[2] = { -96, -32 }, xmax[2] = { 31, 95 }, mid[2] = { -32, 31 };
+  BitString b;
+  b.put((unsigned)kSgrCand[cand][0], 4);
+  for (int i = 0; i < 2; i++) lr_put_signed_ref(b, xmin[i], xmax[i] + 1, 4, ref ? kSgrCand[ref - 1][1 + i] : mid[i], kSgrCand[cand][1 + i]);
+  return b;
+}
 // ref: 0 = Wiener_Taps_Mid (tile start), r = candidate r-1 (the previous unit of the tile that was coded with a filter)
 BitString lr_code_of(int ref, int cand) {
   static const int tmin[3] = { -5, -23, -17 }, tmax[3] = { 10, 8, 46 }, tk[3] = { 1, 2, 3 }, mid[3] = { 3, -7, 15 };
@@ -352,6 +363,7 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
   emit_rows(v, CL::DC_SIGN, &av1_default_dc_sign_cdf[q][0][0], 6, 3, nullptr, 2);
   emit_rows(v, CL::COEFF_BASE_EOB, &av1_default_coeff_base_eob_cdf[q][0][0][0], 40, 4, nullptr, 3);
   emit_rows(v, CL::USE_WIENER, av1_default_use_wiener_cdf, 1, 3, nullptr, 2);
+  emit_rows(v, CL::RESTORE_SW, av1_default_switchable_restore_cdf, 1, 4, nullptr, 3);
   // inter frames
   emit_rows(v, CL::IF_Y_MODE, av1_default_if_y_mode_cdf, 4, 14, nullptr, 13);
   emit_rows(v, CL::IS_INTER, av1_default_is_inter_cdf, 4, 3, nullptr, 2);
@@ -561,9 +573,12 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.hdr_slot_bytes = 512;
   for (int i = 0; i < 4; i++) { P.lf_level[i] = deblock_level(r, true); P.lf_level_inter[i] = deblock_level(r, false); }
   P.lf_sharpness = 0;
-  P.enable_lr = p.enable_lr ? 1 : 0;
+  P.enable_lr = (int)p.enable_lr;
   for (int rf = 0; rf < 4; rf++)
-    for (int k = 0; k < 3; k++) { const BitString b = lr_code_of(rf, k); P.lr_code_len[rf][k] = b.len; P.lr_code_bits[rf][k] = b.bits; }
+    for (int k = 0; k < 3; k++) {
+      const BitString b = lr_code_of(rf, k); P.lr_code_len[rf][k] = b.len; P.lr_code_bits[rf][k] = b.bits;
+      const BitString g = sgr_code_of(rf, k); P.sgr_code_len[rf][k] = g.len; P.sgr_code_bits[rf][k] = g.bits;
+    }
   return AV1MI_OK;
 }
 

@@ -564,7 +564,8 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   // instantiation skips the other's frames.
   const int inter_frame = INTER;
   if (av1mi_frame_is_inter(P, f) != (int)INTER) return;
-  int lr_prev = 0;  // RefLrWiener of the tile: 0 = Wiener_Taps_Mid, k = candidate k-1 (the last unit coded with a filter)
+  int lr_prev = 0;  // RefLrWiener of the tile: 0 = Wiener_Taps_Mid, k = candidate k-1 (the last unit coded with a Wiener filter)
+  int sgr_prev = 0; // RefSgrXqd of the tile: 0 = Sgrproj_Xqd_Mid, k = self-guided candidate k-1 (the last self-guided unit)
 #pragma nounroll
   for (int si = 0; si < TSB * TSB; si++) {
   const int sbr = tr * TSB + si / TSB, sbc = tc * TSB + si % TSB;
@@ -591,8 +592,15 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     const int urows = imax((P.true_h + 32) / 64, 1), ucols = imax((P.true_w + 32) / 64, 1);  // from the signalled size
     if (sbr < urows && sbc < ucols) {
       const int ch = uni(lr_choice[(size_t)f * urows * ucols + sbr * ucols + sbc]);
-      sym_wide(y, lane, adapt, ch != 0, CL::USE_WIENER, 2);
-      if (ch) {
+      // choice: 0 = off, 1..3 = Wiener candidate, 4..6 = self-guided candidate (RESTORE_SWITCHABLE frames only)
+      if (P.enable_lr == 2) sym_wide(y, lane, adapt, ch == 0 ? 0 : (ch <= 3 ? 1 : 2), CL::RESTORE_SW, 3);
+      else sym_wide(y, lane, adapt, ch != 0, CL::USE_WIENER, 2);
+      if (ch > 3) {
+        const int len = P.sgr_code_len[sgr_prev][ch - 4];
+        const unsigned long long bits = P.sgr_code_bits[sgr_prev][ch - 4];
+        for (int i = len - 1; i >= 0; i--) emit1(y, lane, ENT_LITERAL((int)((bits >> i) & 1)));
+        sgr_prev = ch - 3;
+      } else if (ch) {
         const int len = P.lr_code_len[lr_prev][ch - 1];
         const unsigned long long bits = P.lr_code_bits[lr_prev][ch - 1];
         for (int i = len - 1; i >= 0; i--) emit1(y, lane, ENT_LITERAL((int)((bits >> i) & 1)));

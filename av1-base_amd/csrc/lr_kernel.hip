@@ -8,7 +8,8 @@
 //
 // MI355X mapping: one wave per 64x64 unit (lane = column).  Per stripe of the unit the horizontal pass of 70 rows goes to
 // LDS as int16 (the spec's clamp keeps it in 16 bits for 8/10 bit), the vertical pass reads 7 LDS rows per sample.  The
-// three candidates are evaluated for their SSE only; the winner is applied in a last pass that writes the final
+// three candidates are evaluated for their SSE only (with enable_lr = 2 also three self-guided candidates: the A/B grids of
+// both box-filter passes go to LDS per stripe section, see sgr_grid); the winner is applied in a last pass that writes the final
 // reconstruction (chroma is copied: FrameRestorationType = NONE).  Algorithmic HBM bytes: CDEF frame read + pre-CDEF rows
 // at stripe edges + source read + final write = ~3*L*b + N*b per frame.
 #include <hip/hip_runtime.h>
@@ -58,7 +59,127 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
   return v;
 }
 
+// ---- self-guided restoration (enable_lr = 2; §7.17.3 self guided filter process / box filter process) ---------------
+// Candidates (oracle/av1o_lr.c av1o_sgr_candidates): parameter set 9 (pass 0: r = 2, eps 68; pass 1: r = 1, eps 15) with the
+// weights (xqd0, xqd1) = (31, 31), (0, 31), (31, 95): both box-filter passes are computed once per sample, the candidates
+// differ only in the final blend.
+__constant__ int8_t c_sgr_cand[3][3] = { { 9, 31, 31 }, { 9, 0, 31 }, { 9, 31, 95 } };
+// A (<= 256) and B of the box filter at the positions a unit section needs: rows ya - 1 .. yb (<= 66), columns xs - 1 .. xs + 64
+__shared__ uint16_t g_sgrA[2][66][66];
+__shared__ int32_t g_sgrB[2][66][66];
+
+// get_source_sample (§7.17.6): the row of the frame that supplies restoration input row y of the stripe [s0, s1]
 template <typename PIX>
+__device__ __forceinline__ const PIX *lr_row(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int y, int s0, int s1) {
+  int yy = clampi(y, 0, P.true_h - 1);
+  const PIX *fr = cdef;
+  if (yy < s0) { yy = yy > s0 - 2 ? yy : s0 - 2; fr = pre; }
+  else if (yy > s1) { yy = yy < s1 + 2 ? yy : s1 + 2; fr = pre; }
+  return fr + (size_t)yy * P.stride_y;
+}
+
+// A and B from the box sums (sum of samples b, of squares a) of a (2r+1)^2 window
+template <int R>
+__device__ __forceinline__ void sgr_ab(uint32_t a, uint32_t b, int bd, uint32_t &A, int32_t &B) {
+  constexpr uint32_t n = (2 * R + 1) * (2 * R + 1), eps = R == 2 ? 68 : 15, n2e = n * n * eps;
+  constexpr uint32_t s = ((1u << 20) + n2e / 2) / n2e, one_by_n = ((1u << 12) + n / 2) / n;
+  const uint32_t a8 = (a + ((1u << (2 * (bd - 8))) >> 1)) >> (2 * (bd - 8));
+  const uint32_t d = (b + ((1u << (bd - 8)) >> 1)) >> (bd - 8);
+  const uint32_t p = a8 * n > d * d ? a8 * n - d * d : 0;
+  const uint32_t z = (uint32_t)(((unsigned long long)p * s + (1u << 19)) >> 20);
+  const uint32_t a2 = z >= 255 ? 256 : (z == 0 ? 1 : ((z << 8) + z / 2) / (z + 1));
+  A = a2;
+  B = (int32_t)(((unsigned long long)(256 - a2) * b * one_by_n + (1u << 11)) >> 12);
+}
+
+// A/B of pass PASS (radius R) for the section rows ya - 1 .. yb and columns xs - 1 .. xs + 64 -> g_sgrA/B[PASS][row - (ya - 1)][col - (xs - 1)].
+// Pass 0 is only read on odd rows.  Lane = column xs + lane with a sliding window of row sums; the two edge columns
+// are shared out over the lanes afterwards (direct sums).
+template <typename PIX, int PASS>
+__device__ __forceinline__ void sgr_grid(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int xs, int ya, int yb, int s0, int s1, int lane) {
+  constexpr int R = PASS == 0 ? 2 : 1, WN = 2 * R + 1;
+  const int W = P.true_w, bd = P.bit_depth;
+  const int x = xs + lane;
+  int xi[WN];
+#pragma unroll
+  for (int t = 0; t < WN; t++) xi[t] = clampi(x + t - R, 0, W - 1);
+  uint32_t h1[WN], h2[WN];   // ring of the last WN row sums
+#pragma unroll
+  for (int t = 0; t < WN; t++) { h1[t] = 0; h2[t] = 0; }
+  for (int yy = ya - 1 - R; yy <= yb + R; yy++) {
+    const PIX *row = lr_row<PIX>(P, cdef, pre, yy, s0, s1);
+    uint32_t r1 = 0, r2 = 0;
+#pragma unroll
+    for (int t = 0; t < WN; t++) { const uint32_t c = row[xi[t]]; r1 += c; r2 += c * c; }
+#pragma unroll
+    for (int t = 0; t < WN - 1; t++) { h1[t] = h1[t + 1]; h2[t] = h2[t + 1]; }
+    h1[WN - 1] = r1; h2[WN - 1] = r2;
+    const int yc = yy - R;   // centre row of the window that just became complete
+    if (yc >= ya - 1 && (PASS == 1 || (yc & 1))) {
+      uint32_t b = 0, a = 0;
+#pragma unroll
+      for (int t = 0; t < WN; t++) { b += h1[t]; a += h2[t]; }
+      uint32_t A; int32_t B;
+      sgr_ab<R>(a, b, bd, A, B);
+      g_sgrA[PASS][yc - (ya - 1)][lane + 1] = (uint16_t)A;
+      g_sgrB[PASS][yc - (ya - 1)][lane + 1] = B;
+    }
+  }
+  const int rows = yb - ya + 2;
+  for (int task = lane; task < rows * 2; task += 64) {
+    const int ri = task >> 1, side = task & 1;
+    const int yc = ya - 1 + ri, xc = side ? xs + 64 : xs - 1;
+    if (PASS == 0 && !(yc & 1)) continue;
+    uint32_t a = 0, b = 0;
+    for (int dy = -R; dy <= R; dy++) {
+      const PIX *row = lr_row<PIX>(P, cdef, pre, yc + dy, s0, s1);
+#pragma unroll
+      for (int dx = -R; dx <= R; dx++) { const uint32_t c = row[clampi(xc + dx, 0, W - 1)]; b += c; a += c * c; }
+    }
+    uint32_t A; int32_t B;
+    sgr_ab<R>(a, b, bd, A, B);
+    g_sgrA[PASS][ri][side ? 65 : 0] = (uint16_t)A;
+    g_sgrB[PASS][ri][side ? 65 : 0] = B;
+  }
+}
+
+// the two box-filter outputs (flt0: r = 2, flt1: r = 1) of sample (x = xs + lane, y) from the grids; cur = the CDEF sample
+__device__ __forceinline__ void sgr_flt(int lane, int y, int ya, int cur, int &flt0, int &flt1) {
+  const int ri = y - (ya - 1), c = lane + 1;
+  {
+    int a = 0, b = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int w = (dx == 0 || dy == 0) ? 4 : 3;
+        a += w * (int)g_sgrA[1][ri + dy][c + dx]; b += w * g_sgrB[1][ri + dy][c + dx];
+      }
+    flt1 = (a * cur + b + (1 << 8)) >> 9;
+  }
+  {
+    int a = 0, b = 0;
+    if (y & 1) {  // odd row: the row itself, weights 5 6 5, shift 4
+      a = 5 * (int)g_sgrA[0][ri][c - 1] + 6 * (int)g_sgrA[0][ri][c] + 5 * (int)g_sgrA[0][ri][c + 1];
+      b = 5 * g_sgrB[0][ri][c - 1] + 6 * g_sgrB[0][ri][c] + 5 * g_sgrB[0][ri][c + 1];
+      flt0 = (a * cur + b + (1 << 7)) >> 8;
+    } else {      // even row: the rows above and below, shift 5
+#pragma unroll
+      for (int dy = -1; dy <= 1; dy += 2) {
+        a += 5 * (int)g_sgrA[0][ri + dy][c - 1] + 6 * (int)g_sgrA[0][ri + dy][c] + 5 * (int)g_sgrA[0][ri + dy][c + 1];
+        b += 5 * g_sgrB[0][ri + dy][c - 1] + 6 * g_sgrB[0][ri + dy][c] + 5 * g_sgrB[0][ri + dy][c + 1];
+      }
+      flt0 = (a * cur + b + (1 << 8)) >> 9;
+    }
+  }
+}
+__device__ __forceinline__ int sgr_blend(int cur, int flt0, int flt1, int w0, int w1, int maxv) {
+  const int u = cur << 4, w2 = 128 - w0 - w1;
+  const int v = w1 * u + w0 * flt0 + w2 * flt1;   // set 9: both radii non-zero
+  return clampi((v + (1 << 10)) >> 11, 0, maxv);
+}
+
+template <typename PIX, bool SGR>
 __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX *__restrict__ pre, const PIX *__restrict__ cdef,
                                                     const PIX *__restrict__ src, PIX *__restrict__ out, uint8_t *__restrict__ choice) {
   // units and stripes follow the signalled size; the last unit of a row/column also carries the padding up to the coded
@@ -73,7 +194,7 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
   const int x0 = uc * 64, x1 = uc == ucols - 1 ? P.true_w : x0 + 64;
   const int maxv = (1 << P.bit_depth) - 1;
   // ---- SSE without restoration and with each candidate
-  unsigned long long sse[4] = { 0, 0, 0, 0 };
+  unsigned long long sse[7] = { 0, 0, 0, 0, 0, 0, 0 };
   for (int xs = x0; xs < x1; xs += 64) {
     const int x = xs + lane;
     const bool active = x < x1;
@@ -97,12 +218,30 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
             sse[k + 1] += (unsigned long long)(d * d);
           }
       }
+      if constexpr (SGR) {
+        __syncthreads();
+        sgr_grid<PIX, 0>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
+        sgr_grid<PIX, 1>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
+        __syncthreads();
+        if (active)
+          for (int y = ya; y < yb; y++) {
+            const int cur = (int)cdef[(size_t)y * P.stride_y + x], sv = (int)src[(size_t)y * P.stride_y + x];
+            int f0, f1;
+            sgr_flt(lane, y, ya, cur, f0, f1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const int d = sgr_blend(cur, f0, f1, c_sgr_cand[k][1], c_sgr_cand[k][2], maxv) - sv;
+              sse[4 + k] += (unsigned long long)(d * d);
+            }
+          }
+      }
     }
   }
   int best = 0;
   {
     unsigned long long bs = wave_sum64(sse[0]);
-    for (int k = 0; k < 3; k++) {
+    const int ncand = SGR ? 6 : 3;
+    for (int k = 0; k < ncand; k++) {
       const unsigned long long s = wave_sum64(sse[k + 1]);
       if (s < bs) { bs = s; best = k + 1; }
     }
@@ -115,7 +254,21 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
     for (int st = (y0 + 8) / 64; st * 64 - 8 < y1; st++) {
       const int s0 = st * 64 - 8, s1 = s0 + 63;
       const int ya = y0 > s0 ? y0 : s0, yb = y1 < s1 + 1 ? y1 : s1 + 1;
-      if (best) {
+      if (best > 3) {
+        if constexpr (SGR) {
+          __syncthreads();
+          sgr_grid<PIX, 0>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
+          sgr_grid<PIX, 1>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
+          __syncthreads();
+          if (active)
+            for (int y = ya; y < yb; y++) {
+              const int cur = (int)cdef[(size_t)y * P.stride_y + x];
+              int f0, f1;
+              sgr_flt(lane, y, ya, cur, f0, f1);
+              out[(size_t)y * P.stride_y + x] = (PIX)sgr_blend(cur, f0, f1, c_sgr_cand[best - 4][1], c_sgr_cand[best - 4][2], maxv);
+            }
+        }
+      } else if (best) {
         int tf[7];
         taps_of(best - 1, tf);
         __syncthreads();
@@ -149,9 +302,13 @@ extern "C" hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, 
                                       hipStream_t stream) {
   const int urows = (P->true_h + 32) / 64 > 0 ? (P->true_h + 32) / 64 : 1, ucols = (P->true_w + 32) / 64 > 0 ? (P->true_w + 32) / 64 : 1;
   const int grid = P->n_frames * urows * ucols;
-  if (P->bit_depth == 8)
-    hipLaunchKernelGGL(lr_unit_kernel<uint8_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice);
-  else
-    hipLaunchKernelGGL(lr_unit_kernel<uint16_t>, dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice);
+  // enable_lr = 2 (RESTORE_SWITCHABLE): the instantiation with the self-guided candidates (61 KB of LDS per wave for the A/B grids)
+  if (P->bit_depth == 8) {
+    if (P->enable_lr == 2) hipLaunchKernelGGL((lr_unit_kernel<uint8_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice);
+    else hipLaunchKernelGGL((lr_unit_kernel<uint8_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice);
+  } else {
+    if (P->enable_lr == 2) hipLaunchKernelGGL((lr_unit_kernel<uint16_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice);
+    else hipLaunchKernelGGL((lr_unit_kernel<uint16_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice);
+  }
   return hipGetLastError();
 }

@@ -58,6 +58,8 @@ typedef struct {
   uint32_t first_frame;     /* number of the chunk's first frame inside the clip (seeds grain_seed per frame) */
   uint32_t me_range;        /* inter frames: motion search range in luma samples, 8 or 16 (0 = 8) */
   uint32_t enable_lr;       /* 1 = loop restoration on luma (Wiener, 64x64 units, each unit off or one of 3 filters by SSE);
+                               2 = RESTORE_SWITCHABLE: each unit off, one of the 3 Wiener filters or one of 3 self-guided
+                               filters (parameter set 9, three weightings);
                                default 0: the decision needs the CDEF output, which serialises CDEF before entropy coding */
   uint32_t tile_sb;         /* tile size in 64x64 superblocks, both ways: 0 = automatic (1; 2 when the frame has more than 64
                                superblock rows or columns, e.g. 8K - AV1 allows at most 64 x 64 tiles), or force 1 / 2 */

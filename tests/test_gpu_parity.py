@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-HIP_HAS_SGR = False   # enable_lr = 2 (self-guided restoration units) in the HIP path
+HIP_HAS_SGR = True    # enable_lr = 2 (self-guided restoration units) in the HIP path
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -487,6 +487,25 @@ def test_loop_restoration_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, key
         assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
 
 
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint,cq,extra", [
+    (64, 64, 8, 1, 5, 1, 30, dict()), (200, 120, 8, 3, 5, 240, 30, dict()), (328, 248, 10, 2, 4, 1, 30, dict(deblock=1)),
+    (648, 360, 10, 3, 5, 2, 45, dict(tile_sb=2)), (202, 122, 8, 3, 5, 240, 50, dict(subpel=1)), (136, 200, 10, 2, 3, 1, 20, dict())])
+def test_switchable_restoration_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, cq, extra):
+    """enable_lr = 2 (RESTORE_SWITCHABLE): per unit off, one of the Wiener filters or one of the self-guided filters (both
+    box-filter passes, A/B grids across stripe and unit edges); restoration_type / lr_sgr_set / weights against
+    RefSgrXqd in the tile data - bit-exact against the oracle (whose self-guided filter dav1d pins for all 16 sets)."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=950 + w, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, enable_lr=2, cq_level=cq, **extra)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    tsb = extra.get("tile_sb", 1)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, enable_lr=2, base_q_idx=av1mi.cq_to_qindex(cq), deblock=extra.get("deblock", 0),
+                                subpel=extra.get("subpel", 0), tile_w_sb=tsb, tile_h_sb=tsb)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert list(sizes) == [len(t) for t in tus]
+    assert data == b"".join(tus)
+    assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
+
+
 @pytest.mark.parametrize("w,h,bd,n,bs,keyint,lr", [(328, 248, 8, 2, 4, 1, 0), (200, 120, 10, 3, 5, 240, 0), (264, 200, 8, 3, 3, 2, 1),
                                                   (648, 360, 10, 2, 5, 2, 1), (136, 136, 8, 2, 5, 1, 0)])
 def test_tiles_of_two_by_two_superblocks_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, lr):
@@ -570,6 +589,8 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
         qm = int(rng2.integers(0, 2))
         qmin = int(rng2.integers(0, 16))
         qmax = int(rng2.integers(qmin, 16))
+        if lr and rng2.integers(0, 2):
+            lr = 2   # RESTORE_SWITCHABLE
         big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=3000 + it, t=t) for t in range(n)]
         frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
         p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
