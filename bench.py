@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--me-range", type=int, default=8)
     ap.add_argument("--cq", type=int, default=30, help="CQ level (the headline metric is quoted at 30; the reference's production string uses 8)")
     ap.add_argument("--film-grain", type=int, default=0)
+    ap.add_argument("--sgr", action="store_true", help="loop restoration with switchable units: off / Wiener / self-guided (enable_lr = 2)")
     ap.add_argument("--subpel", action="store_true", help="inter frames: quarter-sample motion vectors + EIGHTTAP interpolation (default: whole-sample vectors)")
     ap.add_argument("--qm", action="store_true", help="quantiser matrices on, --qm-min 1 --qm-max 15 as in the reference's SVT_PARAMS (av1an.rs:14)")
     ap.add_argument("--deblock", action="store_true", help="deblocking filter on (default off: loop_filter_level 0, SURVEY.md §8a a19)")
@@ -171,7 +172,7 @@ def main():
     torch.cuda.synchronize(dev)
     params = av1mi.default_params(w, h, bd, block_log2=args.block_log2, cdf_update=0 if args.static_cdf else 1, keyint=args.keyint,
                                   me_range=args.me_range, cq_level=args.cq, film_grain=args.film_grain,
-                                  deblock=1 if args.deblock else 0, enable_lr=1 if args.lr else 0)
+                                  deblock=1 if args.deblock else 0, enable_lr=2 if args.sgr else (1 if args.lr else 0))
     params.subpel = 1 if args.subpel else 0
     if args.qm:
         params.enable_qm, params.qm_min, params.qm_max = 1, 1, 15
@@ -263,7 +264,7 @@ def main():
                                        w, h, n, "all-key-frame" if args.keyint <= 1 else "IPPP (keyint %d, 1 reference, +-%d full search%s)" % (args.keyint, args.me_range, " + quarter-sample refinement, EIGHTTAP" if args.subpel else ""),
                                        bd, args.cq, av1mi.cq_to_qindex(args.cq), 1 << args.block_log2, 1 << args.block_log2,
                                        "static" if args.static_cdf else "adaptive") + (", deblocking on" if args.deblock else "") + (", quantiser matrices 1..15" if args.qm else "") + (
-                                           ", loop restoration on" if args.lr else ""),
+                                           ", loop restoration (Wiener + self-guided) on" if args.sgr else (", loop restoration on" if args.lr else "")),
                        "frames_per_chunk": n, "chunks_per_gpu": W_,
                        "parallelism": "chunk-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
