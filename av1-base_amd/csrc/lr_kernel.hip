@@ -19,7 +19,7 @@ namespace {
 
 __constant__ int8_t c_wiener_cand[3][3] = { { 0, 0, -4 }, { 1, -3, -6 }, { 3, -7, 15 } };
 
-__shared__ int16_t g_mid[70][64];
+__shared__ int16_t g_mid[70][72];   // Wiener: horizontal-pass output [row][lane]; self-guided: the staged source window (sgr_stage)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -64,9 +64,12 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 // weights (xqd0, xqd1) = (31, 31), (0, 31), (31, 95): both box-filter passes are computed once per sample, the candidates
 // differ only in the final blend.
 __constant__ int8_t c_sgr_cand[3][3] = { { 9, 31, 31 }, { 9, 0, 31 }, { 9, 31, 95 } };
-// A (<= 256) and B of the box filter at the positions a unit section needs: rows ya - 1 .. yb (<= 66), columns xs - 1 .. xs + 64
-__shared__ uint16_t g_sgrA[2][66][66];
-__shared__ int32_t g_sgrB[2][66][66];
+// A (<= 256) and B of the box filter at the positions a slice of SGR_ROWS rows of a unit section needs: rows ya - 1 .. yb
+// (<= SGR_ROWS + 2), columns xs - 1 .. xs + 64.  Slices keep the LDS footprint at 24 KB (6 waves per CU; whole 64-row sections
+// needed 62 KB: 2 waves per CU, half the SIMDs idle, 3x slower).
+#define SGR_ROWS 16
+__shared__ uint16_t g_sgrA[2][SGR_ROWS + 2][66];
+__shared__ int32_t g_sgrB[2][SGR_ROWS + 2][66];
 
 // get_source_sample (§7.17.6): the row of the frame that supplies restoration input row y of the stripe [s0, s1]
 template <typename PIX>
@@ -92,25 +95,34 @@ __device__ __forceinline__ void sgr_ab(uint32_t a, uint32_t b, int bd, uint32_t 
   B = (int32_t)(((unsigned long long)(256 - a2) * b * one_by_n + (1u << 11)) >> 12);
 }
 
-// A/B of pass PASS (radius R) for the section rows ya - 1 .. yb and columns xs - 1 .. xs + 64 -> g_sgrA/B[PASS][row - (ya - 1)][col - (xs - 1)].
-// Pass 0 is only read on odd rows.  Lane = column xs + lane with a sliding window of row sums; the two edge columns
-// are shared out over the lanes afterwards (direct sums).
-template <typename PIX, int PASS>
-__device__ __forceinline__ void sgr_grid(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int xs, int ya, int yb, int s0, int s1, int lane) {
+// Source window of a unit section for the box sums: restoration input rows ya - 3 .. yb + 2 (get_source_sample's stripe rule
+// per row), columns xs - 3 .. xs + 66 (clamped to the frame) -> win[row - (ya - 3)][col - (xs - 3)], all loads independent.
+template <typename PIX>
+__device__ __forceinline__ void sgr_stage(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int xs, int ya, int yb, int s0, int s1, int lane) {
+  uint16_t (*win)[72] = reinterpret_cast<uint16_t (*)[72]>(g_mid);
+  const int rows = yb - ya + 6, W = P.true_w;
+#pragma unroll 8
+  for (int p = lane; p < rows * 70; p += 64) {
+    const int i = p / 70, j = p - i * 70;
+    win[i][j] = (uint16_t)lr_row<PIX>(P, cdef, pre, ya - 3 + i, s0, s1)[clampi(xs - 3 + j, 0, W - 1)];
+  }
+}
+
+// A/B of pass PASS (radius R) for the section rows ya - 1 .. yb and columns xs - 1 .. xs + 64 -> g_sgrA/B[PASS][row - (ya - 1)][col - (xs - 1)],
+// from the staged window.  Pass 0 is only read on odd rows.  Lane = column xs + lane with a sliding window of row sums; the
+// two edge columns are shared out over the lanes afterwards (direct sums).
+template <int PASS>
+__device__ __forceinline__ void sgr_grid(int bd, int ya, int yb, int lane) {
   constexpr int R = PASS == 0 ? 2 : 1, WN = 2 * R + 1;
-  const int W = P.true_w, bd = P.bit_depth;
-  const int x = xs + lane;
-  int xi[WN];
-#pragma unroll
-  for (int t = 0; t < WN; t++) xi[t] = clampi(x + t - R, 0, W - 1);
+  const uint16_t (*win)[72] = reinterpret_cast<const uint16_t (*)[72]>(g_mid);
   uint32_t h1[WN], h2[WN];   // ring of the last WN row sums
 #pragma unroll
   for (int t = 0; t < WN; t++) { h1[t] = 0; h2[t] = 0; }
   for (int yy = ya - 1 - R; yy <= yb + R; yy++) {
-    const PIX *row = lr_row<PIX>(P, cdef, pre, yy, s0, s1);
+    const uint16_t *row = win[yy - (ya - 3)] + lane + 3 - R;
     uint32_t r1 = 0, r2 = 0;
 #pragma unroll
-    for (int t = 0; t < WN; t++) { const uint32_t c = row[xi[t]]; r1 += c; r2 += c * c; }
+    for (int t = 0; t < WN; t++) { const uint32_t c = row[t]; r1 += c; r2 += c * c; }
 #pragma unroll
     for (int t = 0; t < WN - 1; t++) { h1[t] = h1[t + 1]; h2[t] = h2[t + 1]; }
     h1[WN - 1] = r1; h2[WN - 1] = r2;
@@ -128,13 +140,13 @@ __device__ __forceinline__ void sgr_grid(const Av1miDevParams &P, const PIX *cde
   const int rows = yb - ya + 2;
   for (int task = lane; task < rows * 2; task += 64) {
     const int ri = task >> 1, side = task & 1;
-    const int yc = ya - 1 + ri, xc = side ? xs + 64 : xs - 1;
+    const int yc = ya - 1 + ri, j = side ? 67 : 2;   // window column of xs + 64 / xs - 1
     if (PASS == 0 && !(yc & 1)) continue;
     uint32_t a = 0, b = 0;
     for (int dy = -R; dy <= R; dy++) {
-      const PIX *row = lr_row<PIX>(P, cdef, pre, yc + dy, s0, s1);
+      const uint16_t *row = win[yc + dy - (ya - 3)] + j - R;
 #pragma unroll
-      for (int dx = -R; dx <= R; dx++) { const uint32_t c = row[clampi(xc + dx, 0, W - 1)]; b += c; a += c * c; }
+      for (int t = 0; t < WN; t++) { const uint32_t c = row[t]; b += c; a += c * c; }
     }
     uint32_t A; int32_t B;
     sgr_ab<R>(a, b, bd, A, B);
@@ -219,21 +231,26 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
           }
       }
       if constexpr (SGR) {
-        __syncthreads();
-        sgr_grid<PIX, 0>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
-        sgr_grid<PIX, 1>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
-        __syncthreads();
-        if (active)
-          for (int y = ya; y < yb; y++) {
-            const int cur = (int)cdef[(size_t)y * P.stride_y + x], sv = (int)src[(size_t)y * P.stride_y + x];
-            int f0, f1;
-            sgr_flt(lane, y, ya, cur, f0, f1);
+        for (int yh = ya; yh < yb; yh += SGR_ROWS) {
+          const int ye = yh + SGR_ROWS < yb ? yh + SGR_ROWS : yb;
+          __syncthreads();
+          sgr_stage<PIX>(P, cdef, pre, xs, yh, ye, s0, s1, lane);
+          __syncthreads();
+          sgr_grid<0>(P.bit_depth, yh, ye, lane);
+          sgr_grid<1>(P.bit_depth, yh, ye, lane);
+          __syncthreads();
+          if (active)
+            for (int y = yh; y < ye; y++) {
+              const int cur = (int)cdef[(size_t)y * P.stride_y + x], sv = (int)src[(size_t)y * P.stride_y + x];
+              int f0, f1;
+              sgr_flt(lane, y, yh, cur, f0, f1);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-              const int d = sgr_blend(cur, f0, f1, c_sgr_cand[k][1], c_sgr_cand[k][2], maxv) - sv;
-              sse[4 + k] += (unsigned long long)(d * d);
+              for (int k = 0; k < 3; k++) {
+                const int d = sgr_blend(cur, f0, f1, c_sgr_cand[k][1], c_sgr_cand[k][2], maxv) - sv;
+                sse[4 + k] += (unsigned long long)(d * d);
+              }
             }
-          }
+        }
       }
     }
   }
@@ -256,17 +273,22 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
       const int ya = y0 > s0 ? y0 : s0, yb = y1 < s1 + 1 ? y1 : s1 + 1;
       if (best > 3) {
         if constexpr (SGR) {
-          __syncthreads();
-          sgr_grid<PIX, 0>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
-          sgr_grid<PIX, 1>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
-          __syncthreads();
-          if (active)
-            for (int y = ya; y < yb; y++) {
-              const int cur = (int)cdef[(size_t)y * P.stride_y + x];
-              int f0, f1;
-              sgr_flt(lane, y, ya, cur, f0, f1);
-              out[(size_t)y * P.stride_y + x] = (PIX)sgr_blend(cur, f0, f1, c_sgr_cand[best - 4][1], c_sgr_cand[best - 4][2], maxv);
-            }
+          for (int yh = ya; yh < yb; yh += SGR_ROWS) {
+            const int ye = yh + SGR_ROWS < yb ? yh + SGR_ROWS : yb;
+            __syncthreads();
+            sgr_stage<PIX>(P, cdef, pre, xs, yh, ye, s0, s1, lane);
+            __syncthreads();
+            sgr_grid<0>(P.bit_depth, yh, ye, lane);
+            sgr_grid<1>(P.bit_depth, yh, ye, lane);
+            __syncthreads();
+            if (active)
+              for (int y = yh; y < ye; y++) {
+                const int cur = (int)cdef[(size_t)y * P.stride_y + x];
+                int f0, f1;
+                sgr_flt(lane, y, yh, cur, f0, f1);
+                out[(size_t)y * P.stride_y + x] = (PIX)sgr_blend(cur, f0, f1, c_sgr_cand[best - 4][1], c_sgr_cand[best - 4][2], maxv);
+              }
+          }
         }
       } else if (best) {
         int tf[7];
