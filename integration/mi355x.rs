@@ -52,6 +52,7 @@ pub fn run_mi355x(params: &Av1anEncodeParams, cq_level: u32) -> Result<(), Encod
     p.keyint = 240;                                      // "--keyint 240": IPPP inside a chunk, chunks start at scene cuts
     p.film_grain = 20;                                   // "--film-grain 20": film-grain table in every frame header
     p.enable_qm = 1; p.qm_min = 1; p.qm_max = 15;        // "--enable-qm 1 --qm-min 1 --qm-max 15": quantiser matrices
+    p.subpel = 1; p.deblock = 1; p.enable_lr = 2;        // tools SVT-AV1 has on at "--preset 3": sub-sample motion, deblocking, restoration
     let job = Av1miJob { input_path: i.as_ptr(), output_path: o.as_ptr(), temp_dir: t.as_ptr(),
                          workers: params.concurrency.av1an_workers, chunk_frames: 0 /* scene-cut chunks */, gpu_mask: 0, params: p };
     let mut rep = Av1miReport::default();

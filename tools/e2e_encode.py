@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end check, part 1 (on the MI355X box): synthesise a clip with scene cuts as Y4M, encode it through the
-run_av1an drop-in (scene-cut chunks, IPPP, several chunks in flight) and leave the IVF under gpurun_out/.
+run_av1an drop-in (scene-cut chunks, IPPP with quarter-sample vectors, quantiser matrices, deblocking, switchable restoration, several
+chunks in flight) and leave the IVF under gpurun_out/.
 Part 2 (tools/e2e_decode.py, where dav1d is available) decodes it and compares with the source."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,8 @@ def main():
             fr = bench.synthclip_frame(w, h, bd, 4000 + t // scene_len, t % scene_len)   # re-seeded every scene_len frames
             f.write(b"FRAME\n" + b"".join(p.astype("<u2").tobytes() for p in fr))
     out = os.path.join(out_dir, "e2e.ivf")
-    rep = av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, out_dir, av1mi.derive_plan(16), chunk_frames=0, keyint=240, enable_lr=1, film_grain=0))
+    rep = av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, out_dir, av1mi.derive_plan(16), chunk_frames=0, keyint=240, enable_lr=2, film_grain=0,
+                                              deblock=1, subpel=1, enable_qm=1, qm_min=1, qm_max=15))   # every optional tool on (grain off: PSNR is compared)
     os.remove(y4m)
     print("frames %d chunks %d bytes %d psnr %.2f %.2f %.2f" % (rep.frames, rep.chunks, rep.bytes, rep.psnr[0], rep.psnr[1], rep.psnr[2]))
 
