@@ -858,7 +858,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   if (!inter_chunk && !lr) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s2));
   HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s2));
   HIPCHK(c, hipEventRecord(c->ev[9], s2));
-  HIPCHK(c, hipStreamWaitEvent(s, c->ev[9], 0));  // join: everything below sees the CDEF output too
+  // packing and the download of the bitstream need nothing from the second stream: they run beside the tail of CDEF / SSE;
+  // the join comes before the reconstruction and the SSE are read (below)
   HIPCHK(c, av1mi_launch_pack(&P, c->d_slots, c->d_tile_bytes, c->d_tile_off, c->d_frame_size, c->d_payload, c->d_frame_off, c->d_hdr,
                               c->d_out, c->d_overflow, 0, s));
   HIPCHK(c, av1mi_launch_pack(&P, c->d_slots, c->d_tile_bytes, c->d_tile_off, c->d_frame_size, c->d_payload, c->d_frame_off, c->d_hdr,
@@ -871,13 +872,14 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   HIPCHK(c, hipMemcpyAsync(&overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (overflow) {
+    (void)hipStreamSynchronize(s2);  // the retry reuses the buffers the second stream is still reading
     set_err(c, "a tile outgrew its %d-byte bitstream slot or its %d-entry symbol stream", P.tile_slot_bytes, P.stream_cap);
     return AV1MI_E_OVERFLOW;
   }
   const size_t total = (size_t)foff[n_frames];
-  if (total > c->out_cap) { set_err(c, "internal: packed size exceeds buffer"); return AV1MI_E_OVERFLOW; }
+  if (total > c->out_cap) { (void)hipStreamSynchronize(s2); set_err(c, "internal: packed size exceeds buffer"); return AV1MI_E_OVERFLOW; }
   uint8_t *host = (uint8_t *)malloc(total ? total : 1);
-  if (!host) return AV1MI_E_OOM;
+  if (!host) { (void)hipStreamSynchronize(s2); return AV1MI_E_OOM; }
   if (c->h_out_cap < total) {
     if (c->h_out) (void)hipHostFree(c->h_out);
     c->h_out = nullptr; c->h_out_cap = 0;
@@ -886,6 +888,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   uint8_t *dst = c->h_out ? c->h_out : host;
   hipError_t e1 = hipMemcpyAsync(dst, c->d_out, total, hipMemcpyDeviceToHost, s);
   hipError_t e2 = hipEventRecord(c->ev[6], s);
+  if (e2 == hipSuccess) e2 = hipStreamWaitEvent(s, c->ev[9], 0);  // join: the final reconstruction and the SSE come from the second stream
   if (e1 == hipSuccess && e2 == hipSuccess && recon) {
     const void *fin = c->d_fin;
     if (padded) {  // crop to the signalled size, in the caller's tight layout
@@ -903,6 +906,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   }
   if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
   if (e1 != hipSuccess || e2 != hipSuccess) {
+    (void)hipStreamSynchronize(s2);
     free(host);
     set_err(c, "device-to-host copy failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return AV1MI_E_HIP;
