@@ -1,4 +1,5 @@
-// me_kernel.hip - integer-pel full-search motion estimation for inter frames.
+// me_kernel.hip - motion estimation for inter frames: integer-pel full search (SAD) and, with
+// subpel = 1, the half-/quarter-sample refinement with an SATD cost (second half of this file).
 //
 // Replaces the motion search SVT-AV1 runs inside the av1an worker the reference forks
 // (/root/reference/crates/daemon/src/encode/av1an.rs:126-139).  Encoder-side, non-normative; the algorithm is the

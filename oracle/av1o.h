@@ -10,8 +10,10 @@
  * a plain-C restatement of (1) the encoder algorithm this build defines for that path
  *  and (2) the NORMATIVE AV1 decoding processes the encoder must mirror
  * (AV1 Bitstream & Decoding Process Specification: §5.5 sequence header, §5.9 frame header,
- * §5.11 tile/block syntax, §7.11.2 intra prediction, §7.12 dequant, §7.13 inverse
- * transforms, §7.15 CDEF, §8.2 symbol coder).
+ * §5.11 tile/block syntax incl. the inter syntax and §7.10.2 motion vector prediction, §7.11.2 intra
+ * prediction, §7.11.3 motion compensation (BILINEAR and EIGHTTAP), §7.12 dequant incl. quantiser
+ * matrices, §7.13 inverse transforms, §7.14 deblocking, §7.15 CDEF, §7.17 loop restoration (Wiener and
+ * self-guided), §8.2 symbol coder).
  *
  * PARITY PIN: parity with SVT-AV1 output is UNPINNED (no av1an/SVT-AV1 anywhere, the
  * reference holds no media fixtures: SURVEY.md §8c).  The normative half IS pinned: streams

@@ -7,7 +7,6 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-HIP_HAS_SGR = True    # enable_lr = 2 (self-guided restoration units) in the HIP path
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -53,8 +52,6 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         p.intra_mode_mask = cfgk.get("mode_mask", 0)
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         p.enable_lr = cfgk.get("enable_lr", 0)
-        if p.enable_lr == 2 and not HIP_HAS_SGR:
-            continue
         if cfgk.get("deblock", 0) == 2:
             continue   # explicit levels: oracle-only test hook
         p.deblock = cfgk.get("deblock", 0)
@@ -267,7 +264,7 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
         bs = cfgk.get("min_bs_log2", 4)
         if any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("film_grain") or bs > 5:
             continue
-        if m["width"] % 8 or m["height"] % 8 or (cfgk.get("enable_lr") == 2 and not HIP_HAS_SGR):
+        if m["width"] % 8 or m["height"] % 8:
             continue   # (covered by test_sizes_that_are_not_multiples_of_8: fixtures here are generated full-size)
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, keyint=240, me_range=cfgk.get("me_range", 8),
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0), deblock=cfgk.get("deblock", 0),
@@ -330,7 +327,6 @@ def test_subsample_motion_vectors_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, 
         kw.update(enable_qm=1, qm_y=extra["qm_min"], qm_uv=extra["qm_min"])
     cfg = oracle.default_config(w, h, bd, **kw)
     tus, recs = oracle_chunk(oracle, cfg, frames, 240)
-    frac = 0
     assert list(sizes) == [len(t) for t in tus]
     off = 0
     for i, tu in enumerate(tus):
