@@ -356,6 +356,27 @@ def test_4k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):
     assert recon.tobytes()[fb:2 * fb] == raw_of(recs[1], bd)
 
 
+def test_4k_every_optional_tool_equals_oracle(av1mi, ctx, oracle):
+    """3840x2160 10-bit key + P frame with every optional tool on at once: quarter-sample vectors with the SATD refinement,
+    quantiser matrices, deblocking, switchable Wiener / self-guided restoration, film-grain table."""
+    w, h, bd, n = 3840, 2160, 10, 2
+    frames = [oracle.synthclip_frame(w, h, bd, seed=2161, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, keyint=2, subpel=1, enable_qm=1, qm_min=1, qm_max=15, deblock=1, enable_lr=2, film_grain=20)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    lvl = oracle.qm_level(av1mi.cq_to_qindex(30), 1, 15)
+    tus, recs, ref, prev = [], [], None, None
+    for t, f in enumerate(frames):
+        cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5, subpel=1, enable_qm=1, qm_y=lvl, qm_uv=lvl, deblock=1, enable_lr=2,
+                                    film_grain=1, fg_y_scaling=40, fg_c_scaling=20, fg_seed=(7391 + 173 * t) & 0xFFFF)
+        tu, rec, st = oracle.encode_frame(cfg, f, with_seq_hdr=(t == 0), ref=ref, prev_src=prev)
+        tus.append(tu)
+        recs.append(rec)
+        ref, prev = rec, f
+    assert list(sizes) == [len(t) for t in tus]
+    assert data == b"".join(tus)
+    assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
+
+
 def _ebml(buf, pos, end):
     """yield (id, payload_start, payload_end) of the EBML elements in buf[pos:end]"""
     while pos < end:
