@@ -34,7 +34,8 @@ hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frame
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
 hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop, hipStream_t s);
 hipError_t av1mi_launch_deblock(const Av1miDevParams *P, void *rec, const Av1miBlkInfo *blk, hipStream_t s);
-hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice, hipStream_t s);
+hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice,
+                           unsigned long long *unit_sse, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
                                 const uint8_t *lr_choice,
@@ -424,6 +425,7 @@ struct av1mi_ctx {
   std::vector<Av1miQmEntry> h_qm;
   int qm_key = -1;
   uint8_t *d_lrc = nullptr;            // per restoration unit: 0 = off, k = candidate k-1
+  unsigned long long *d_lrsse = nullptr;  // per restoration unit: the candidates' SSE sums (scratch of lr_kernel.hip's two phases)
   size_t out_cap = 0;
   // host staging (pinned)
   uint8_t *h_out = nullptr;
@@ -453,11 +455,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -517,6 +519,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     const size_t nf = c->cap_frames;
     HIPCHK(c, hipMalloc(&c->d_cd, nf * frame_samples * bps));
     HIPCHK(c, hipMalloc((void **)&c->d_lrc, nf * nsb + 64));
+    HIPCHK(c, hipMalloc((void **)&c->d_lrsse, (nf * nsb + 64) * 8 * sizeof(unsigned long long)));
   }
   c->res = r;
   Av1miDevParams &P = c->P;
@@ -791,7 +794,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     if (lr) {  // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
       if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
       HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, s));
-      HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, s));
+      HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, c->d_lrsse, s));
     }
   } else {
     // Inter chunk: a P frame needs the previous frame's final (post-CDEF) reconstruction, so motion search,
@@ -836,7 +839,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, s));
       if (lr) {
         const int upf = ((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
-        HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, s));
+        HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, c->d_lrsse + (size_t)f * upf * 8, s));
       }
     }
   }

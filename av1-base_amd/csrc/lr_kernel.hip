@@ -6,7 +6,7 @@
 // 64-row stripe come from the pre-CDEF frame, at most 2 rows away).  Encoder part: a unit takes the
 // candidate filter with the smallest SSE against the source, or none; restated in oracle/av1o_lr.c.
 //
-// MI355X mapping: one wave per 64x64 unit (lane = column).  Per stripe of the unit the horizontal pass of 70 rows goes to
+// MI355X mapping: waves of 16 rows of a 64x64 unit (lane = column), two phases (see lr_unit_kernel).  Per stripe of the unit the horizontal pass of 70 rows goes to
 // LDS as int16 (the spec's clamp keeps it in 16 bits for 8/10 bit), the vertical pass reads 7 LDS rows per sample.  The
 // three candidates are evaluated for their SSE only (with enable_lr = 2 also three self-guided candidates: the A/B grids of
 // both box-filter passes go to LDS per stripe section, see sgr_grid); the winner is applied in a last pass that writes the final
@@ -19,29 +19,21 @@ namespace {
 
 __constant__ int8_t c_wiener_cand[3][3] = { { 0, 0, -4 }, { 1, -3, -6 }, { 3, -7, 15 } };
 
-__shared__ int16_t g_mid[70][72];   // Wiener: horizontal-pass output [row][lane]; self-guided: the staged source window (sgr_stage)
+// a wave works on at most 16 rows (LR_SLICES): the source window of those rows (3 more above, 2..3 below, 3 columns either
+// side; get_source_sample's stripe rule applied per row) is staged once and both filters read it from LDS
+__shared__ uint16_t g_win[22][72];
+__shared__ int16_t g_mid[22][72];   // Wiener: horizontal-pass output [row][lane]
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// horizontal pass of rows [ya - 3, yb + 3) of one stripe for column x into g_mid[row - (ya - 3)][lane]
-template <typename PIX>
-__device__ __forceinline__ void wiener_h(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int x, int ya, int yb, int s0, int s1,
-                                         const int *f, bool active, int lane) {
-  const int W = P.true_w, H = P.true_h, bd = P.bit_depth;  // PlaneEndX + 1, PlaneEndY + 1 (§7.17.6): the signalled size
+// horizontal pass of rows [ya - 3, yb + 3) for column xs + lane, from the staged window, into g_mid[row - (ya - 3)][lane]
+__device__ __forceinline__ void wiener_h(int bd, int ya, int yb, const int *f, int lane) {
   const int offset = 1 << (bd + 7 - 3 - 1), limit = (1 << (bd + 1 + 7 - 3)) - 1;
-  for (int r = ya - 3; r < yb + 3; r++) {
-    int yy = clampi(r, 0, H - 1);
-    const PIX *fr = cdef;
-    if (yy < s0) { yy = yy > s0 - 2 ? yy : s0 - 2; fr = pre; }
-    else if (yy > s1) { yy = yy < s1 + 2 ? yy : s1 + 2; fr = pre; }
+  for (int r = 0; r < yb - ya + 6; r++) {
     int s = 0;
-    if (active) {
-      const PIX *row = fr + (size_t)yy * P.stride_y;
 #pragma unroll
-      for (int t = 0; t < 7; t++) s += f[t] * (int)row[clampi(x + t - 3, 0, W - 1)];
-      s = clampi((s + 4) >> 3, -offset, limit - offset);
-    }
-    g_mid[r - (ya - 3)][lane] = (int16_t)s;
+    for (int t = 0; t < 7; t++) s += f[t] * (int)g_win[r][lane + t];
+    g_mid[r][lane] = (int16_t)clampi((s + 4) >> 3, -offset, limit - offset);
   }
 }
 __device__ __forceinline__ int wiener_v(int row_in_mid, int lane, const int *f, int maxv) {
@@ -67,7 +59,7 @@ __constant__ int8_t c_sgr_cand[3][3] = { { 9, 31, 31 }, { 9, 0, 31 }, { 9, 31, 9
 // A (<= 256) and B of the box filter at the positions a slice of SGR_ROWS rows of a unit section needs: rows ya - 1 .. yb
 // (<= SGR_ROWS + 2), columns xs - 1 .. xs + 64.  Slices keep the LDS footprint at 24 KB (6 waves per CU; whole 64-row sections
 // needed 62 KB: 2 waves per CU, half the SIMDs idle, 3x slower).
-#define SGR_ROWS 16
+#define SGR_ROWS 16   /* == the rows of a wave's slice */
 __shared__ uint16_t g_sgrA[2][SGR_ROWS + 2][66];
 __shared__ int32_t g_sgrB[2][SGR_ROWS + 2][66];
 
@@ -98,8 +90,8 @@ __device__ __forceinline__ void sgr_ab(uint32_t a, uint32_t b, int bd, uint32_t 
 // Source window of a unit section for the box sums: restoration input rows ya - 3 .. yb + 2 (get_source_sample's stripe rule
 // per row), columns xs - 3 .. xs + 66 (clamped to the frame) -> win[row - (ya - 3)][col - (xs - 3)], all loads independent.
 template <typename PIX>
-__device__ __forceinline__ void sgr_stage(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int xs, int ya, int yb, int s0, int s1, int lane) {
-  uint16_t (*win)[72] = reinterpret_cast<uint16_t (*)[72]>(g_mid);
+__device__ __forceinline__ void lr_stage(const Av1miDevParams &P, const PIX *cdef, const PIX *pre, int xs, int ya, int yb, int s0, int s1, int lane) {
+  uint16_t (*win)[72] = g_win;
   const int rows = yb - ya + 6, W = P.true_w;
 #pragma unroll 8
   for (int p = lane; p < rows * 70; p += 64) {
@@ -114,7 +106,7 @@ __device__ __forceinline__ void sgr_stage(const Av1miDevParams &P, const PIX *cd
 template <int PASS>
 __device__ __forceinline__ void sgr_grid(int bd, int ya, int yb, int lane) {
   constexpr int R = PASS == 0 ? 2 : 1, WN = 2 * R + 1;
-  const uint16_t (*win)[72] = reinterpret_cast<const uint16_t (*)[72]>(g_mid);
+  const uint16_t (*win)[72] = g_win;
   uint32_t h1[WN], h2[WN];   // ring of the last WN row sums
 #pragma unroll
   for (int t = 0; t < WN; t++) { h1[t] = 0; h2[t] = 0; }
@@ -191,20 +183,30 @@ __device__ __forceinline__ int sgr_blend(int cur, int flt0, int flt1, int w0, in
   return clampi((v + (1 << 10)) >> 11, 0, maxv);
 }
 
-template <typename PIX, bool SGR>
+// A unit is LR_SLICES waves, one per 16 of its rows (the last unit of a column has up to 103), in two launches: PHASE 0 adds
+// the slice's SSE of every candidate to the unit's sums (atomics), PHASE 1 reads the sums, takes the same decision in every
+// slice and applies it to its rows.  (As one wave per unit the kernel took 221 us of an inter frame's serial chain.)
+#define LR_SLICES 7
+template <typename PIX, bool SGR, int PHASE>
 __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX *__restrict__ pre, const PIX *__restrict__ cdef,
-                                                    const PIX *__restrict__ src, PIX *__restrict__ out, uint8_t *__restrict__ choice) {
+                                                    const PIX *__restrict__ src, PIX *__restrict__ out, uint8_t *__restrict__ choice,
+                                                    unsigned long long *__restrict__ unit_sse /* [frame][unit][8] */) {
   // units and stripes follow the signalled size; the last unit of a row/column also carries the padding up to the coded
   // size (copied, never filtered), so the whole frame buffer is defined
   const int urows = (P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1, ucols = (P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1;
   const int per_frame = urows * ucols;
-  const int f = blockIdx.x / per_frame, u = blockIdx.x % per_frame, ur = u / ucols, uc = u % ucols;
+  const int item = blockIdx.x / LR_SLICES, slice = blockIdx.x % LR_SLICES;
+  const int f = item / per_frame, u = item % per_frame, ur = u / ucols, uc = u % ucols;
   const int lane = threadIdx.x;
   const size_t fo = (size_t)f * P.frame_samples;
   pre += fo; cdef += fo; src += fo; out += fo;
-  const int y0 = ur ? ur * 64 - 8 : 0, y1 = ur == urows - 1 ? P.true_h : ur * 64 + 56;
+  const int uy0 = ur ? ur * 64 - 8 : 0, uy1 = ur == urows - 1 ? P.true_h : ur * 64 + 56;   // the unit's rows
+  const int y0 = uy0 + slice * 16, y1 = y0 + 16 < uy1 ? y0 + 16 : uy1;                      // this wave's rows
+  if (y0 >= uy1) return;
   const int x0 = uc * 64, x1 = uc == ucols - 1 ? P.true_w : x0 + 64;
   const int maxv = (1 << P.bit_depth) - 1;
+  unsigned long long *usse = unit_sse + (size_t)item * 8;
+  if constexpr (PHASE == 0) {
   // ---- SSE without restoration and with each candidate
   unsigned long long sse[7] = { 0, 0, 0, 0, 0, 0, 0 };
   for (int xs = x0; xs < x1; xs += 64) {
@@ -213,89 +215,89 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
     for (int st = (y0 + 8) / 64; st * 64 - 8 < y1; st++) {
       const int s0 = st * 64 - 8, s1 = s0 + 63;
       const int ya = y0 > s0 ? y0 : s0, yb = y1 < s1 + 1 ? y1 : s1 + 1;
-      if (active)
-        for (int y = ya; y < yb; y++) {
-          const int d = (int)cdef[(size_t)y * P.stride_y + x] - (int)src[(size_t)y * P.stride_y + x];
-          sse[0] += (unsigned long long)(d * d);
-        }
+      __syncthreads();
+      lr_stage<PIX>(P, cdef, pre, xs, ya, yb, s0, s1, lane);   // the section's source window, once, for every candidate
+      __syncthreads();
+      int cur[16], sv[16];   // this lane's CDEF and source samples of the section (<= 16 rows)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int y = ya + i < yb ? ya + i : yb - 1;
+        cur[i] = (int)g_win[y - ya + 3][lane + 3];
+        sv[i] = active ? (int)src[(size_t)y * P.stride_y + x] : cur[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (ya + i < yb) { const int d = cur[i] - sv[i]; sse[0] += (unsigned long long)(d * d); }
       for (int k = 0; k < 3; k++) {
         int tf[7];
         taps_of(k, tf);
-        __syncthreads();
-        wiener_h<PIX>(P, cdef, pre, x, ya, yb, s0, s1, tf, active, lane);
-        __syncthreads();
-        if (active)
-          for (int y = ya; y < yb; y++) {
-            const int d = wiener_v(y - ya, lane, tf, maxv) - (int)src[(size_t)y * P.stride_y + x];
-            sse[k + 1] += (unsigned long long)(d * d);
-          }
+        wiener_h(P.bit_depth, ya, yb, tf, lane);   // g_mid is private to the lane's column: no barrier needed
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          if (active && ya + i < yb) { const int d = wiener_v(i, lane, tf, maxv) - sv[i]; sse[k + 1] += (unsigned long long)(d * d); }
       }
       if constexpr (SGR) {
-        for (int yh = ya; yh < yb; yh += SGR_ROWS) {
-          const int ye = yh + SGR_ROWS < yb ? yh + SGR_ROWS : yb;
-          __syncthreads();
-          sgr_stage<PIX>(P, cdef, pre, xs, yh, ye, s0, s1, lane);
-          __syncthreads();
-          sgr_grid<0>(P.bit_depth, yh, ye, lane);
-          sgr_grid<1>(P.bit_depth, yh, ye, lane);
-          __syncthreads();
-          if (active)
-            for (int y = yh; y < ye; y++) {
-              const int cur = (int)cdef[(size_t)y * P.stride_y + x], sv = (int)src[(size_t)y * P.stride_y + x];
-              int f0, f1;
-              sgr_flt(lane, y, yh, cur, f0, f1);
+        sgr_grid<0>(P.bit_depth, ya, yb, lane);
+        sgr_grid<1>(P.bit_depth, ya, yb, lane);
+        __syncthreads();
 #pragma unroll
-              for (int k = 0; k < 3; k++) {
-                const int d = sgr_blend(cur, f0, f1, c_sgr_cand[k][1], c_sgr_cand[k][2], maxv) - sv;
-                sse[4 + k] += (unsigned long long)(d * d);
-              }
+        for (int i = 0; i < 16; i++)
+          if (active && ya + i < yb) {
+            int f0, f1;
+            sgr_flt(lane, ya + i, ya, cur[i], f0, f1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const int d = sgr_blend(cur[i], f0, f1, c_sgr_cand[k][1], c_sgr_cand[k][2], maxv) - sv[i];
+              sse[4 + k] += (unsigned long long)(d * d);
             }
-        }
+          }
       }
     }
   }
+  for (int k = 0; k < (SGR ? 7 : 4); k++) {
+    const unsigned long long v = wave_sum64(sse[k]);
+    if (lane == 0 && v) atomicAdd(&usse[k], v);
+  }
+  } else {
   int best = 0;
   {
-    unsigned long long bs = wave_sum64(sse[0]);
+    unsigned long long bs = usse[0];
     const int ncand = SGR ? 6 : 3;
     for (int k = 0; k < ncand; k++) {
-      const unsigned long long s = wave_sum64(sse[k + 1]);
+      const unsigned long long s = usse[k + 1];
       if (s < bs) { bs = s; best = k + 1; }
     }
   }
-  if (lane == 0) choice[blockIdx.x] = (uint8_t)best;
-  // ---- apply: luma of the unit, and the co-located chroma (copied)
+  if (lane == 0 && slice == 0) choice[item] = (uint8_t)best;
+  // ---- apply: luma of the slice, and the co-located chroma (copied)
   for (int xs = x0; xs < x1; xs += 64) {
     const int x = xs + lane;
     const bool active = x < x1;
     for (int st = (y0 + 8) / 64; st * 64 - 8 < y1; st++) {
       const int s0 = st * 64 - 8, s1 = s0 + 63;
       const int ya = y0 > s0 ? y0 : s0, yb = y1 < s1 + 1 ? y1 : s1 + 1;
+      if (best) {
+        __syncthreads();
+        lr_stage<PIX>(P, cdef, pre, xs, ya, yb, s0, s1, lane);
+        __syncthreads();
+      }
       if (best > 3) {
         if constexpr (SGR) {
-          for (int yh = ya; yh < yb; yh += SGR_ROWS) {
-            const int ye = yh + SGR_ROWS < yb ? yh + SGR_ROWS : yb;
-            __syncthreads();
-            sgr_stage<PIX>(P, cdef, pre, xs, yh, ye, s0, s1, lane);
-            __syncthreads();
-            sgr_grid<0>(P.bit_depth, yh, ye, lane);
-            sgr_grid<1>(P.bit_depth, yh, ye, lane);
-            __syncthreads();
-            if (active)
-              for (int y = yh; y < ye; y++) {
-                const int cur = (int)cdef[(size_t)y * P.stride_y + x];
-                int f0, f1;
-                sgr_flt(lane, y, yh, cur, f0, f1);
-                out[(size_t)y * P.stride_y + x] = (PIX)sgr_blend(cur, f0, f1, c_sgr_cand[best - 4][1], c_sgr_cand[best - 4][2], maxv);
-              }
-          }
+          sgr_grid<0>(P.bit_depth, ya, yb, lane);
+          sgr_grid<1>(P.bit_depth, ya, yb, lane);
+          __syncthreads();
+          if (active)
+            for (int y = ya; y < yb; y++) {
+              const int cur = (int)g_win[y - ya + 3][lane + 3];
+              int f0, f1;
+              sgr_flt(lane, y, ya, cur, f0, f1);
+              out[(size_t)y * P.stride_y + x] = (PIX)sgr_blend(cur, f0, f1, c_sgr_cand[best - 4][1], c_sgr_cand[best - 4][2], maxv);
+            }
         }
       } else if (best) {
         int tf[7];
         taps_of(best - 1, tf);
-        __syncthreads();
-        wiener_h<PIX>(P, cdef, pre, x, ya, yb, s0, s1, tf, active, lane);
-        __syncthreads();
+        wiener_h(P.bit_depth, ya, yb, tf, lane);
         if (active)
           for (int y = ya; y < yb; y++) out[(size_t)y * P.stride_y + x] = (PIX)wiener_v(y - ya, lane, tf, maxv);
       } else if (active) {
@@ -304,8 +306,8 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
     }
   }
   {
-    // padding between the signalled and the coded size (< 8 samples): copied with the last unit of the row / column
-    const int py1 = ur == urows - 1 ? P.height : y1, px1 = uc == ucols - 1 ? P.width : x1;
+    // padding between the signalled and the coded size (< 8 samples): copied with the last unit of the row / column (its last slice)
+    const int py1 = (ur == urows - 1 && y1 == uy1) ? P.height : y1, px1 = uc == ucols - 1 ? P.width : x1;
     for (int y = y0; y < py1; y++)
       for (int x = x0 + lane; x < px1; x += 64)
         if (y >= y1 || x >= x1) out[(size_t)y * P.stride_y + x] = cdef[(size_t)y * P.stride_y + x];
@@ -316,21 +318,32 @@ __global__ void __launch_bounds__(64) lr_unit_kernel(Av1miDevParams P, const PIX
         for (int x = cx0 + lane; x < cx1; x += 64) out[po + (size_t)y * P.stride_c + x] = cdef[po + (size_t)y * P.stride_c + x];
     }
   }
+  }  // PHASE 1
+}
+
+template <typename PIX, bool SGR>
+void launch_lr_phases(const Av1miDevParams *P, int grid, const PIX *pre, const PIX *cdef, const PIX *src, PIX *out, uint8_t *choice,
+                      unsigned long long *unit_sse, hipStream_t stream) {
+  hipLaunchKernelGGL((lr_unit_kernel<PIX, SGR, 0>), dim3(grid), dim3(64), 0, stream, *P, pre, cdef, src, out, choice, unit_sse);
+  hipLaunchKernelGGL((lr_unit_kernel<PIX, SGR, 1>), dim3(grid), dim3(64), 0, stream, *P, pre, cdef, src, out, choice, unit_sse);
 }
 
 }  // namespace
 
+// unit_sse: P->n_frames x units x 8 sums (scratch of the two phases; cleared here).
 extern "C" hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice,
-                                      hipStream_t stream) {
+                                      unsigned long long *unit_sse, hipStream_t stream) {
   const int urows = (P->true_h + 32) / 64 > 0 ? (P->true_h + 32) / 64 : 1, ucols = (P->true_w + 32) / 64 > 0 ? (P->true_w + 32) / 64 : 1;
-  const int grid = P->n_frames * urows * ucols;
-  // enable_lr = 2 (RESTORE_SWITCHABLE): the instantiation with the self-guided candidates (61 KB of LDS per wave for the A/B grids)
+  const int units = P->n_frames * urows * ucols, grid = units * LR_SLICES;
+  hipError_t e = hipMemsetAsync(unit_sse, 0, (size_t)units * 8 * sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  // enable_lr = 2 (RESTORE_SWITCHABLE): the instantiation with the self-guided candidates (24 KB of LDS per wave)
   if (P->bit_depth == 8) {
-    if (P->enable_lr == 2) hipLaunchKernelGGL((lr_unit_kernel<uint8_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice);
-    else hipLaunchKernelGGL((lr_unit_kernel<uint8_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice);
+    if (P->enable_lr == 2) launch_lr_phases<uint8_t, true>(P, grid, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice, unit_sse, stream);
+    else launch_lr_phases<uint8_t, false>(P, grid, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice, unit_sse, stream);
   } else {
-    if (P->enable_lr == 2) hipLaunchKernelGGL((lr_unit_kernel<uint16_t, true>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice);
-    else hipLaunchKernelGGL((lr_unit_kernel<uint16_t, false>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice);
+    if (P->enable_lr == 2) launch_lr_phases<uint16_t, true>(P, grid, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice, unit_sse, stream);
+    else launch_lr_phases<uint16_t, false>(P, grid, (const uint16_t *)pre, (const uint16_t *)cdef, (const uint16_t *)src, (uint16_t *)out, choice, unit_sse, stream);
   }
   return hipGetLastError();
 }
