@@ -25,7 +25,7 @@
 #include "av1mi_dev.h"
 
 extern "C" {
-hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
+hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
                               const unsigned long long *me_best, hipStream_t s);
 hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, const unsigned long long *best, unsigned long long *refined,
                                       int me_range, int frame0, int count, hipStream_t stream);
@@ -413,6 +413,7 @@ struct av1mi_ctx {
   Av1miBlkInfo *d_blk = nullptr;
   uint8_t *d_slots = nullptr, *d_out = nullptr, *d_hdr = nullptr;
   uint16_t *d_cdf = nullptr;
+  Av1miDevParams *d_params = nullptr;  // copy of P for the kernels that read their parameters through a pointer (recon)
   uint32_t *d_tile_bytes = nullptr, *d_tile_off = nullptr, *d_frame_size = nullptr, *d_payload = nullptr, *d_sym = nullptr;
   uint32_t *d_streams = nullptr, *d_combos = nullptr;
   unsigned long long *d_frame_off = nullptr, *d_sse = nullptr;
@@ -455,11 +456,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -497,6 +498,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));
     HIPCHK(c, hipMalloc((void **)&c->d_hdr, 256 + nf * 512));
     HIPCHK(c, hipMalloc((void **)&c->d_cdf, Av1miCdfLayout::TOTAL * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_params, sizeof(Av1miDevParams)));
     HIPCHK(c, hipMalloc((void **)&c->d_tile_bytes, nf * nsb * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_tile_off, nf * nsb * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_sym, nf * nsb * 4));
@@ -766,6 +768,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   std::vector<uint16_t> cdf = make_cdf_blob(r.qidx);
   HIPCHK(c, hipMemcpyAsync(c->d_hdr, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemcpyAsync(c->d_cdf, cdf.data(), cdf.size() * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->d_params, &P, sizeof(P), hipMemcpyHostToDevice, s));  // the recon kernel reads its parameters from device memory
   HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, s));
   HIPCHK(c, hipMemsetAsync(c->d_sse, 0, (size_t)n_frames * 24, s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -790,7 +793,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   const bool lr = P.enable_lr != 0;
   void *cdef_out = lr ? c->d_cd : c->d_fin;   // with loop restoration CDEF writes d_cd and the restored frame goes to d_fin
   if (!inter_chunk) {
-    HIPCHK(c, av1mi_launch_recon(&P, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
+    HIPCHK(c, av1mi_launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
     if (lr) {  // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
       if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
       HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, s));
@@ -826,12 +829,12 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       Av1miBlkInfo *blkf = c->d_blk + f * nb8;
       int16_t *lvf = c->d_levels + f * nsb * AV1MI_SB_LEVELS;
       if (!av1mi_frame_is_inter(P, (int)f)) {
-        HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, nullptr, nullptr, s));
+        HIPCHK(c, av1mi_launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, nullptr, nullptr, s));
       } else {
         const uint8_t *reff = (const uint8_t *)c->d_fin + (f - 1) * fbytes;
         unsigned long long *mef = (P.subpel ? c->d_me_sub : c->d_me) + f * nb8;
         HIPCHK(c, hipStreamWaitEvent(s, c->me_ev[f], 0));
-        HIPCHK(c, av1mi_launch_recon(&P1, srcf, recf, lvf, blkf, reff, mef, s));
+        HIPCHK(c, av1mi_launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, reff, mef, s));
       }
       if (!av1mi_frame_is_inter(P, (int)f)) { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level[i]; }
       else { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level_inter[i]; }

@@ -239,12 +239,19 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
   int16_t *mid = g_mc.mid + grp * (NPL == 1 ? 0 : 23 * 16);
   const int ix0 = (px0 >> 4) - 3, iy0 = (py0 >> 4) - 3;
   const int16_t *fh = c_subpel[N <= 4][px0 & 15], *fv = c_subpel[N <= 4][py0 & 15];
-  for (int p = sl; p < WN * WN; p += G) {
-    const int i = p / WN, j = p - i * WN;
-    int yy = iy0 + i, xx = ix0 + j;
-    yy = yy < 0 ? 0 : (yy > last_y ? last_y : yy);
-    xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
-    win[p] = (uint16_t)rp[(size_t)yy * stride + xx];
+  {  // all loads of the window in flight together (a loop of dependent load -> LDS store pairs paid the latency 24 times)
+    constexpr int K = (WN * WN + G - 1) / G;
+    PIX v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int p = sl + k * G, i = p / WN, j = p - i * WN;
+      int yy = iy0 + i, xx = ix0 + j;
+      yy = yy < 0 ? 0 : (yy > last_y ? last_y : yy);
+      xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
+      v[k] = rp[(size_t)yy * stride + xx];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) { const int p = sl + k * G; if (p < WN * WN) win[p] = (uint16_t)v[k]; }
   }
   __syncthreads();
   for (int p = sl; p < WN * N; p += G) {
@@ -274,7 +281,7 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
 // SAD, DESIGN.md §3.3] -> prediction -> forward transform -> dead-zone quantiser -> normative
 // dequantiser + inverse transform -> reconstruction (HBM + line buffers).
 // `mode_io`: in = mode to use (chroma), out = decided mode (luma).  eob_out[g] = eob of group g.
-template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB>
+template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM>
 __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
                                                   int &mode_io, InterInfo &ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
   constexpr int N = 1 << LOG2N;
@@ -457,8 +464,10 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   // dead-zone quantiser + normative dequantiser (§7.12.3) of this lane's coefficient row.  QM: the step of every position
   // comes from the context's quantiser-matrix table {Round2(q * Quantizer_Matrix, 5), ceil(2^32 / that)}; the matrices are
   // symmetric, so lanes read entry [j][row] (consecutive addresses across the wave).
-  auto quant_row = [&](auto qm_tag) {
-    constexpr bool QM = decltype(qm_tag)::value;
+  if (tx_lane) {
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = S->scratch[so + sl * ST + j];
+    Tx1d<LOG2N>::fwd(x, ht);
     const int row = sl;
     constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
     const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row : nullptr;
@@ -493,13 +502,6 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
       }
       x[j] = d;
     }
-  };
-  if (tx_lane) {
-#pragma unroll
-    for (int j = 0; j < N; j++) x[j] = S->scratch[so + sl * ST + j];
-    Tx1d<LOG2N>::fwd(x, ht);
-    if (P->qm_tab) quant_row(std::true_type{});
-    else quant_row(std::false_type{});
   }
   for (int o = G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(my_key, o, 64); my_key = t > my_key ? t : my_key; }
   int eob = 0;
@@ -568,7 +570,7 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
   return 0;
 }
 
-template <typename PIX, bool INTER, int TSB>
+template <typename PIX, bool INTER, int TSB, bool QM>
 __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
                                                   Av1miBlkInfo *info, int b8_stride, const PIX *ref_frame,
                                                   const unsigned long long *me_best /* this superblock's first unit */) {
@@ -601,14 +603,14 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
     // luma (mode decision inside), then U and V together
     switch (bsl) {
-      case 5: tx_item<PIX, 5, 1, INTER, TSB>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      case 4: tx_item<PIX, 4, 1, INTER, TSB>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      default: tx_item<PIX, 3, 1, INTER, TSB>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 5: tx_item<PIX, 5, 1, INTER, TSB, QM>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 4: tx_item<PIX, 4, 1, INTER, TSB, QM>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      default: tx_item<PIX, 3, 1, INTER, TSB, QM>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
     }
     switch (bsl) {
-      case 5: tx_item<PIX, 4, 2, INTER, TSB>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      case 4: tx_item<PIX, 3, 2, INTER, TSB>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      default: tx_item<PIX, 2, 2, INTER, TSB>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 5: tx_item<PIX, 4, 2, INTER, TSB, QM>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 4: tx_item<PIX, 3, 2, INTER, TSB, QM>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      default: tx_item<PIX, 2, 2, INTER, TSB, QM>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
     }
     if (cx.lane == 0) {
       const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
@@ -626,11 +628,16 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
   }
 }
 
-template <typename PIX, bool INTER, int TSB>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_sb_kernel(Av1miDevParams P, const PIX *__restrict__ src, PIX *__restrict__ rec,
+template <typename PIX, bool INTER, int TSB, bool QM>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
                                                      const unsigned long long *__restrict__ me_best) {
+  // The parameters come through a pointer to device memory, not by value: the transform items are `noinline` and take the
+  // address of the block, and the address of a by-value kernel argument is a private copy - every lane wrote the whole
+  // structure (0.6 KB) to scratch at the start of the kernel and read its fields back from there.  Loads through a
+  // uniform const pointer are scalar loads.
+  const Av1miDevParams &P = *Pd;
   // one wave per TILE: TSB x TSB superblocks in raster order (TSB = 1 unless the frame needs more than 64 x 64 tiles)
   const int tiles_per_frame = P.tile_rows * P.tile_cols, sbs_per_frame = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
@@ -646,7 +653,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (sbr >= P.sb_rows || sbc >= P.sb_cols) continue;
     const int sb = sbr * P.sb_cols + sbc;
     SbCtx cx;
-    cx.P = &P; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
+    cx.P = Pd; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
     cx.tox = (si % TSB) * 64; cx.toy = (si / TSB) * 64;
     // decoded-block map (clear_block_decoded_flags, spec §5.11.3): the row above and the column left of the superblock
     // are decoded as far as the TILE reaches (so the above-right superblock of a two-superblock tile counts)
@@ -670,8 +677,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
     Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
     // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
-    encode_superblock<PIX, INTER, TSB>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
-                                       me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
+    encode_superblock<PIX, INTER, TSB, QM>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
+                                           me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
   }
 }
 #undef S
@@ -680,13 +687,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // ref == nullptr: P->n_frames key frames in one launch.  ref != nullptr: ONE inter frame (P->n_frames must be 1),
 // predicted from `ref` with the motion search results `me_best` of that frame.
-extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const void *src, void *rec, int16_t *levels,
+// dP: the same parameters in device memory (what the kernel reads; n_frames and the loop-filter levels are not used by it).
+extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels,
                                          Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, hipStream_t stream) {
   const int grid = P->n_frames * P->tile_rows * P->tile_cols;
   const bool inter = ref != nullptr;
-#define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                         \
-  hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)src, (PIXT *)rec, \
-                     levels, blk, (const PIXT *)ref, me_best)
+  // quantiser matrices (P->qm_tab): kernels of their own, so the plain quantiser's registers and scratch are what they were
+#define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \
+  do {                                                                                                                                      \
+    if (P->qm_tab) hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, true>), dim3(grid), dim3(64), 0, stream, dP, (const PIXT *)src,  \
+                                      (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                \
+    else hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, false>), dim3(grid), dim3(64), 0, stream, dP, (const PIXT *)src,           \
+                            (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                          \
+  } while (0)
   if (P->bit_depth == 8) {
     if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(uint8_t, true, 1); else RECON_LAUNCH(uint8_t, false, 1); }
     else { if (inter) RECON_LAUNCH(uint8_t, true, 2); else RECON_LAUNCH(uint8_t, false, 2); }
