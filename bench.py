@@ -248,7 +248,7 @@ def main():
         # runs of this same workload, profiles/); gfx950 correction: FETCH_SIZE counts 64 B per 128-B request.
         traffic = traffic_raw = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")))
             if (w, h, n, bd, args.block_log2, args.static_cdf, args.keyint, args.cq) == (1920, 1080, 60, 10, 5, False, 1, 30) and dom in pm["kernels"]:
                 kk = pm["kernels"][dom]
                 traffic_raw = (kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024
