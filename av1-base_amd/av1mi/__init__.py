@@ -193,9 +193,11 @@ class Context:
         _raise_for(rc, self.last_error())
         return list(sad), list(cut), state
 
-    def encode_chunk(self, params, frames, n_frames, on_device=False, want_recon=False, recon_ptr=None):
+    def encode_chunk(self, params, frames, n_frames, on_device=False, want_recon=False, recon_ptr=None, copy_out=True):
         """frames: bytes-like/numpy (host) or an int device pointer (on_device=True).
-        Returns (bitstream bytes, [frame sizes], Report, recon bytes or None)."""
+        Returns (bitstream bytes, [frame sizes], Report, recon bytes or None).  copy_out=False: the library's host buffer is
+        released without being copied into a Python object (first element None; Report.bytes has the size) - what a
+        throughput measurement wants: the C call has returned, the bitstream was complete in host memory."""
         import numpy as np
         out = Buf()
         sizes = (C.c_uint32 * n_frames)()
@@ -220,7 +222,7 @@ class Context:
                                      C.byref(rep))
         if rc:
             _raise_for(rc, self.last_error())
-        data = C.string_at(out.data, out.size)
+        data = C.string_at(out.data, out.size) if copy_out else None
         _lib.av1mi_free(out.data)
         return data, list(sizes), rep, recon
 

@@ -910,6 +910,9 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     syms.resize((size_t)n_frames * P.tile_rows * P.tile_cols);
     e1 = hipMemcpyAsync(syms.data(), c->d_sym, syms.size() * 4, hipMemcpyDeviceToHost, s);
   }
+  // the bitstream is on the host once ev[6] has passed: hand it over to the caller's buffer while the second stream finishes
+  if (e1 == hipSuccess && e2 == hipSuccess) e1 = hipEventSynchronize(c->ev[6]);
+  if (e1 == hipSuccess && e2 == hipSuccess && dst != host) memcpy(host, dst, total);
   if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
   if (e1 != hipSuccess || e2 != hipSuccess) {
     (void)hipStreamSynchronize(s2);
@@ -917,7 +920,6 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     set_err(c, "device-to-host copy failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return AV1MI_E_HIP;
   }
-  if (dst != host) memcpy(host, dst, total);
   out->data = host; out->size = total;
   if (frame_sizes) for (uint32_t f = 0; f < n_frames; f++) frame_sizes[f] = (uint32_t)(foff[f + 1] - foff[f]);
   if (report) {
