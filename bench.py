@@ -158,10 +158,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # rehearsal on a one-GPU box (the 8-GPU runs are the driver's): AV1MI_BENCH_BACKEND=gloo AV1MI_BENCH_ONE_DEVICE=1 runs the
+    # same multi-rank control flow with every rank on GPU 0 and the timing collectives over gloo
+    backend = os.environ.get("AV1MI_BENCH_BACKEND", "nccl")
+    if os.environ.get("AV1MI_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     import av1mi
@@ -225,7 +233,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
