@@ -209,6 +209,7 @@ struct InterInfo {
   int mv_row, mv_col;      // 1/8 luma samples (multiples of 8)
   int sad_inter;           // luma SAD of that vector
   int is_inter;
+  int pre_eob[3];          // PH == 2: the eobs of the block's inter version (recon_inter_pre_kernel computed it already)
 };
 
 // Motion-compensated sample (spec §7.11.3.4, unscaled reference, BILINEAR filter, not compound): position in 1/16
@@ -281,7 +282,11 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
 // SAD, DESIGN.md §3.3] -> prediction -> forward transform -> dead-zone quantiser -> normative
 // dequantiser + inverse transform -> reconstruction (HBM + line buffers).
 // `mode_io`: in = mode to use (chroma), out = decided mode (luma).  eob_out[g] = eob of group g.
-template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM>
+// PH = 0: the whole item.  Inter frames are reconstructed in two launches (recon_inter_pre_kernel, then recon_sb_kernel):
+// PH = 1 codes the block as an inter block, no neighbours involved (no edges, no mode decision, no line buffers);
+// PH = 2 takes the intra/inter decision with the neighbours in place and, when motion compensation wins, only moves the
+// finished block's edges from HBM into the line buffers - the block is coded here only if intra prediction wins.
+template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM, int PH>
 __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
                                                   int &mode_io, InterInfo &ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
   constexpr int N = 1 << LOG2N;
@@ -300,14 +305,36 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   const int pc = plane0 > 0;
   const int r4 = y0 >> 2, c4 = x0 >> 2;
   constexpr int step = (N >> 2) > 0 ? (N >> 2) : 1;
-  const int have_ar = S->blkdec[pc][r4 - 1 + 1][c4 + step + 1];
-  const int have_bl = S->blkdec[pc][r4 + step + 1][c4 - 1 + 1];
+  const int have_ar = PH == 1 ? 0 : S->blkdec[pc][r4 - 1 + 1][c4 + step + 1];
+  const int have_bl = PH == 1 ? 0 : S->blkdec[pc][r4 + step + 1][c4 - 1 + 1];
   const long poff = plane == 0 ? 0 : (plane == 1 ? P->plane_off_u : P->plane_off_v);
   const int gs = plane0 ? P->stride_c : P->stride_y;
   const int gx = (plane0 ? cx.sb_x >> 1 : cx.sb_x) + x0, gy = (plane0 ? cx.sb_y >> 1 : cx.sb_y) + y0;
   // tile-local plane coordinates of the block: what the line buffers and edge availability are indexed by
   const int lx = (plane0 ? cx.tox >> 1 : cx.tox) + x0, ly = (plane0 ? cx.toy >> 1 : cx.toy) + y0;
   const int have_above = ly > 0, have_left = lx > 0;
+  // PH == 2, motion compensation won: the block is already reconstructed in HBM - bottom row, right column and corners go to
+  // the line buffers, the decoded-block map and the eob are set, nothing else happens
+  auto inter_done = [&]() {
+    if constexpr (PH == 2) {
+      const PIX *pl = rec_frame + poff;
+      if (sl < N) {
+        LN.above[plane][lx + sl] = (uint16_t)pl[(size_t)(gy + N - 1) * gs + gx + sl];
+        LN.left[plane][ly + sl] = (uint16_t)pl[(size_t)(gy + sl) * gs + gx + N - 1];
+      }
+      if (sl < step) {
+        const int j = sl + 1;
+        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = (uint16_t)pl[(size_t)(gy + N - 1) * gs + gx + 4 * j - 1];
+        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = (uint16_t)pl[(size_t)(gy + 4 * j - 1) * gs + gx + N - 1];
+      }
+      for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
+      if (sl == 0) eob_out[grp] = ii.pre_eob[plane];
+      __syncthreads();
+    }
+  };
+  if constexpr (PH == 2) {
+    if (plane0 > 0 && ii.is_inter) { inter_done(); return; }
+  }
   // ---- source block -> LDS (coalesced rows)
   {
     const PIX *pl = frame + poff;
@@ -315,6 +342,8 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     for (int p = sl; p < N * N; p += G) S->srcblk[po + p] = (uint16_t)pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))];
   }
   // ---- edges from the line buffers (spec §7.11.2; tile == superblock: nothing outside it is available)
+  int dcv = 0;
+  if constexpr (PH != 1) {
   {
     const int max_x = ((plane0 ? P->width >> 1 : P->width) - 1) - (gx - lx);   // frame limit, tile-local
     const int max_y = ((plane0 ? P->height >> 1 : P->height) - 1) - (gy - ly);
@@ -351,7 +380,6 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   }
   __syncthreads();
   // ---- DC value (sum within the lane group)
-  int dcv;
   {
     int s = 0;
     if (sl < N) s = (have_above ? S->edge_a[eo + 1 + sl] : 0) + (have_left ? S->edge_l[eo + 1 + sl] : 0);
@@ -360,10 +388,13 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     else if (have_above || have_left) dcv = (s + (N >> 1)) >> LOG2N;
     else dcv = 1 << (bd - 1);
   }
+  } else {
+    __syncthreads();
+  }
   // ---- mode decision (luma) + final prediction: one loop, the last trip writes the prediction
   int best_mode = mode_io, best_sad = 0x7FFFFFFF, sad_dc = -1;
-  int first = (NPL == 1 && plane0 == 0) ? 0 : 13;
-  if (NPL == 1 && plane0 == 0 && P->mode_mask == 0x7u) {
+  int first = (PH != 1 && NPL == 1 && plane0 == 0) ? 0 : 13;
+  if (PH != 1 && NPL == 1 && plane0 == 0 && P->mode_mask == 0x7u) {
     // default candidate set {DC, V, H}: the three SADs in one pass over the block instead of three
     int s_dc = 0, s_v = 0, s_h = 0;
     const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
@@ -384,11 +415,14 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
 #pragma nounroll
   for (int m = first; m <= 13; m++) {
     const bool final_trip = m == 13;
-    if (final_trip && NPL == 1 && plane0 == 0) {
+    if (PH != 1 && final_trip && NPL == 1 && plane0 == 0) {
       // DC is kept unless the best other candidate at least halves its SAD
       if (sad_dc >= 0 && (best_sad == 0x7FFFFFFF || 2 * (long)best_sad >= (long)sad_dc)) { best_mode = DC_PRED; best_sad = sad_dc; }
       // inter frames: motion compensation wins when its luma SAD is not larger
       if (INTER) ii.is_inter = ii.sad_inter <= best_sad;
+      if constexpr (PH == 2) {
+        if (ii.is_inter) { mode_io = best_mode; inter_done(); return; }
+      }
     }
     const int mode = final_trip ? best_mode : m;
     if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
@@ -537,16 +571,18 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     PIX *pl = rec_frame + poff;
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))] = (PIX)S->blkpix[po + p];
-    if (sl < N) {
-      LN.above[plane][lx + sl] = S->blkpix[po + (N - 1) * N + sl];
-      LN.left[plane][ly + sl] = S->blkpix[po + sl * N + (N - 1)];
+    if constexpr (PH != 1) {
+      if (sl < N) {
+        LN.above[plane][lx + sl] = S->blkpix[po + (N - 1) * N + sl];
+        LN.left[plane][ly + sl] = S->blkpix[po + sl * N + (N - 1)];
+      }
+      if (sl < step) {  // corners at every 4-aligned position of the bottom row and right column
+        const int j = sl + 1;
+        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = S->blkpix[po + (N - 1) * N + 4 * j - 1];
+        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
+      }
+      for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
     }
-    if (sl < step) {  // corners at every 4-aligned position of the bottom row and right column
-      const int j = sl + 1;
-      LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = S->blkpix[po + (N - 1) * N + 4 * j - 1];
-      LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
-    }
-    for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
   }
   if (sl == 0) eob_out[grp] = eob;
   __syncthreads();
@@ -598,19 +634,22 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
         ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
       }
+      // the block's inter version is done (recon_inter_pre_kernel): its eobs, in case motion compensation wins
+      const Av1miBlkInfo &pre = info[(by >> 3) * b8_stride + (bx >> 3)];
+      ii.pre_eob[0] = pre.eob[0]; ii.pre_eob[1] = pre.eob[1]; ii.pre_eob[2] = pre.eob[2];
     }
     int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
     int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
     // luma (mode decision inside), then U and V together
     switch (bsl) {
-      case 5: tx_item<PIX, 5, 1, INTER, TSB, QM>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      case 4: tx_item<PIX, 4, 1, INTER, TSB, QM>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      default: tx_item<PIX, 3, 1, INTER, TSB, QM>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 5: tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 4: tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      default: tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
     }
     switch (bsl) {
-      case 5: tx_item<PIX, 4, 2, INTER, TSB, QM>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      case 4: tx_item<PIX, 3, 2, INTER, TSB, QM>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      default: tx_item<PIX, 2, 2, INTER, TSB, QM>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 5: tx_item<PIX, 4, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 4: tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      default: tx_item<PIX, 2, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
     }
     if (cx.lane == 0) {
       const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
@@ -681,6 +720,67 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                            me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
   }
 }
+
+// First launch of an inter frame: every leaf block coded as an INTER block - motion compensation with the search's vector,
+// transform, quantisation, reconstruction, levels - with one wave per cell of the largest block size, all blocks of the
+// frame at once: nothing here depends on a neighbour.  It leaves the reconstruction and the levels in place and a
+// provisional block-info entry (is_inter = 1, eobs, vector); recon_sb_kernel then walks the tiles in order for the part
+// that does depend on neighbours - the intra SAD of the decision and the blocks intra prediction wins.
+// (As one kernel a P frame was 510 waves of six serial block passes: 290 us of latency on the chunk's serial chain.)
+template <typename PIX, bool QM>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_inter_pre_kernel(const Av1miDevParams *__restrict__ Pd,
+                                                     const PIX *__restrict__ src, PIX *__restrict__ rec, int16_t *__restrict__ levels,
+                                                     Av1miBlkInfo *__restrict__ blk, const PIX *__restrict__ ref,
+                                                     const unsigned long long *__restrict__ me_best, int cell_log2) {
+  const Av1miDevParams &P = *Pd;
+  const int u = 1 << (cell_log2 - 3);
+  for (int uy = blockIdx.y * u; uy < (int)(blockIdx.y + 1) * u; uy++)
+    for (int ux = blockIdx.x * u; ux < (int)(blockIdx.x + 1) * u; ux++) {
+      const int x = ux * 8, y = uy * 8;
+      if (x >= P.width || y >= P.height) continue;
+      SbCtx cx;
+      cx.P = Pd; cx.lane = threadIdx.x; cx.sb_x = x & ~63; cx.sb_y = y & ~63; cx.tox = 0; cx.toy = 0;
+      const int bx = x - cx.sb_x, by = y - cx.sb_y;
+      const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
+      if (bsl == 0) continue;
+      const int n = 1 << bsl;
+      InterInfo ii;
+      ii.ref = ref; ii.is_inter = 1; ii.pre_eob[0] = ii.pre_eob[1] = ii.pre_eob[2] = 0;
+      const unsigned long long key = me_best[(size_t)uy * P.b8_cols + ux];
+      if (P.subpel) {
+        ii.mv_row = (int16_t)(key >> 16); ii.mv_col = (int16_t)key;
+        ii.sad_inter = (int)(key >> 36);
+      } else {
+        const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
+        const int dyv = idx / nc - R, dxv = idx % nc - R;
+        ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
+        ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
+      }
+      const int sb = (cx.sb_y >> 6) * P.sb_cols + (cx.sb_x >> 6);
+      int16_t *sb_levels = levels + (size_t)sb * AV1MI_SB_LEVELS;
+      int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
+      int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
+      int mode = 0;
+      __syncthreads();
+      switch (bsl) {
+        case 5: tx_item<PIX, 5, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+        case 4: tx_item<PIX, 4, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+        default: tx_item<PIX, 3, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      }
+      switch (bsl) {
+        case 5: tx_item<PIX, 4, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+        case 4: tx_item<PIX, 3, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+        default: tx_item<PIX, 2, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      }
+      if (threadIdx.x == 0) {
+        Av1miBlkInfo bi;
+        bi.ymode = 0; bi.skip = (uint8_t)((S->eobs[0] | S->eobs[1] | S->eobs[2]) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = 1;
+        bi.eob[0] = (uint16_t)S->eobs[0]; bi.eob[1] = (uint16_t)S->eobs[1]; bi.eob[2] = (uint16_t)S->eobs[2];
+        bi.mv_row = (int16_t)ii.mv_row; bi.mv_col = (int16_t)ii.mv_col; bi.pad = 0;
+        blk[(size_t)uy * P.b8_cols + ux] = bi;   // the leaf's origin unit is what recon_sb_kernel reads back
+      }
+    }
+}
 #undef S
 
 }  // namespace
@@ -692,6 +792,19 @@ extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDev
                                          Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, hipStream_t stream) {
   const int grid = P->n_frames * P->tile_rows * P->tile_cols;
   const bool inter = ref != nullptr;
+  if (inter) {  // first launch of an inter frame: every block as an inter block, all at once (see recon_inter_pre_kernel)
+    const int g = P->max_bs_log2 > 5 ? 5 : P->max_bs_log2, cell = 1 << g;
+    dim3 pgrid((P->width + cell - 1) / cell, (P->height + cell - 1) / cell);
+#define PRE_LAUNCH(PIXT)                                                                                                                     \
+    do {                                                                                                                                     \
+      if (P->qm_tab) hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, true>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec, \
+                                        levels, blk, (const PIXT *)ref, me_best, g);                                                         \
+      else hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, false>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec,          \
+                              levels, blk, (const PIXT *)ref, me_best, g);                                                                   \
+    } while (0)
+    if (P->bit_depth == 8) PRE_LAUNCH(uint8_t); else PRE_LAUNCH(uint16_t);
+#undef PRE_LAUNCH
+  }
   // quantiser matrices (P->qm_tab): kernels of their own, so the plain quantiser's registers and scratch are what they were
 #define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \
   do {                                                                                                                                      \
