@@ -338,7 +338,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   // ---- source block -> LDS (coalesced rows)
   {
     const PIX *pl = frame + poff;
-#pragma unroll 4
+#pragma unroll   // all of the block's loads in flight together (N*N/G <= 16 per lane)
     for (int p = sl; p < N * N; p += G) S->srcblk[po + p] = (uint16_t)pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))];
   }
   // ---- edges from the line buffers (spec §7.11.2; tile == superblock: nothing outside it is available)
@@ -723,8 +723,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // First launch of an inter frame: every leaf block coded as an INTER block - motion compensation with the search's vector,
 // transform, quantisation, reconstruction, levels - with one wave per cell of the largest block size, all blocks of the
-// frame at once: nothing here depends on a neighbour.  It leaves the reconstruction and the levels in place and a
-// provisional block-info entry (is_inter = 1, eobs, vector); recon_sb_kernel then walks the tiles in order for the part
+// frame at once (luma and chroma in waves of their own): nothing here depends on a neighbour.  It leaves the reconstruction
+// and the levels in place and the eobs in a provisional block-info entry; recon_sb_kernel then walks the tiles in order for the part
 // that does depend on neighbours - the intra SAD of the decision and the blocks intra prediction wins.
 // (As one kernel a P frame was 510 waves of six serial block passes: 290 us of latency on the chunk's serial chain.)
 template <typename PIX, bool QM>
@@ -762,22 +762,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
       int mode = 0;
       __syncthreads();
-      switch (bsl) {
-        case 5: tx_item<PIX, 5, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-        case 4: tx_item<PIX, 4, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-        default: tx_item<PIX, 3, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      }
-      switch (bsl) {
-        case 5: tx_item<PIX, 4, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-        case 4: tx_item<PIX, 3, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-        default: tx_item<PIX, 2, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      }
-      if (threadIdx.x == 0) {
-        Av1miBlkInfo bi;
-        bi.ymode = 0; bi.skip = (uint8_t)((S->eobs[0] | S->eobs[1] | S->eobs[2]) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = 1;
-        bi.eob[0] = (uint16_t)S->eobs[0]; bi.eob[1] = (uint16_t)S->eobs[1]; bi.eob[2] = (uint16_t)S->eobs[2];
-        bi.mv_row = (int16_t)ii.mv_row; bi.mv_col = (int16_t)ii.mv_col; bi.pad = 0;
-        blk[(size_t)uy * P.b8_cols + ux] = bi;   // the leaf's origin unit is what recon_sb_kernel reads back
+      // blockIdx.z = 0: the luma block, 1: the two chroma blocks - separate waves, half the latency; each leaves its eobs
+      // in the provisional block-info entry (the only fields recon_sb_kernel reads back)
+      Av1miBlkInfo *bi = &blk[(size_t)uy * P.b8_cols + ux];
+      if (blockIdx.z == 0) {
+        switch (bsl) {
+          case 5: tx_item<PIX, 5, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+          case 4: tx_item<PIX, 4, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+          default: tx_item<PIX, 3, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+        }
+        if (threadIdx.x == 0) bi->eob[0] = (uint16_t)S->eobs[0];
+      } else {
+        switch (bsl) {
+          case 5: tx_item<PIX, 4, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+          case 4: tx_item<PIX, 3, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+          default: tx_item<PIX, 2, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+        }
+        if (threadIdx.x == 0) { bi->eob[1] = (uint16_t)S->eobs[1]; bi->eob[2] = (uint16_t)S->eobs[2]; }
       }
     }
 }
@@ -794,7 +795,7 @@ extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDev
   const bool inter = ref != nullptr;
   if (inter) {  // first launch of an inter frame: every block as an inter block, all at once (see recon_inter_pre_kernel)
     const int g = P->max_bs_log2 > 5 ? 5 : P->max_bs_log2, cell = 1 << g;
-    dim3 pgrid((P->width + cell - 1) / cell, (P->height + cell - 1) / cell);
+    dim3 pgrid((P->width + cell - 1) / cell, (P->height + cell - 1) / cell, 2);   // z: luma | chroma
 #define PRE_LAUNCH(PIXT)                                                                                                                     \
     do {                                                                                                                                     \
       if (P->qm_tab) hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, true>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec, \
