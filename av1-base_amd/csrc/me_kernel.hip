@@ -101,9 +101,11 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
       a = __builtin_amdgcn_sad_u16(s2[k], (dxi & 1) ? rO[k + h] : rE[k + h], a);
       b = __builtin_amdgcn_sad_u16(s2[k + 4], (dxi & 1) ? rO[k + 4 + h] : rE[k + 4 + h], b);
     }
-    a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
-    a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
-    a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
+    // sum over the 8 lanes of the same parity inside each row of 16 lanes (the 8 rows of a sub-block): rotations within the
+    // row as DPP operands of the additions (row_ror 2, 4, 8) - a cross-lane shuffle each would go through the LDS pipe
+    a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x122, 0xF, 0xF, false); b += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x122, 0xF, 0xF, false);
+    a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x124, 0xF, 0xF, false); b += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x124, 0xF, 0xF, false);
+    a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x128, 0xF, 0xF, false); b += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x128, 0xF, 0xF, false);
     if ((r & 7) == 0) {  // lanes of the first row of each sub-block row: sub-blocks (r >> 3, 2 * half) and (.., 2 * half + 1)
       sad8[dxi][(r >> 3) * 4 + 2 * half] = a;
       sad8[dxi][(r >> 3) * 4 + 2 * half + 1] = b;
