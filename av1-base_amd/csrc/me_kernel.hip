@@ -112,7 +112,27 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
     }
   }
   __syncthreads();
-  // ---- leaves of the cell: lane u < 16 = 8x8 unit u; a leaf origin sums its sub-blocks for every dx
+  // ---- the usual cell: one 32x32 leaf.  Lane = dx candidate: each sums the 16 sub-block SADs of its dx, a wave minimum
+  // over (cost, candidate) picks the best of this dy (as one lane looping over the candidates it was a third of the kernel)
+  if (leaf_bsl_cell(P, cx, cy, 0, 0) == 5) {
+    if (cy + dy >= -16 && cy + dy + 32 <= H + 16) {
+      unsigned long long key = ~0ull;
+      if (lane < NC) {
+        const int dx = lane - R;
+        if (!(cx + dx < -16 || cx + dx + 32 > W + 16)) {
+          uint32_t sad = 0;
+#pragma unroll
+          for (int i = 0; i < 16; i++) sad += sad8[lane][i];
+          const unsigned long long cost = (unsigned long long)sad + (unsigned long long)(32 * (iabs(dx) + iabs(dy)));
+          key = (cost << 16) | (unsigned long long)(dyi * NC + lane);
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = t < key ? t : key; }
+      if (lane == 0 && key != ~0ull) atomicMin(&best[(size_t)(cy >> 3) * P.b8_cols + (cx >> 3)], key);
+    }
+    return;
+  }
+  // ---- other cells (smaller blocks, frame edges): lane u < 16 = 8x8 unit u; a leaf origin sums its sub-blocks for every dx
   if (lane < 16) {
     const int ux = lane & 3, uy = lane >> 2;
     const int bsl = leaf_bsl_cell(P, cx, cy, ux, uy);
