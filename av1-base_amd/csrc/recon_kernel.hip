@@ -651,18 +651,17 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
       case 4: tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
       default: tx_item<PIX, 2, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
     }
-    if (cx.lane == 0) {
-      const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
-      const int skip = (e0 | e1 | e2) == 0;
+    {  // the block's info into every 8x8 unit it covers: one lane per unit
       const int n8 = n >> 3;
-      for (int i = 0; i < n8; i++)
-        for (int j = 0; j < n8; j++) {
-          Av1miBlkInfo bi;
-          bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)skip; bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
-          bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2;
-          bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0); bi.pad = 0;
-          info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
-        }
+      if (cx.lane < n8 * n8) {
+        const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
+        const int i = cx.lane / n8, j = cx.lane - i * n8;
+        Av1miBlkInfo bi;
+        bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)((e0 | e1 | e2) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
+        bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2;
+        bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0); bi.pad = 0;
+        info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
+      }
     }
   }
 }
