@@ -173,6 +173,36 @@ def test_encode_file_y4m_to_ivf(av1mi, oracle, tmp_path):
     assert not list(tmp_path.glob("*.tmp*"))
 
 
+def test_encode_file_at_the_reference_operating_point(av1mi, oracle, tmp_path):
+    """The drop-in with the reference's SVT_PARAMS (av1an.rs:14: --crf 8 --film-grain 20 --enable-qm 1 --qm-min 1 --qm-max 15
+    --keyint 240) plus the tools SVT-AV1 has on at preset 3 (sub-sample motion, deblocking, restoration), 10-bit as the
+    reference's pix-format: several IPPP chunks through the worker pool, every temporal unit equal to the oracle's."""
+    w, h, bd, n, cf = 200, 120, 10, 10, 4
+    frames = [oracle.synthclip_frame(w, h, bd, seed=88, t=t) for t in range(n)]
+    y4m = tmp_path / "clip.y4m"
+    with open(y4m, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420p10\n" % (w, h))
+        for fr in frames:
+            f.write(b"FRAME\n" + raw_of(fr, bd))
+    out = tmp_path / "clip.obu"
+    rep = av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, tmp_path, av1mi.derive_plan(8), cq_level=8, chunk_frames=cf, keyint=240, film_grain=20,
+                                              enable_qm=1, qm_min=1, qm_max=15, subpel=1, deblock=1, enable_lr=2))
+    qidx = av1mi.cq_to_qindex(8)
+    lvl = oracle.qm_level(qidx, 1, 15)
+    ref_stream = b""
+    for c0 in range(0, n, cf):
+        ref = prev = None
+        for t in range(c0, min(n, c0 + cf)):
+            cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5, base_q_idx=qidx, subpel=1, deblock=1, enable_lr=2,
+                                        enable_qm=1, qm_y=lvl, qm_uv=lvl, film_grain=1, fg_y_scaling=40, fg_c_scaling=20,
+                                        fg_seed=(7391 + 173 * t) & 0xFFFF)
+            tu, rec, _ = oracle.encode_frame(cfg, frames[t], with_seq_hdr=(t == c0), ref=ref, prev_src=prev)
+            ref_stream += tu
+            ref, prev = rec, frames[t]
+    assert out.read_bytes() == ref_stream
+    assert rep.frames == n and rep.chunks == 3
+
+
 def test_stress_carries_and_long_tiles(av1mi, ctx, oracle):
     """High-rate content (uniform noise, low CQ) makes long tiles, many output bytes, 0xFF runs and
     carries that ripple into words already stored - the paths of the range-coding kernel that ordinary
