@@ -38,7 +38,7 @@ hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void 
                            unsigned long long *unit_sse, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
-                                const uint8_t *lr_choice,
+                                const uint8_t *lr_choice, uint32_t *tile_order,
                                 hipStream_t s, hipEvent_t mid);
 hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t s);
 hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
@@ -852,7 +852,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   // second stream; symbolize and CDEF are both throughput-bound and would only slow each other.
   hipStream_t s2 = getenv("AV1MI_SERIAL") ? c->stream : c->stream2;  // AV1MI_SERIAL: single-stream timing experiments
   HIPCHK(c, hipEventRecord(c->ev[3], s));
-  HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc, s, c->ev[7]));
+  HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
+                                 c->d_tile_off /* scratch until the packing kernels fill it */, s, c->ev[7]));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   if (!inter_chunk && !lr && P.lf_level[0]) {  // deblocking reads only the reconstruction and block info: beside symbolize
     HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));

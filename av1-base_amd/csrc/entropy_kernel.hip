@@ -739,6 +739,31 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
 }
 #undef S
 
+// Tiles in the order of decreasing symbol-stream length, to batches of 16 entries: a counting sort in one workgroup
+// (histogram over length / 16 in LDS, exclusive scan, scatter).  Which tile of a bucket comes first does not matter -
+// every tile writes only its own slot.
+__global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles, const uint32_t *__restrict__ stream_len, uint32_t *__restrict__ order) {
+  __shared__ uint32_t hist[1024];
+  __shared__ uint32_t base[1024];
+  const int t = threadIdx.x;
+  hist[t] = 0;
+  __syncthreads();
+  for (int i = t; i < n_tiles; i += 1024) {
+    const uint32_t b = stream_len[i] >> 4;
+    atomicAdd(&hist[1023 - (b > 1023 ? 1023 : b)], 1u);
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t acc = 0;
+    for (int k = 0; k < 1024; k++) { base[k] = acc; acc += hist[k]; }
+  }
+  __syncthreads();
+  for (int i = t; i < n_tiles; i += 1024) {
+    const uint32_t b = stream_len[i] >> 4;
+    order[atomicAdd(&base[1023 - (b > 1023 ? 1023 : b)], 1u)] = (uint32_t)i;
+  }
+}
+
 // ================================================================================= K4
 // One lane per tile, 64 tiles per workgroup, TWO waves per workgroup working as a pipeline:
 //   wave 0 (resolver): walks the tile's stream, adapts the tile's narrow CDF rows (LDS, [slot][lane] x
@@ -756,10 +781,13 @@ __shared__ RcLds g_rc;
 __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, int n_tiles, const uint16_t *__restrict__ cdf_init,
                                                              const uint32_t *__restrict__ streams, const uint32_t *__restrict__ stream_len,
                                                              const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
-                                                             uint32_t *__restrict__ tile_bytes) {
+                                                             uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ order) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 64 + lane;
-  const bool live = tile < n_tiles;
+  // order != nullptr (more tiles than the chip holds workgroups for at once): the 64 tiles of a workgroup are neighbours in
+  // the order of decreasing stream length (tile_order_kernel) - a wave lasts as long as its longest tile, so similar lengths
+  // waste the fewest lane-cycles, and the long ones start first
+  const bool live = (int)(blockIdx.x * 64 + lane) < n_tiles;
+  const int tile = live ? (order ? (int)order[blockIdx.x * 64 + lane] : (int)(blockIdx.x * 64 + lane)) : n_tiles;
   const int count_raw = live ? (int)stream_len[tile] : 0;
   const bool overflow = count_raw > P.stream_cap;
   const int count = overflow ? 0 : count_raw;
@@ -921,7 +949,8 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
 
 extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels,
                                            const Av1miBlkInfo *blk, uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos,
-                                           uint8_t *slots, uint32_t *tile_bytes, const uint8_t *lr_choice, hipStream_t stream, hipEvent_t mid) {
+                                           uint8_t *slots, uint32_t *tile_bytes, const uint8_t *lr_choice, uint32_t *tile_order /* n_tiles entries of scratch */,
+                                           hipStream_t stream, hipEvent_t mid) {
   const int n_tiles = P->n_frames * P->tile_rows * P->tile_cols;
   const bool has_inter = P->keyint > 1 && P->n_frames > 1;
 #define SYM_LAUNCH(FULLV, INTERV, TSBV)                                                                                                   \
@@ -936,7 +965,13 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   }
 #undef SYM_LAUNCH
   if (mid) (void)hipEventRecord(mid, stream);
+  // The range coder holds 2 workgroups (of 64 tiles) per CU.  Up to that many workgroups all run at once and the kernel lasts
+  // as long as its longest tile: the natural order is best (a workgroup of 64 long tiles would be slower per symbol than
+  // one long tile among short ones - measured 1.1 -> 2.1 ms).  Beyond it the workgroups run in rounds, and what counts is
+  // the sum over workgroups of their longest tile: sorted order (4K, 30 frames: 3.9 -> 2.9 ms).
+  const bool sorted = (n_tiles + 63) / 64 > 2 * 256;
+  if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len, tile_order);
   hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
-                     tile_combos, slots, tile_bytes);
+                     tile_combos, slots, tile_bytes, sorted ? tile_order : (uint32_t *)nullptr);
   return hipGetLastError();
 }
