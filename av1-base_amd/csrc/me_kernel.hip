@@ -9,13 +9,14 @@
 // candidate in (dy, dx) raster order.
 //
 // MI355X mapping: the search is open loop (source against previous source), so it does not sit on the frame-by-frame
-// reconstruction chain of a chunk: ONE launch searches every inter frame of the chunk (grid.z = frame) on a second
+// reconstruction chain of a chunk: the inter frames are searched up front, a launch and an event per frame, on a second
 // stream while the chain runs.  Grid x/y = (32x32 cells of the frame) x (2R+1 values of dy) = 34 680 waves per 1080p
 // frame at R = 8.  A wave owns one cell and one
 // dy: lane = 16 consecutive samples of one cell row (source in registers, the 16 + 2R reference samples the
 // 2R+1 dx candidates need in registers, each loaded once); per dx the lane forms two 8-sample partial SADs,
-// xor-shuffles over the row bits turn them into the 16 8x8 sub-block SADs of the cell, and the leaf blocks of the
-// cell (one 32x32, or 16x16 / 8x8 blocks at frame edges or smaller block sizes) sum their sub-blocks from LDS.
+// DPP row rotations turn them into the 16 8x8 sub-block SADs of the cell, and the leaf blocks of the
+// cell (one 32x32 - its dx candidates then reduced one per lane - or 16x16 / 8x8 blocks at frame edges or smaller block
+// sizes) sum their sub-blocks from LDS.
 // Each leaf's best candidate of this dy goes into a 64-bit atomicMin on (cost << 16 | candidate index).
 // Algorithmic HBM bytes per frame: source luma read once + reference luma read once = 2*L*b (L luma samples);
 // the (2R+1)-fold re-reads of the reference by the dy waves of a cell are L2 hits.

@@ -1,5 +1,6 @@
-// recon_kernel.hip - closed-loop intra reconstruction of one 64x64 superblock (= one tile) per
-// wavefront, for every superblock of every frame of a chunk in one launch.
+// recon_kernel.hip - closed-loop reconstruction: one tile (1 or 2x2 64x64 superblocks) per wavefront, every tile of every
+// key frame of a chunk in one launch (recon_sb_kernel); inter frames one at a time, in two launches - every block as an
+// inter block in parallel (recon_inter_pre_kernel), then the tile walk that decides and codes the intra winners.
 //
 // Replaces the per-superblock inner loop that the reference runs inside an external SVT-AV1
 // worker (av1an -> SVT-AV1, reached through `run_av1an`,
@@ -7,9 +8,9 @@
 // directional/smooth/Paeth/DC intra prediction (AV1 spec §7.11.2), forward DCT/ADST, dead-zone
 // quantiser, normative dequantiser (§7.12.3) and inverse DCT/ADST (§7.13.3).
 //
-// MI355X mapping: one 64-lane wave owns one superblock; the superblock's
-// reconstruction lives in LDS (u16 planes) for the whole walk, so neighbour edges never touch
-// HBM; source pixels are read once (coalesced rows) into registers; transforms run one row or
+// MI355X mapping: one 64-lane wave owns one tile; the edges its blocks predict from
+// live in LDS line buffers for the whole walk, so neighbour edges never touch
+// HBM; source pixels are read once (coalesced rows); transforms run one row or
 // column per lane on VGPR-resident straight-line butterflies (txfm_gen.h) with the 2-D
 // transposition staged through a padded LDS tile (stride n+1: conflict-free for both row and
 // column access); quantised levels are staged in LDS and leave as 16-byte-per-lane stores.
