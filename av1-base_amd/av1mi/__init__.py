@@ -36,13 +36,13 @@ E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_OOM, E_OVERFLOW, E_FORMAT, E_UNSUPPORTED = 
 
 # every symbol include/av1mi.h declares
 ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", "av1mi_last_error", "av1mi_encode_chunk",
-               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute"]
+               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute", "av1mi_probe_y4m"]
 
 
 class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "bit_depth", "cq_level", "keyint", "block_log2", "cdf_update",
                                           "enable_cdef", "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec",
-                                          "cdef_damping")] + [("intra_mode_mask", C.c_uint32), ("film_grain", C.c_uint32), ("first_frame", C.c_uint32), ("me_range", C.c_uint32), ("enable_lr", C.c_uint32), ("tile_sb", C.c_uint32), ("deblock", C.c_uint32), ("enable_qm", C.c_uint32), ("qm_min", C.c_uint32), ("qm_max", C.c_uint32), ("subpel", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                                          "cdef_damping")] + [("intra_mode_mask", C.c_uint32), ("film_grain", C.c_uint32), ("first_frame", C.c_uint32), ("me_range", C.c_uint32), ("enable_lr", C.c_uint32), ("tile_sb", C.c_uint32), ("deblock", C.c_uint32), ("enable_qm", C.c_uint32), ("qm_min", C.c_uint32), ("qm_max", C.c_uint32), ("subpel", C.c_uint32), ("color_range", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class Buf(C.Structure):
@@ -79,6 +79,12 @@ class JobMetrics(C.Structure):
                 ("size_in_bytes_after", C.c_uint64)]
 
 
+class ClipInfo(C.Structure):
+    """include/av1mi.h: av1mi_clip_info"""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bit_depth", C.c_uint32), ("fps_num", C.c_uint32), ("fps_den", C.c_uint32),
+                ("color_range", C.c_uint32), ("frames", C.c_uint64)]
+
+
 STATE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.POINTER(JobMetrics))
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64)
 
@@ -94,6 +100,7 @@ _lib.av1mi_scene_cuts.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c
                                   C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
 _lib.av1mi_encode_file.argtypes = [C.POINTER(Job), PROGRESS_CB, C.c_void_p, C.POINTER(Report)]
 _lib.av1mi_job_execute.argtypes = [C.POINTER(ExecJob), STATE_CB, C.c_void_p, C.POINTER(JobMetrics), C.c_char_p, C.c_size_t]
+_lib.av1mi_probe_y4m.argtypes = [C.c_char_p, C.POINTER(ClipInfo)]
 _lib.av1mi_cq_to_qindex.argtypes = [C.c_uint32]
 _lib.av1mi_cq_to_qindex.restype = C.c_uint32
 _lib.av1mi_abi_version.restype = C.c_uint32
@@ -137,6 +144,13 @@ def default_params(width, height, bit_depth=8, **kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def probe_y4m(path):
+    """Geometry, frame rate, range tag and frame count of a Y4M file (include/av1mi.h: av1mi_probe_y4m)."""
+    ci = ClipInfo()
+    _raise_for(_lib.av1mi_probe_y4m(os.fspath(path).encode(), C.byref(ci)))
+    return ci
 
 
 def cq_to_qindex(cq):

@@ -38,7 +38,7 @@ void on_progress(void *user, uint32_t done, uint32_t total, double fps, uint64_t
   st.m.total_frames = total;
   st.m.progress = total ? (float)done / (float)total : 0.f;
   st.m.fps = (float)fps;
-  st.m.bitrate_kbps = done ? (float)((double)bytes * 8.0 / 1000.0 / ((double)done / 30.0)) : 0.f;  // at a nominal 30 fps
+  st.m.bitrate_kbps = done ? (float)((double)bytes * 8.0 / 1000.0 / ((double)done / st.fps_n_over_d)) : 0.f;  // at the clip's own frame rate
   if (st.cb) st.cb(st.user, st.m.stage, &st.m);
 }
 
@@ -82,6 +82,11 @@ extern "C" int av1mi_job_execute(const av1mi_exec_job *job, av1mi_state_cb state
     if (metrics) *metrics = st.m;
     return code;
   };
+  {  // the clip's frame rate (bitrate) - the reference has no source for it (JobMetrics.bitrate_kbps stays 0, job_executor.rs:117-137); here from the Y4M header
+    av1mi_clip_info ci = {};
+    st.fps_n_over_d = (av1mi_probe_y4m(job->input_path, &ci) == AV1MI_OK && ci.fps_num && ci.fps_den) ? (double)ci.fps_num / ci.fps_den : 30.0;
+    st.m.total_frames = ci.frames;
+  }
   set_stage(st, "encoding");                          // job.state = JobState::Encoding (job_executor.rs:270)
   const std::string chunks = std::string(job->temp_base_dir) + "/chunks_" + job->id;  // :274
   int rc = mkdir_p(chunks);                           // create_dir_all -> JobError::TempDirCreation

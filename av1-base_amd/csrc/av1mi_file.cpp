@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -30,7 +31,9 @@ namespace {
 struct Y4m {
   FILE *f = nullptr;
   uint32_t w = 0, h = 0, bd = 8, fps_n = 30, fps_d = 1;
+  int color_range = -1;       // XCOLORRANGE tag: 0 LIMITED, 1 FULL, -1 absent
   size_t frame_bytes = 0;
+  uint64_t total_frames = 0;  // from the file size (plain "FRAME\n" markers); 0 = unknown (pipe)
 };
 
 int y4m_open(const char *path, Y4m *y) {
@@ -48,6 +51,10 @@ int y4m_open(const char *path, Y4m *y) {
       case 'W': y->w = (uint32_t)atoi(tok + 1); break;
       case 'H': y->h = (uint32_t)atoi(tok + 1); break;
       case 'F': sscanf(tok + 1, "%u:%u", &y->fps_n, &y->fps_d); break;
+      case 'X':
+        if (!strcmp(tok, "XCOLORRANGE=FULL")) y->color_range = 1;
+        else if (!strcmp(tok, "XCOLORRANGE=LIMITED")) y->color_range = 0;
+        break;
       case 'C':
         if (strncmp(tok + 1, "420p10", 6) == 0) y->bd = 10;
         else if (strncmp(tok + 1, "420", 3) == 0 && (tok[4] == 0 || tok[4] == 'j' || tok[4] == 'm' || (tok[4] == 'p' && tok[5] == 'a'))) y->bd = 8;
@@ -57,7 +64,14 @@ int y4m_open(const char *path, Y4m *y) {
     }
   }
   if (!ok420 || !y->w || !y->h) return AV1MI_E_FORMAT;
+  if (!y->fps_n || !y->fps_d) { y->fps_n = 30; y->fps_d = 1; }
   y->frame_bytes = (size_t)y->w * y->h * 3 / 2 * (y->bd > 8 ? 2 : 1);
+  {  // frame count of a regular file: every frame is "FRAME\n" + frame_bytes (frame parameters would only make this an over-estimate)
+    const long pos = ftell(y->f);
+    struct stat sb;
+    if (pos >= 0 && fstat(fileno(y->f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > pos)
+      y->total_frames = (uint64_t)(sb.st_size - pos) / (6 + y->frame_bytes);
+  }
   return 0;
 }
 
@@ -215,6 +229,18 @@ struct Chunk {
 
 }  // namespace
 
+extern "C" int av1mi_probe_y4m(const char *path, av1mi_clip_info *info) {
+  if (!path || !info) return AV1MI_E_INVALID_ARG;
+  Y4m y;
+  const int rc = y4m_open(path, &y);
+  if (y.f) fclose(y.f);
+  if (rc) return rc;
+  info->width = y.w; info->height = y.h; info->bit_depth = y.bd; info->fps_num = y.fps_n; info->fps_den = y.fps_d;
+  info->color_range = y.color_range > 0 ? 1u : 0u;
+  info->frames = y.total_frames;
+  return AV1MI_OK;
+}
+
 extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total) {
   if (!job || !job->input_path || !job->output_path) return AV1MI_E_INVALID_ARG;
   Y4m y;
@@ -222,6 +248,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   if (rc) { if (y.f) fclose(y.f); return rc; }
   av1mi_params prm = job->params;
   prm.width = y.w; prm.height = y.h; prm.bit_depth = y.bd;
+  if (y.color_range >= 0) prm.color_range = (uint32_t)y.color_range;  // the clip's own tag wins over the job's default
   const bool scene_mode = job->chunk_frames == 0;
   const uint32_t chunk_frames = job->chunk_frames ? job->chunk_frames : 60;
   // contexts: `workers` chunks in flight, spread round-robin over the allowed GPUs
@@ -316,7 +343,9 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
         tot.ms_pack += ck->rep.ms_pack; tot.ms_h2d += ck->rep.ms_h2d; tot.ms_d2h += ck->rep.ms_d2h; tot.ms_total += ck->rep.ms_total;
         if (cb) {
           double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-          cb(user, frames_done, frames_read, sec > 0 ? frames_done / sec : 0.0, bytes_out);
+          // total: the clip's length when the input is a regular file, else the frames read so far
+          const uint32_t tot_frames = y.total_frames >= frames_read ? (uint32_t)y.total_frames : frames_read;
+          cb(user, frames_done, tot_frames, sec > 0 ? frames_done / sec : 0.0, bytes_out);
         }
       }
       av1mi_free(ck->out.data);

@@ -105,7 +105,7 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
-  if (p.subpel > 1 || p.enable_lr > 2) return AV1MI_E_INVALID_ARG;
+  if (p.subpel > 1 || p.enable_lr > 2 || p.color_range > 1) return AV1MI_E_INVALID_ARG;
   if (p.enable_qm > 1 || p.qm_min > 15 || p.qm_max > 15 || (p.enable_qm && p.qm_min > p.qm_max)) return AV1MI_E_INVALID_ARG;
   // level from the quantiser index, as SVT-AV1 / libaom derive it ("--qm-min", "--qm-max")
   r->qm_level = p.enable_qm ? (int)(p.qm_min + (uint32_t)r->qidx * (p.qm_max + 1 - p.qm_min) / 256) : 15;
@@ -165,7 +165,7 @@ std::vector<uint8_t> make_sequence_header(const Resolved &r) {
   b.put(p.bit_depth > 8, 1);  // high_bitdepth
   b.put(0, 1);                // mono_chrome
   b.put(0, 1);                // color_description_present_flag
-  b.put(1, 1);                // color_range
+  b.put(p.color_range ? 1 : 0, 1);  // color_range: 0 = studio (limited) range, 1 = full range
   b.put(0, 2);                // chroma_sample_position
   b.put(0, 1);                // separate_uv_delta_q
   b.put(p.film_grain ? 1 : 0, 1);  // film_grain_params_present
@@ -468,8 +468,11 @@ void free_workspace(av1mi_ctx *c) {
 
 int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   const av1mi_params &p = r.p;
+  // the per-tile buffers (symbol streams, bitstream slots, packed output) are sized by the tile grid and the per-tile
+  // capacities, which follow tile_sb: a context that switches tile_sb at the same frame size must not reuse them
+  // (648x360: 66 tiles x 4096 entries at tile_sb 1, but 18 x 16384 at tile_sb 2)
   bool same = c->cap_frames >= n_frames && c->res.p.width == p.width && c->res.p.height == p.height && c->res.p.bit_depth == p.bit_depth &&
-              c->ws_scale == c->cap_scale;
+              c->ws_scale == c->cap_scale && c->res.tile_sb == r.tile_sb;
   const int bps = p.bit_depth > 8 ? 2 : 1;
   const size_t frame_samples = (size_t)r.cw * r.ch * 3 / 2;   // coded size
   const size_t nsb = (size_t)r.sb_cols * r.sb_rows;

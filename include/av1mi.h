@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AV1MI_ABI_VERSION 3
+#define AV1MI_ABI_VERSION 4
 
 /* positive failure codes (-> Av1anFailed(code)) */
 enum {
@@ -73,7 +73,10 @@ typedef struct {
   uint32_t subpel;          /* inter frames: 1 = quarter-sample motion vectors (the full search's winner refined over its half- and then
                                quarter-sample neighbours) predicted with the 8-tap EIGHTTAP filter; 0 (default) = whole-sample
                                vectors, frame filter BILINEAR */
-  uint32_t reserved[2];
+  uint32_t color_range;     /* color_config.color_range of the sequence header: 0 (default) = studio / limited range - what Y4M input and the
+                               reference's pipeline (ffmpeg -> SVT-AV1, `--pix-format yuv420p10le`, av1an.rs:90) carry; 1 = full range.
+                               av1mi_encode_file takes it from the Y4M header's XCOLORRANGE tag when there is one */
+  uint32_t reserved[1];
 } av1mi_params;
 
 typedef struct {
@@ -160,8 +163,17 @@ typedef struct {
   av1mi_params params;      /* width/height/bit_depth are taken from the Y4M header */
 } av1mi_job;
 
+/* frames_total: the clip's length when the input is a regular file (from its size), else the frames read so far */
 typedef void (*av1mi_progress_cb)(void *user, uint32_t frames_done, uint32_t frames_total, double fps,
                                   uint64_t bytes_out);
+
+/* What the daemon's probe pass (JobMetrics.total_frames / bitrate_kbps, crates/daemon/src/metrics.rs:12-30; zeros today, job_executor.rs:117-137) needs
+ * from a Y4M input: geometry, frame rate, range tag, frame count (0 = unknown: not a regular file). */
+typedef struct {
+  uint32_t width, height, bit_depth, fps_num, fps_den, color_range;
+  uint64_t frames;
+} av1mi_clip_info;
+int av1mi_probe_y4m(const char *path, av1mi_clip_info *info);
 
 int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total);
 

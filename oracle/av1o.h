@@ -71,6 +71,8 @@ typedef struct {
    * --qm-min 1 --qm-max 15`, av1an.rs:14): level 0 (steepest) .. 14, 15 = flat (no matrix for that plane) */
   int enable_qm;          /* 1: using_qmatrix */
   int qm_y, qm_uv;        /* qm_y; qm_u = qm_v (separate_uv_delta_q is 0) */
+  int color_range;        /* color_config.color_range: 0 = studio / limited (default: what Y4M and the reference's ffmpeg -> SVT-AV1
+                             pipeline carry), 1 = full */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */

@@ -134,7 +134,7 @@ static void write_color_config(BitW *b, const Av1oConfig *cfg) {
   bw_put(b, cfg->bit_depth > 8, 1); /* high_bitdepth (profile 0: no twelve_bit) */
   bw_put(b, 0, 1);                  /* mono_chrome */
   bw_put(b, 0, 1);                  /* color_description_present_flag */
-  bw_put(b, 1, 1);                  /* color_range: full */
+  bw_put(b, cfg->color_range ? 1 : 0, 1); /* color_range: 0 studio (limited), 1 full */
   bw_put(b, 0, 2);                  /* chroma_sample_position (4:2:0): unknown */
   bw_put(b, 0, 1);                  /* separate_uv_delta_q */
 }

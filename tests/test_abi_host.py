@@ -31,7 +31,7 @@ def test_exports_every_declared_symbol(av1mi):
     lib = C.CDLL(os.path.abspath(av1mi.LIB_PATH))
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert av1mi._lib.av1mi_abi_version() == 3
+    assert av1mi._lib.av1mi_abi_version() == 4
 
 
 def test_cq_mapping_matches_aom_table(av1mi):
@@ -60,6 +60,44 @@ def test_headers_match_oracle(av1mi, oracle, w, h, bd, cdf):
         buf = C.create_string_buffer(64)
         n = oracle.lib().av1o_write_sequence_header(C.byref(cfg), buf, 64)
         assert buf.raw[:n] == seq
+
+
+def test_color_range_bit_of_the_sequence_header(av1mi, oracle):
+    """color_config.color_range: studio (0) unless asked otherwise - Y4M input and the reference's ffmpeg -> SVT-AV1 pipeline
+    carry limited-range video; the bit must follow av1mi_params.color_range exactly as the oracle writes it."""
+    seqs = {}
+    for cr in (0, 1):
+        p = av1mi.default_params(200, 120, 10, color_range=cr)
+        seq, _, _ = av1mi.write_headers(p)
+        cfg = oracle.default_config(200, 120, 10, color_range=cr)
+        buf = C.create_string_buffer(64)
+        n = oracle.lib().av1o_write_sequence_header(C.byref(cfg), buf, 64)
+        assert buf.raw[:n] == seq
+        seqs[cr] = seq
+    assert seqs[0] != seqs[1] and av1mi.default_params(64, 64, 8).color_range == 0
+    with pytest.raises(av1mi.EncodeFailed):
+        av1mi.write_headers(av1mi.default_params(64, 64, 8, color_range=2))
+
+
+def test_probe_y4m_reports_rate_range_and_length(av1mi, tmp_path):
+    """av1mi_probe_y4m: what JobMetrics.total_frames / bitrate_kbps need (frame count from the file size, frame rate),
+    plus the XCOLORRANGE tag; malformed input is AV1MI_E_FORMAT, a missing file -errno."""
+    w, h, n = 72, 56, 5
+    f = tmp_path / "a.y4m"
+    f.write_bytes(b"YUV4MPEG2 W%d H%d F30000:1001 Ip A1:1 C420p10 XYSCSS=420P10 XCOLORRANGE=FULL\n" % (w, h) + (b"FRAME\n" + bytes(w * h * 3)) * n)
+    ci = av1mi.probe_y4m(f)
+    assert (ci.width, ci.height, ci.bit_depth, ci.fps_num, ci.fps_den, ci.color_range, ci.frames) == (w, h, 10, 30000, 1001, 1, n)
+    g = tmp_path / "b.y4m"
+    g.write_bytes(b"YUV4MPEG2 W%d H%d F25:1 C420jpeg\n" % (w, h) + (b"FRAME\n" + bytes(w * h * 3 // 2)) * 2)
+    ci = av1mi.probe_y4m(g)
+    assert (ci.bit_depth, ci.fps_num, ci.fps_den, ci.color_range, ci.frames) == (8, 25, 1, 0, 2)
+    bad = tmp_path / "c.y4m"
+    bad.write_bytes(b"RIFF....")
+    with pytest.raises(av1mi.EncodeFailed) as ei:
+        av1mi.probe_y4m(bad)
+    assert ei.value.code == av1mi.E_FORMAT
+    with pytest.raises(av1mi.EncodeIo):
+        av1mi.probe_y4m(tmp_path / "missing.y4m")
 
 
 def test_invalid_parameters_map_to_failed(av1mi):

@@ -495,8 +495,49 @@ def test_job_execute_segment_states_and_metrics(av1mi, oracle, tmp_path):
     rc, stages, m, err = av1mi.job_execute("abc", y4m, out, tmp_path / "work", workers=2, keyint=4)
     assert rc == 0 and err == "" and stages == ["encoding", "validating", "size_gating"]
     assert m.frames_encoded == n and m.total_frames == n and m.progress == 1.0 and m.fps > 0 and m.bitrate_kbps > 0
+    # bitrate at the clip's own frame rate (30 fps here): bytes of the finished file over n / 30 seconds, within the container overhead
+    assert 0.5 < m.bitrate_kbps / (m.size_in_bytes_after * 8 / 1000 / (n / 30)) <= 1.0
     assert m.size_in_bytes_after == out.stat().st_size > 0 and 25 < m.psnr < 60 and m.crf == 30 and m.workers == 2
     assert (tmp_path / "work").exists() and not (tmp_path / "work" / "chunks_abc").exists()
+
+
+def test_progress_reports_the_clip_length_and_range_tag_is_honoured(av1mi, oracle, tmp_path):
+    """The progress callback's total is the clip's length from the start (not "frames read so far"), progress is monotonic,
+    and an XCOLORRANGE=FULL tag of the Y4M header ends up in the sequence header (default: studio range)."""
+    w, h, n = 72, 56, 10
+    frames = [oracle.synthclip_frame(w, h, 8, seed=83, t=t) for t in range(n)]
+    streams = {}
+    for tag, cr in ((b"", 0), (b" XCOLORRANGE=FULL", 1), (b" XCOLORRANGE=LIMITED", 0)):
+        y4m = tmp_path / ("clip%d%d.y4m" % (cr, len(tag)))
+        with open(y4m, "wb") as f:
+            f.write(b"YUV4MPEG2 W%d H%d F24:1 Ip A1:1 C420jpeg%s\n" % (w, h, tag))
+            for fr in frames:
+                f.write(b"FRAME\n" + raw_of(fr, 8))
+        out = tmp_path / ("o%d%d.obu" % (cr, len(tag)))
+        seen = []
+        av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, tmp_path, av1mi.derive_plan(8, workers_override=2), chunk_frames=2),
+                         progress=lambda d, t, fps, b: seen.append((d, t)))
+        assert seen and all(t == n for _, t in seen) and [d for d, _ in seen] == sorted(d for d, _ in seen) and seen[-1][0] == n
+        cfg = oracle.default_config(w, h, 8, min_bs_log2=5, max_bs_log2=5, color_range=cr)
+        assert out.read_bytes() == b"".join(oracle.encode_frame(cfg, fr)[0] for fr in frames), tag
+        streams[tag] = out.read_bytes()
+    assert streams[b""] == streams[b" XCOLORRANGE=LIMITED"] != streams[b" XCOLORRANGE=FULL"]
+
+
+def test_one_context_switching_tile_size_at_the_same_frame_size(av1mi, oracle):
+    """Regression: the per-tile buffers are sized by the tile grid.  648x360 is 11 x 6 superblocks: 66 tiles x 4096 entries at
+    tile_sb 1 but 18 tiles x 16384 at tile_sb 2 - a context reusing its workspace across that switch wrote past the end."""
+    w, h, bd, n = 648, 360, 8, 2
+    frames = [oracle.synthclip_frame(w, h, bd, seed=84, t=t) for t in range(n)]
+    raw = b"".join(raw_of(f, bd) for f in frames)
+    with av1mi.Context(0) as c:
+        for tsb in (1, 2, 1):
+            p = av1mi.default_params(w, h, bd, tile_sb=tsb)
+            data, sizes, rep, recon = c.encode_chunk(p, raw, n, want_recon=True)
+            cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5, tile_w_sb=tsb, tile_h_sb=tsb)
+            tus, recs = oracle_chunk(oracle, cfg, frames, 1)
+            assert data == b"".join(tus), tsb
+            assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs), tsb
 
 
 def test_encode_file_many_chunks_few_workers(av1mi, oracle, tmp_path):
