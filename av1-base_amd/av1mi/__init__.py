@@ -36,7 +36,7 @@ E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_OOM, E_OVERFLOW, E_FORMAT, E_UNSUPPORTED = 
 
 # every symbol include/av1mi.h declares
 ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", "av1mi_last_error", "av1mi_encode_chunk",
-               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute", "av1mi_probe_y4m"]
+               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute", "av1mi_probe_y4m", "av1mi_chunk_owner", "av1mi_plan_workers"]
 
 
 class Params(C.Structure):
@@ -100,6 +100,9 @@ _lib.av1mi_scene_cuts.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c
                                   C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
 _lib.av1mi_encode_file.argtypes = [C.POINTER(Job), PROGRESS_CB, C.c_void_p, C.POINTER(Report)]
 _lib.av1mi_job_execute.argtypes = [C.POINTER(ExecJob), STATE_CB, C.c_void_p, C.POINTER(JobMetrics), C.c_char_p, C.c_size_t]
+_lib.av1mi_chunk_owner.argtypes = [C.c_uint32, C.c_uint32]
+_lib.av1mi_chunk_owner.restype = C.c_uint32
+_lib.av1mi_plan_workers.argtypes = [C.c_uint32, C.c_int32, C.c_int, C.POINTER(C.c_int32), C.c_uint32]
 _lib.av1mi_probe_y4m.argtypes = [C.c_char_p, C.POINTER(ClipInfo)]
 _lib.av1mi_cq_to_qindex.argtypes = [C.c_uint32]
 _lib.av1mi_cq_to_qindex.restype = C.c_uint32
@@ -144,6 +147,23 @@ def default_params(width, height, bit_depth=8, **kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def chunk_owner(chunk_index, n_owners):
+    """chunk i -> owner i mod n (include/av1mi.h: av1mi_chunk_owner)"""
+    return int(_lib.av1mi_chunk_owner(chunk_index, n_owners))
+
+
+def chunks_of_rank(n_chunks, world, rank):
+    """the chunks of an n_chunks job that rank `rank` of `world` encodes (bench.py's ranks, one GPU each)"""
+    return [c for c in range(n_chunks) if chunk_owner(c, world) == rank]
+
+
+def plan_workers(workers, gpu_mask, n_devices):
+    """device of every worker context (include/av1mi.h: av1mi_plan_workers)"""
+    buf = (C.c_int32 * 64)()
+    n = _lib.av1mi_plan_workers(workers, gpu_mask, n_devices, buf, 64)
+    return [int(buf[i]) for i in range(min(n, 64))]
 
 
 def probe_y4m(path):

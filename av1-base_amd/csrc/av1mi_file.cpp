@@ -229,6 +229,22 @@ struct Chunk {
 
 }  // namespace
 
+// ---- chunk -> GPU placement: the two rules everything multi-GPU in this build goes through ----------------
+extern "C" uint32_t av1mi_chunk_owner(uint32_t chunk_index, uint32_t n_owners) { return n_owners ? chunk_index % n_owners : 0u; }
+
+extern "C" int av1mi_plan_workers(uint32_t workers, int32_t gpu_mask, int n_devices, int32_t *device_of_worker, uint32_t cap) {
+  if (n_devices <= 0) return 0;
+  int devs[64], nd = 0;
+  for (int d = 0; d < n_devices && d < 32 && nd < 64; d++) if (gpu_mask <= 0 || ((gpu_mask >> d) & 1)) devs[nd++] = d;
+  if (nd == 0) return 0;
+  // default: AV1MI_DEFAULT_WORKERS_PER_GPU chunks in flight per allowed GPU - a chunk's P-frame chain is latency bound, chains of
+  // different chunks overlap (the reference runs `--workers 8` on one host, concurrency.rs:67-73)
+  uint32_t w = workers ? workers : (uint32_t)nd * AV1MI_DEFAULT_WORKERS_PER_GPU;
+  if (w > 64) w = 64;
+  for (uint32_t i = 0; i < w && i < cap; i++) if (device_of_worker) device_of_worker[i] = devs[av1mi_chunk_owner(i, (uint32_t)nd)];
+  return (int)w;
+}
+
 extern "C" int av1mi_probe_y4m(const char *path, av1mi_clip_info *info) {
   if (!path || !info) return AV1MI_E_INVALID_ARG;
   Y4m y;
@@ -254,19 +270,18 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   // contexts: `workers` chunks in flight, spread round-robin over the allowed GPUs
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fclose(y.f); return AV1MI_E_NO_DEVICE; }
-  std::vector<int> devs;
-  for (int d = 0; d < ndev; d++) if (job->gpu_mask <= 0 || ((job->gpu_mask >> d) & 1)) devs.push_back(d);
-  if (devs.empty()) { fclose(y.f); return AV1MI_E_NO_DEVICE; }
-  uint32_t workers = job->workers ? job->workers : (uint32_t)devs.size();
-  if (workers > 64) workers = 64;
+  int32_t dev_of[64];
+  const int planned = av1mi_plan_workers(job->workers, job->gpu_mask, ndev, dev_of, 64);
+  if (planned <= 0) { fclose(y.f); return AV1MI_E_NO_DEVICE; }
+  const uint32_t workers = (uint32_t)planned;
   std::vector<av1mi_ctx *> ctxs(workers, nullptr);
   for (uint32_t i = 0; i < workers; i++) {
-    rc = av1mi_ctx_create(devs[i % devs.size()], &ctxs[i]);
+    rc = av1mi_ctx_create(dev_of[i], &ctxs[i]);
     if (rc) { for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
   }
   av1mi_ctx *det_ctx = nullptr;  // the reader thread's own context for the scene-cut pass
   if (scene_mode) {
-    rc = av1mi_ctx_create(devs[0], &det_ctx);
+    rc = av1mi_ctx_create(dev_of[0], &det_ctx);
     if (rc) { for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
     ctxs.push_back(det_ctx);  // destroyed with the others; gets no worker thread
   }

@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X AV1 chunk-encode path.
 
-Metric (BASELINE.json): encoded frames/s at CQ=30.  Workload at N=1 = BASELINE.json configs[1]:
+Metric (BASELINE.json): encoded frames/s at CQ=30.  Headline workload at N=1 = BASELINE.json configs[1]:
 1080p, 60-frame all-key-frame (intra-only) `synthclip v1` chunk, 10-bit
 (the reference's pixel format, av1an.rs:90) unless --bit-depth 8.  One "step" = one complete
 encode of one chunk per GPU: source frames already resident in HBM -> reconstruction, CDEF,
 entropy coding, bitstream packing on the GPU -> complete OBU bitstream on the host.
 
+At N=1 with default flags the same JSON line carries a `configs` object with the other BASELINE
+configurations a single GPU can run (each with its own fps, roofline and stage times): config 2 with all
+13 intra candidates, config 3 (1080p IPPP, 1 and 4 chunks in flight), config 4's per-GPU unit (4K 10-bit
+IPPP chunk) and the reference's production operating point (av1an.rs:14).
+
 Multi-GPU (torchrun, one rank per GPU): scene-chunks are independent, every
 rank encodes its own chunk (seed 1080 + rank), no data-path collective; weak scaling.  The only
 collectives are the timing barrier and the MAX over ranks.
+
+CPU baseline (reported only; rank 0, N=1): runs BEFORE anything touches the GPU, in SURVEY §8d's order -
+the reference's own av1an / SVT-AV1 if on PATH, else libaom 3.13.2 through the image's libavif (8-bit: this
+libaom has no high-bit-depth build), else the build's own C restatement ("port").
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +54,19 @@ def _splitmix64(x):
         return x ^ (x >> np.uint64(31))
 
 
+def _rects(w, h, seed, t):
+    """the six moving rectangles of `synthclip v1`: (x, y, w, h, [value per plane])"""
+    rects = []
+    for k in range(6):
+        hh = _splitmix64((seed * 977 + k) & _M64)
+        vx, vy = (3 if hh & 1 else -3), (2 if hh & 2 else -2)
+        rw, rh = 32 + (hh >> 8) % (w // 4 + 1), 32 + (hh >> 24) % (h // 4 + 1)
+        rx, ry = (hh >> 40) % w + vx * t, (hh >> 52) % h + vy * t
+        h2 = _splitmix64(hh)
+        rects.append((rx % w, ry % h, rw, rh, [(h2 >> 3) & 255, (h2 >> 13) & 255, (h2 >> 23) & 255]))
+    return rects
+
+
 def synthclip_frame(w, h, bd, seed, t):
     """`synthclip v1` in numpy: gradients panning (2, 1) px/frame, 6 opaque rectangles moving (+-3, +-2),
     splitmix64 noise; byte for byte what oracle/av1o_synth.c generates (tests/test_oracle.py checks that), written here
@@ -52,14 +78,7 @@ def synthclip_frame(w, h, bd, seed, t):
         m = np.where(m > P, 2 * P - m, m)
         return (m * 64) // P
     sh, maxv, G = bd - 8, (1 << bd) - 1, (1 if bd == 8 else 4)
-    rects = []
-    for k in range(6):
-        hh = _splitmix64((seed * 977 + k) & _M64)
-        vx, vy = (3 if hh & 1 else -3), (2 if hh & 2 else -2)
-        rw, rh = 32 + (hh >> 8) % (w // 4 + 1), 32 + (hh >> 24) % (h // 4 + 1)
-        rx, ry = (hh >> 40) % w + vx * t, (hh >> 52) % h + vy * t
-        h2 = _splitmix64(hh)
-        rects.append((rx % w, ry % h, rw, rh, [(h2 >> 3) & 255, (h2 >> 13) & 255, (h2 >> 23) & 255]))
+    rects = _rects(w, h, seed, t)
     planes = []
     for pl in range(3):
         ss = 1 if pl else 0
@@ -83,7 +102,7 @@ def synthclip_frame(w, h, bd, seed, t):
 
 
 def make_clip(w, h, bd, n, seed):
-    """synthclip v1 frames as one I420 byte string"""
+    """synthclip v1 frames as one I420 byte string (numpy; the CPU legs and small cases)"""
     import numpy as np
     dt = np.uint8 if bd == 8 else np.dtype("<u2")
     out = []
@@ -93,37 +112,361 @@ def make_clip(w, h, bd, n, seed):
     return b"".join(out)
 
 
-def _cpu_worker(args):
-    w, h, bd, bs, seed, t0, cnt = args
+def _s64(v):
+    """a 64-bit pattern as the int64 torch works in"""
+    v &= _M64
+    return v - (1 << 64) if v >> 63 else v
+
+
+def make_clip_torch(w, h, bd, n, seed, device):
+    """The same clip, synthesised where it is needed (HBM) with torch integer arithmetic: a 60-frame 1080p clip takes
+    a fraction of a second instead of 14 s of numpy (4K: 35 s).  int64 two's-complement multiplies wrap like uint64 ones;
+    logical right shifts are arithmetic shifts with the sign extension masked off.  tests/test_oracle.py checks it against
+    the numpy and the C generators on the CPU device.  Returns a uint8 tensor (I420, little-endian 16-bit above 8 bit)."""
+    import torch
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def mix(x):
+        x = x + _s64(0x9E3779B97F4A7C15)
+        x = (x ^ lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+        x = (x ^ lsr(x, 27)) * _s64(0x94D049BB133111EB)
+        return x ^ lsr(x, 31)
+
+    def tri(v, P):
+        m = v % (2 * P)
+        m = torch.where(m > P, 2 * P - m, m)
+        return (m * 64) // P
+    sh, maxv, G = bd - 8, (1 << bd) - 1, (1 if bd == 8 else 4)
+    bps = 2 if bd > 8 else 1
+    out = torch.empty((n, w * h * 3 // 2 * bps), dtype=torch.uint8, device=device)
+    for t in range(n):
+        rects = _rects(w, h, seed, t)
+        off = 0
+        for pl in range(3):
+            ss = 1 if pl else 0
+            pw, ph = w >> ss, h >> ss
+            A1, A2, P1, P2 = (48, 32, 53, 41) if pl else (96, 64, 97, 61)
+            base = 128 - (A1 + A2) // 2 if pl else 16
+            x = torch.arange(pw, dtype=torch.int64, device=device)[None, :]
+            y = torch.arange(ph, dtype=torch.int64, device=device)[:, None]
+            v = base + (tri(x + ((2 * t) >> ss), P1) * A1) // 64 + (tri(y + (t >> ss), P2) * A2) // 64
+            v = v.expand(ph, pw).clone()
+            fx, fy = x << ss, y << ss
+            for (px, py, rw, rh, rv) in rects:
+                inside = (fx >= px) & (fx < px + rw) & (fy >= py) & (fy < py + rh)
+                v = torch.where(inside, torch.full_like(v, rv[pl]), v)
+            v = v << sh
+            key = (_s64(seed ^ ((t << 40) & _M64))) ^ ((pl * 8192 + y) << 20) ^ x
+            nz = mix(key)
+            v = torch.clamp(v + ((nz & 15) - 8) * G, 0, maxv)
+            nb = pw * ph * bps
+            if bps == 1:
+                out[t, off:off + nb] = v.to(torch.uint8).reshape(-1)
+            else:
+                out[t, off:off + nb] = torch.stack((v & 255, v >> 8), dim=-1).to(torch.uint8).reshape(-1)
+            off += nb
+    return out.reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _psnr(sse, n, mx):
+    return 99.0 if sse <= 0 else 10.0 * math.log10(mx * mx * n / sse)
+
+
+def _port_worker(args):
+    """the build's own C restatement (oracle/): same algorithm as the GPU path, one process per core"""
+    w, h, bd, bs, seed, t0, cnt, keyint = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import av1o
     cfg = av1o.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs)
     frames = [av1o.synthclip_frame(w, h, bd, seed=seed, t=t0 + i) for i in range(cnt)]
     t = time.perf_counter()
-    nbytes = 0
-    for fr in frames:
-        tu, _, _ = av1o.encode_frame(cfg, fr)
+    nbytes, sse, ref, prev = 0, [0, 0, 0], None, None
+    for i, fr in enumerate(frames):
+        key = keyint <= 1 or i % keyint == 0
+        tu, rec, st = av1o.encode_frame(cfg, fr, with_seq_hdr=key, ref=None if key else ref, prev_src=None if key else prev)
         nbytes += len(tu)
-    return time.perf_counter() - t, nbytes
+        ref, prev = rec, fr
+        for k in range(3):
+            sse[k] += int(st.sse[k])
+    return time.perf_counter() - t, nbytes, sse, cnt
 
 
-def cpu_baseline(w, h, bd, bs, budget_s=20.0):
-    """The CPU oracle (kind 'port': same algorithm, plain C, one process per host core) on a
-    bounded sample of the same workload."""
-    import multiprocessing as mp
-    cores = min(len(os.sched_getaffinity(0)), 16)
-    # one calibration frame on one core
-    t1, _ = _cpu_worker((w, h, bd, bs, 1080, 0, 1))
-    per_core = max(1, min(4, int(budget_s / max(t1, 1e-3))))
-    jobs = [(w, h, bd, bs, 1080, c * per_core, per_core) for c in range(cores)]
+def _libaom_worker(args):
+    """libaom 3.13.2 through libavif's C API (tools/oracle_avif.py): I420 in, no RGB anywhere; all-key-frame = one still per
+    frame, IPPP = one image sequence (libaom's own inter coding, key frame first only)"""
+    w, h, bd, speed, seed, t0, cnt, keyint = args
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import numpy as np
+    import oracle_avif
+    frames = [synthclip_frame(w, h, bd, seed, t0 + i) for i in range(cnt)]
     t = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
+    if keyint <= 1:
+        avs = [oracle_avif.libaom_encode_yuv420([fr], bd, 30, speed, 1) for fr in frames]
+    else:
+        avs = [oracle_avif.libaom_encode_yuv420(frames, bd, 30, speed, 1, keyint=0)]
+    dt = time.perf_counter() - t
+    nbytes, sse = sum(len(a) for a in avs), [0, 0, 0]
+    dec = [oracle_avif.decode_yuv(a)[0] for a in avs] if keyint <= 1 else oracle_avif.decode_sequence(avs[0], w, h)
+    for fr, d in zip(frames, dec):
+        for k in range(3):
+            sse[k] += int(((d[k].astype(np.int64) - fr[k].astype(np.int64)) ** 2).sum())
+    return dt, nbytes, sse, cnt
+
+
+def _pool_run(fn, jobs, cores):
+    import multiprocessing as mp
+    t = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:   # nothing in this process has touched HIP yet (see main)
+        res = pool.map(fn, jobs)
     wall = time.perf_counter() - t
-    frames = cores * per_core
-    return {"value": round(frames / wall, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same 1080p synthclip chunk, %d per core, oracle (plain C restatement), single-frame %.2f s" % (
-                frames, per_core, t1)}
+    frames = sum(r[3] for r in res)
+    nbytes = sum(r[1] for r in res)
+    sse = [sum(r[2][k] for r in res) for k in range(3)]
+    return wall, frames, nbytes, sse
+
+
+def _reference_cli_leg(w, h, cores, keyint, frames):
+    """SURVEY §8d choice 1: the reference's own path, if the box has it.  `av1an` with the reference's argv
+    (build_av1an_command, av1an.rs:79-107; the one constant changed: --crf 30, --keyint as the config says, preset 8), or a
+    bare SvtAv1EncApp.  Expected to be absent (the GPU box receives only this repository)."""
+    av1an, svt = shutil.which("av1an"), shutil.which("SvtAv1EncApp")
+    if not av1an and not svt:
+        return None
+    tmp = tempfile.mkdtemp(prefix="av1mi_cpu_")
+    try:
+        y4m = os.path.join(tmp, "clip.y4m")
+        with open(y4m, "wb") as f:
+            f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420p10 XYSCSS=420P10\n" % (w, h))
+            for t in range(frames):
+                f.write(b"FRAME\n" + b"".join(p.astype("<u2").tobytes() for p in synthclip_frame(w, h, 10, 1080, t)))
+        out = os.path.join(tmp, "out.mkv" if av1an else "out.ivf")
+        vp = "--crf 30 --preset 8 --keyint %d" % (1 if keyint <= 1 else keyint)
+        workers = 8 if cores >= 32 else 4   # ConcurrencyPlan::derive, concurrency.rs:67-73
+        if av1an:
+            cmd = [av1an, "-i", y4m, "-o", out, "--encoder", "svt-av1", "--pix-format", "yuv420p10le", "--video-params", vp,
+                   "--audio-params", "-c:a copy", "--workers", str(workers), "--temp", os.path.join(tmp, "chunks")]
+        else:
+            cmd = [svt, "-i", y4m, "-b", out] + vp.split()
+        t = time.perf_counter()
+        rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300).returncode
+        wall = time.perf_counter() - t
+        if rc != 0 or not os.path.exists(out) or os.path.getsize(out) == 0:
+            return None
+        return {"value": round(frames / wall, 3), "unit": "frames/s", "cores": cores, "kind": "reference",
+                "encoder": "av1an + SVT-AV1 (reference argv, --crf 30 --preset 8)" if av1an else "SvtAv1EncApp --crf 30 --preset 8",
+                "sample": "%d frames of the 1080p 10-bit synthclip chunk, whole encode incl. process start" % frames,
+                "bytes_per_frame": round(os.path.getsize(out) / frames, 1), "psnr_db": None}
+    except (OSError, subprocess.SubprocessError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(w, h, bd, bs, keyint, budget_frames_per_core=4):
+    """Reported-only CPU leg on a bounded sample of the headline workload (must run before the process initialises HIP:
+    the worker pool forks).  Order of SURVEY §8d / BASELINE.md §3; the legs that ran besides the chosen one are kept
+    under "others"."""
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    legs = []
+    ref = _reference_cli_leg(w, h, cores, keyint, 16)
+    if ref:
+        legs.append(ref)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import oracle_avif
+        have_aom = oracle_avif.have_libavif()
+    except Exception:
+        have_aom = False
+    if have_aom:
+        for speed, per_core in ((8, budget_frames_per_core), (6, 1)):
+            try:
+                jobs = [(w, h, 8, speed, 1080, c * per_core, per_core, keyint) for c in range(cores)]
+                wall, frames, nbytes, sse = _pool_run(_libaom_worker, jobs, cores)
+                legs.append({"value": round(frames / wall, 3), "unit": "frames/s", "cores": cores, "kind": "libaom",
+                             "encoder": "libaom 3.13.2 via libavif C API, end-usage=q cq-level=30, cpu-used %d, I420 8-bit (this libaom build has no "
+                                        "high bit depth), one single-threaded encoder per core" % speed,
+                             "sample": "%d frames of the same %dx%d synthclip chunk at 8 bit, %d per core (%s)" % (
+                                 frames, w, h, per_core, "one still per frame" if keyint <= 1 else "one IPPP sequence per core"),
+                             "bytes_per_frame": round(nbytes / frames, 1),
+                             "psnr_db": [round(_psnr(sse[k], frames * w * h / (4 if k else 1), 255.0), 2) for k in range(3)]})
+            except Exception as e:   # reported-only: a failing stand-in must not take the benchmark down
+                legs.append({"kind": "libaom", "error": "%s: %s" % (type(e).__name__, e)})
+    try:
+        jobs = [(w, h, bd, bs, 1080, c * budget_frames_per_core, budget_frames_per_core, keyint) for c in range(cores)]
+        wall, frames, nbytes, sse = _pool_run(_port_worker, jobs, cores)
+        legs.append({"value": round(frames / wall, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+                     "encoder": "oracle/: this build's algorithm restated in plain C (bit-identical output to the GPU path), one process per core",
+                     "sample": "%d frames of the same %dx%d %d-bit synthclip chunk, %d per core" % (frames, w, h, bd, budget_frames_per_core),
+                     "bytes_per_frame": round(nbytes / frames, 1),
+                     "psnr_db": [round(_psnr(sse[k], frames * w * h / (4 if k else 1), float((1 << bd) - 1)), 2) for k in range(3)]})
+    except Exception as e:
+        legs.append({"kind": "port", "error": "%s: %s" % (type(e).__name__, e)})
+    good = [l for l in legs if "value" in l]
+    if not good:
+        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "none", "sample": "no CPU encoder could run", "others": legs}
+    best = dict(good[0])
+    best["others"] = [l for l in legs if l is not good[0]]
+    best["vmaf"] = "unavailable offline (no libvmaf)"
+    return best
+
+
+# ------------------------------------------------------------------------------------------------ GPU workloads
+def workload_string(av1mi, a):
+    mask = a["mode_mask"] if a["mode_mask"] else 0x7
+    names = ["DC", "V", "H", "D45", "D135", "D113", "D157", "D203", "D67", "SMOOTH", "SMOOTH_V", "SMOOTH_H", "PAETH"]
+    cand = "all 13 intra candidates" if mask == 0x1FFF else "intra candidates {%s} (mode mask 0x%X)" % (", ".join(n for i, n in enumerate(names) if (mask >> i) & 1), mask)
+    kind = "all-key-frame" if a["keyint"] <= 1 else "IPPP (keyint %d, 1 reference, +-%d full search%s)" % (
+        a["keyint"], a["me_range"], " + quarter-sample SATD refinement, EIGHTTAP" if a["subpel"] else "")
+    s = "%dx%d %d-frame %s synthclip v1 chunk per GPU, %d-bit 4:2:0, CQ=%d (base_q_idx %d), %dx%d blocks, %s, 64x64 tiles, %s CDFs, CDEF on" % (
+        a["width"], a["height"], a["frames"], kind, a["bit_depth"], a["cq"], av1mi.cq_to_qindex(a["cq"]), 1 << a["block_log2"], 1 << a["block_log2"],
+        cand, "static" if a["static_cdf"] else "adaptive")
+    s += (", deblocking on" if a["deblock"] else "") + (", quantiser matrices 1..15" if a["qm"] else "")
+    s += ", loop restoration (Wiener + self-guided) on" if a["sgr"] else (", loop restoration (Wiener) on" if a["lr"] else "")
+    s += (", film-grain table %d" % a["film_grain"]) if a["film_grain"] else ""
+    if a["chunks_per_gpu"] > 1:
+        s += ", %d chunks in flight per GPU on their own contexts" % a["chunks_per_gpu"]
+    return s
+
+
+def algorithmic_bytes(a, rep):
+    """Algorithmic HBM bytes per step and per stage: N = samples per frame, b = bytes per sample"""
+    w, h, n = a["width"], a["height"], a["frames"]
+    b = 2 if a["bit_depth"] > 8 else 1
+    N, L = w * h * 3 // 2, w * h
+    inter = a["keyint"] > 1 and n > 1
+    n_inter = (n - (n + a["keyint"] - 1) // a["keyint"]) if inter else 0
+    lr = a["sgr"] or a["lr"]
+    stage = {"symbolize": n * N * 2 + 4 * int(rep.n_symbols),        # levels read + 32-bit symbol entries written
+             "rangecode": 4 * int(rep.n_symbols) + int(rep.bytes)}   # symbol entries read + bitstream written
+    if not inter:
+        stage["recon"] = n * N * (2 * b + 2)                          # source read + reconstruction written + int16 levels written
+        stage["cdef"] = n * N * 2 * b                                 # reconstruction read + filtered frame written (timed with the SSE pass)
+        if lr:
+            stage["recon"] += n * N * 2 * b + n * (3 * L * b + N * b)   # CDEF and restoration precede entropy coding then
+    else:
+        # the frame-by-frame chain (timed as "recon"): per frame source + reconstruction + levels, CDEF in and out, and per
+        # inter frame the reference read by motion compensation; restoration as above
+        stage["recon"] = n * N * (2 * b + 2) + n * N * 2 * b + n_inter * N * b + (n * (3 * L * b + N * b) if lr else 0)
+        stage["cdef"] = n * N * 2 * b                                 # the SSE pass: two frames read
+    # whole step, SURVEY §8d: intra N(4b+2); inter N(7b+2) + 2Lb (search: source + previous source luma)
+    step = n * N * (4 * b + 2) if not inter else (n - n_inter) * N * (4 * b + 2) + n_inter * (N * (7 * b + 2) + 2 * L * b)
+    return stage, step
+
+
+def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, barrier, max_over_ranks):
+    """`steps` timed steps of workload `a` on this rank; returns (elapsed seconds (max over ranks), stage ms per step, last report)"""
+    w, h, bd, n = a["width"], a["height"], a["bit_depth"], a["frames"]
+    # a job of `world` scene-chunks, one per GPU: this rank's chunk by the product's own placement rule (av1mi_chunk_owner)
+    mine = av1mi.chunks_of_rank(world, world, rank)
+    assert len(mine) == 1, mine
+    d_frames = make_clip_torch(w, h, bd, n, a["seed"] + mine[0], dev)   # HBM-resident input
+    torch.cuda.synchronize(dev)
+    params = av1mi.default_params(w, h, bd, block_log2=a["block_log2"], cdf_update=0 if a["static_cdf"] else 1, keyint=a["keyint"],
+                                  me_range=a["me_range"], cq_level=a["cq"], film_grain=a["film_grain"],
+                                  deblock=1 if a["deblock"] else 0, enable_lr=2 if a["sgr"] else (1 if a["lr"] else 0))
+    params.subpel = 1 if a["subpel"] else 0
+    if a["qm"]:
+        params.enable_qm, params.qm_min, params.qm_max = 1, 1, 15
+    params.intra_mode_mask = a["mode_mask"]
+    C_ = max(1, a["chunks_per_gpu"])
+    ctxs = [av1mi.Context(local_rank) for _ in range(C_)]
+
+    def step():
+        if C_ == 1:
+            return ctxs[0].encode_chunk(params, d_frames.data_ptr(), n, on_device=True, copy_out=False)[2]
+        import threading
+        res = [None] * C_
+
+        def work(i):   # every context encodes the whole chunk (its own copy of the work)
+            res[i] = ctxs[i].encode_chunk(params, d_frames.data_ptr(), n, on_device=True, copy_out=False)[2]
+        th = [threading.Thread(target=work, args=(i,)) for i in range(C_)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        rep = max(res, key=lambda r: r.ms_total)   # stage times of the slowest part
+        rep.n_symbols = sum(r.n_symbols for r in res)
+        rep.max_tile_symbols = max(r.max_tile_symbols for r in res)
+        rep.bytes = sum(r.bytes for r in res)
+        return rep
+    try:
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        stage = {"recon": 0.0, "cdef": 0.0, "entropy": 0.0, "symbolize": 0.0, "pack": 0.0, "d2h": 0.0}
+        rep = None
+        for _ in range(steps):
+            rep = step()
+            stage["recon"] += rep.ms_recon; stage["cdef"] += rep.ms_cdef; stage["entropy"] += rep.ms_entropy
+            stage["pack"] += rep.ms_pack; stage["d2h"] += rep.ms_d2h; stage["symbolize"] += rep.ms_symbolize
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+    finally:
+        for c_ in ctxs:
+            c_.close()
+        del d_frames
+    for s in stage:
+        stage[s] /= steps
+    stage["rangecode"] = stage["entropy"] - stage["symbolize"]
+    return elapsed, stage, rep
+
+
+def result_of(av1mi, a, world, steps, elapsed, stage, rep, traffic_db):
+    C_, n = max(1, a["chunks_per_gpu"]), a["frames"]
+    alg, step_bytes = algorithmic_bytes(a, rep)
+    if C_ > 1:   # C_ copies of the work per step; the stage times are those of the slowest copy
+        step_bytes *= C_
+    dom = max(alg, key=lambda s: stage[s])
+    achieved = alg[dom] / (stage[dom] * 1e-3) / 1e9
+    peak = 8000.0
+    step_gbs = step_bytes * world / (elapsed / steps) / 1e9 / world   # per GPU
+    traffic = traffic_raw = None
+    ent = (traffic_db or {}).get(a["name"], {}).get(dom)
+    if ent:
+        # separate FETCH_SIZE / WRITE_SIZE passes of this same workload (profiles/); gfx950 correction: FETCH_SIZE counts 64 B per
+        # 128-B request, so the fetch side is doubled (an upper estimate for narrow loads)
+        traffic_raw = (ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024
+        traffic = (2 * ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024
+    return {
+        "workload": workload_string(av1mi, a),
+        "fps": round(world * C_ * n * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+        "frames_per_step": world * C_ * n,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+                     "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
+                     "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage[dom], 3),
+                     "step_algorithmic_bytes": step_bytes, "step_achieved": round(step_gbs, 2), "step_frac": round(step_gbs / peak, 5)},
+        "stage_ms": {s: round(v, 3) for s, v in stage.items()},
+        "bytes_per_frame": round(int(rep.bytes) / (C_ * n), 1),
+        "psnr_db": [round(rep.psnr[i], 2) for i in range(3)],
+        "symbols_per_frame": int(rep.n_symbols // (C_ * n)), "max_tile_symbols": int(rep.max_tile_symbols),
+    }
+
+
+def metric_label(a):
+    res = "1080p" if (a["width"], a["height"]) == (1920, 1080) else ("4K" if (a["width"], a["height"]) == (3840, 2160) else "%dx%d" % (a["width"], a["height"]))
+    return "encoded frames/sec at CQ=%d (%s %s)" % (a["cq"], res, "intra-only" if a["keyint"] <= 1 else "IPPP")
+
+
+def extra_configs(base):
+    """the other BASELINE configurations one GPU runs (BASELINE.json configs[1..3] + the reference's production string)"""
+    def mk(name, **kw):
+        d = dict(base)
+        d.update(kw)
+        d["name"] = name
+        return d
+    prod = dict(keyint=240, cq=8, qm=True, film_grain=20, subpel=True, deblock=True, sgr=True)
+    return [
+        mk("cfg2_1080p_intra_all13", mode_mask=0x1FFF),
+        mk("cfg3_1080p_ippp", keyint=240),
+        mk("cfg3_1080p_ippp_x4", keyint=240, chunks_per_gpu=4),
+        mk("cfg4_4k_ippp_chunk", width=3840, height=2160, frames=30, keyint=240, seed=2160),
+        mk("production_1080p", **prod),
+        mk("production_1080p_x4", chunks_per_gpu=4, **prod),
+    ]
 
 
 def main():
@@ -150,12 +493,30 @@ def main():
     ap.add_argument("--block-log2", type=int, default=5)
     ap.add_argument("--static-cdf", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode-mask", type=int, default=0, help="experiment: intra mode candidate mask (0 = default {DC, V, H})")
+    ap.add_argument("--mode-mask", type=lambda s: int(s, 0), default=0, help="intra mode candidate mask (0 = default {DC, V, H}; 0x1FFF = all 13)")
+    ap.add_argument("--configs", choices=["auto", "all", "none"], default="auto",
+                    help="the `configs` object with the other BASELINE configurations: auto = at N=1 when the workload flags are the defaults")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    base = dict(name="cfg2_1080p_intra", width=args.width, height=args.height, frames=args.frames, keyint=args.keyint, me_range=args.me_range,
+                cq=args.cq, film_grain=args.film_grain, sgr=args.sgr, subpel=args.subpel, qm=args.qm, deblock=args.deblock, lr=args.lr,
+                chunks_per_gpu=args.chunks_per_gpu, bit_depth=args.bit_depth, block_log2=args.block_log2, static_cdf=args.static_cdf,
+                mode_mask=args.mode_mask, seed=1080)
+    default_flags = all(getattr(args, k) == ap.get_default(k) for k in (
+        "width", "height", "frames", "keyint", "me_range", "cq", "film_grain", "sgr", "subpel", "qm", "deblock", "lr", "chunks_per_gpu",
+        "bit_depth", "block_log2", "static_cdf", "mode_mask"))
+    if not default_flags:
+        base["name"] = "custom"
+    with_configs = args.configs == "all" or (args.configs == "auto" and world == 1 and default_flags)
+
+    # ---- CPU leg first: its worker pool forks, which must happen before this process (or torch) initialises HIP
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(base["width"], base["height"], base["bit_depth"], base["block_log2"], base["keyint"])
+
     import torch
     dist = None
     # rehearsal on a one-GPU box (the 8-GPU runs are the driver's): AV1MI_BENCH_BACKEND=gloo AV1MI_BENCH_ONE_DEVICE=1 runs the
@@ -174,121 +535,52 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     import av1mi
     dev = torch.device("cuda", local_rank)
-    w, h, bd, n = args.width, args.height, args.bit_depth, args.frames
-    clip = make_clip(w, h, bd, n, 1080 + rank)
-    d_frames = torch.frombuffer(bytearray(clip), dtype=torch.uint8).to(dev)  # HBM-resident input
-    torch.cuda.synchronize(dev)
-    params = av1mi.default_params(w, h, bd, block_log2=args.block_log2, cdf_update=0 if args.static_cdf else 1, keyint=args.keyint,
-                                  me_range=args.me_range, cq_level=args.cq, film_grain=args.film_grain,
-                                  deblock=1 if args.deblock else 0, enable_lr=2 if args.sgr else (1 if args.lr else 0))
-    params.subpel = 1 if args.subpel else 0
-    if args.qm:
-        params.enable_qm, params.qm_min, params.qm_max = 1, 1, 15
-    params.intra_mode_mask = args.mode_mask
-    W_ = max(1, args.chunks_per_gpu)
-    C_ = W_
-    ctxs = [av1mi.Context(local_rank) for _ in range(C_)]
-    ctx = ctxs[0]
-    fbytes = w * h * 3 // 2 * (2 if bd > 8 else 1)
-    parts = [(0, n)] * W_   # every context encodes the whole chunk (its own copy of the work)
-
-    def step():
-        if C_ == 1:
-            return ctx.encode_chunk(params, d_frames.data_ptr(), n, on_device=True, copy_out=False)
-        import threading
-        res = [None] * C_
-
-        def work(i):
-            a, b = parts[i]
-            res[i] = ctxs[i].encode_chunk(params, d_frames.data_ptr() + a * fbytes, b - a, on_device=True, copy_out=False)
-        th = [threading.Thread(target=work, args=(i,)) for i in range(C_)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        # merge: bitstream in frame order, the report of the slowest part for the stage times
-        rep = max((r[2] for r in res), key=lambda r: r.ms_total)
-        rep.n_symbols = sum(r[2].n_symbols for r in res)
-        rep.max_tile_symbols = max(r[2].max_tile_symbols for r in res)
-        rep.bytes = sum(r[2].bytes for r in res)
-        return None, [x for r in res for x in r[1]], rep, None
-
-    for _ in range(args.warmup):
-        step()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    barrier()
-    t0 = time.perf_counter()
-    stage = {"recon": 0.0, "cdef": 0.0, "entropy": 0.0, "symbolize": 0.0, "pack": 0.0, "d2h": 0.0}
-    last = None
-    for _ in range(args.steps):
-        data, sizes, rep, _ = step()
-        last = (data, rep)
-        stage["recon"] += rep.ms_recon; stage["cdef"] += rep.ms_cdef; stage["entropy"] += rep.ms_entropy
-        stage["pack"] += rep.ms_pack; stage["d2h"] += rep.ms_d2h; stage["symbolize"] += rep.ms_symbolize
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
+    def max_over_ranks(elapsed):
+        if dist is None:
+            return elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    traffic_db = None
+    try:
+        traffic_db = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"]
+    except (OSError, KeyError, ValueError):
+        pass
+
+    elapsed, stage, rep = run_workload(av1mi, torch, base, dev, local_rank, rank, world, args.steps, args.warmup, barrier, max_over_ranks)
+    head = result_of(av1mi, base, world, args.steps, elapsed, stage, rep, traffic_db)
+    configs = {}
+    if with_configs:
+        for a in extra_configs(base):
+            k, wu = max(2, min(args.steps, 6)), max(1, min(args.warmup, 2))
+            try:
+                e2, s2, r2 = run_workload(av1mi, torch, a, dev, local_rank, rank, world, k, wu, barrier, max_over_ranks)
+                configs[a["name"]] = result_of(av1mi, a, world, k, e2, s2, r2, traffic_db)
+            except Exception as e:   # a secondary configuration must not take the headline down; it is reported as failed
+                configs[a["name"]] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
-        data, rep = last
-        k = args.steps
-        bps = 2 if bd > 8 else 1
-        N = w * h * 3 // 2  # samples per frame
-        for s in stage:
-            stage[s] /= k
-        # algorithmic HBM bytes per launch of each kernel
-        stage["rangecode"] = stage["entropy"] - stage["symbolize"]
-        alg = {"recon": n * N * (2 * bps + 2),           # source read + reconstruction write + int16 levels write
-               "cdef": n * N * 2 * bps,                  # reconstruction read + filtered write (timed with the SSE kernel)
-               "symbolize": n * N * 2 + 4 * int(rep.n_symbols),   # levels read + 32-bit symbol entries write
-               "rangecode": 4 * int(rep.n_symbols) + int(rep.bytes)}   # symbol entries read + bitstream write
-        dom = max(alg, key=lambda s: stage[s])
-        achieved = alg[dom] / (stage[dom] * 1e-3) / 1e9
-        peak = 8000.0
-        # HBM traffic of the dominant kernel from the committed PMC passes (separate FETCH_SIZE / WRITE_SIZE
-        # runs of this same workload, profiles/); gfx950 correction: FETCH_SIZE counts 64 B per 128-B request.
-        traffic = traffic_raw = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")))
-            if (w, h, n, bd, args.block_log2, args.static_cdf, args.keyint, args.cq) == (1920, 1080, 60, 10, 5, False, 1, 30) and dom in pm["kernels"]:
-                kk = pm["kernels"][dom]
-                traffic_raw = (kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024
-                traffic = (2 * kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024
-        except OSError:
-            pass
         out = {
-            "metric": "encoded frames/sec at CQ=30 (1080p intra-only)", "value": round(world * W_ * n * k / elapsed, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(elapsed / k * 1e3, 3),
+            "metric": metric_label(base), "value": head["fps"], "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-            "config": {"workload": "%dx%d %d-frame %s synthclip v1 chunk per GPU, %d-bit 4:2:0, CQ=%d (base_q_idx %d), "
-                                   "%dx%d blocks, 64x64 tiles, %s CDFs, CDEF on" % (
-                                       w, h, n, "all-key-frame" if args.keyint <= 1 else "IPPP (keyint %d, 1 reference, +-%d full search%s)" % (args.keyint, args.me_range, " + quarter-sample refinement, EIGHTTAP" if args.subpel else ""),
-                                       bd, args.cq, av1mi.cq_to_qindex(args.cq), 1 << args.block_log2, 1 << args.block_log2,
-                                       "static" if args.static_cdf else "adaptive") + (", deblocking on" if args.deblock else "") + (", quantiser matrices 1..15" if args.qm else "") + (
-                                           ", loop restoration (Wiener + self-guided) on" if args.sgr else (", loop restoration on" if args.lr else "")),
-                       "frames_per_chunk": n, "chunks_per_gpu": W_,
+            "config": {"workload": head["workload"], "frames_per_chunk": base["frames"], "chunks_per_gpu": max(1, base["chunks_per_gpu"]),
                        "parallelism": "chunk-per-gpu x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
-                         "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
-                         "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage[dom], 3)},
-            "stage_ms": {s: round(v, 3) for s, v in stage.items()},
-            "bytes_per_frame": round(int(rep.bytes) / n, 1),
-            "psnr_db": [round(rep.psnr[i], 2) for i in range(3)],
-            "symbols_per_frame": int(rep.n_symbols // n), "max_tile_symbols": int(rep.max_tile_symbols),
+            "roofline": head["roofline"], "stage_ms": head["stage_ms"], "bytes_per_frame": head["bytes_per_frame"], "psnr_db": head["psnr_db"],
+            "symbols_per_frame": head["symbols_per_frame"], "max_tile_symbols": head["max_tile_symbols"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, h, bd, args.block_log2)  # (the oracle's all-key-frame path)
+        if configs:
+            out["configs"] = configs
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    for c_ in ctxs:
-        c_.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -155,7 +155,8 @@ typedef struct {
   const char *input_path;   /* Y4M (420jpeg/420p10) - container demux/decode is out of scope */
   const char *output_path;  /* IVF written atomically (tmp + rename); never left zero-length */
   const char *temp_dir;     /* caller-owned scratch (job_executor.rs:275-276); only tmp files go here */
-  uint32_t workers;         /* chunks in flight = contexts (one per visible GPU, round-robin) */
+  uint32_t workers;         /* chunks in flight = contexts, placed on the allowed GPUs by av1mi_plan_workers; 0 = default
+                               (AV1MI_DEFAULT_WORKERS_PER_GPU per allowed GPU) */
   uint32_t chunk_frames;    /* frames per chunk; 0 = chunks end at detected scene cuts (av1mi_scene_cuts,
                                min scene 12 frames) and after 240 frames at the latest (the reference's
                                `--keyint 240`, av1an.rs:14) */
@@ -176,6 +177,18 @@ typedef struct {
 int av1mi_probe_y4m(const char *path, av1mi_clip_info *info);
 
 int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total);
+
+/* ---- chunk -> GPU placement (independent chunks, no exchange step) -----------------------------------------
+ * Replaces the placement av1an does implicitly by forking `--workers N` encoder processes on one host (av1an.rs:100-101;
+ * ConcurrencyPlan.av1an_workers, concurrency.rs:9-18, 67-73).  Two pure functions, so the rule can be tested without a GPU and
+ * is the same wherever chunks meet devices (av1mi_encode_file's worker pool, bench.py's ranks):
+ *   av1mi_chunk_owner   chunk i of a job -> owner i mod n_owners (owner = a rank of the N-GPU bench, or a GPU of one process)
+ *   av1mi_plan_workers  `workers` contexts over the GPUs `gpu_mask` allows among `n_devices`: worker i -> the
+ *                       av1mi_chunk_owner(i, allowed)-th allowed device; workers == 0 -> AV1MI_DEFAULT_WORKERS_PER_GPU per allowed
+ *                       GPU; at most 64.  Writes min(result, cap) entries; returns the worker count, 0 if no device is allowed. */
+#define AV1MI_DEFAULT_WORKERS_PER_GPU 4
+uint32_t av1mi_chunk_owner(uint32_t chunk_index, uint32_t n_owners);
+int av1mi_plan_workers(uint32_t workers, int32_t gpu_mask, int n_devices, int32_t *device_of_worker, uint32_t cap);
 
 /* ---- the caller's encode segment ---------------------------------------------------------------
  * Mirror of the part of JobExecutor::execute that surrounds the encode call (crates/daemon/src/job_executor.rs:

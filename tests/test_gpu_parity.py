@@ -45,10 +45,14 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         cfgk = dict(m["config"])
         bs = cfgk.pop("min_bs_log2", 4)
         cfgk.pop("max_bs_log2", None)
-        if bs > 5 or any(k.startswith("fuzz") for k in cfgk) or (cfgk.get("film_grain") and cfgk.get("fg_seed") != 7391) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("base_q_idx", 120) != 120:
+        qidx = cfgk.get("base_q_idx", 120)
+        # what the C ABI cannot express stays with the oracle tests: fuzzed levels / modes, a film-grain seed other than the ABI's
+        # rule, tile layouts other than 1x1 / 2x2 superblocks, quantiser indices no CQ level maps to
+        if bs > 5 or any(k.startswith("fuzz") for k in cfgk) or (cfgk.get("film_grain") and cfgk.get("fg_seed") != 7391) or cfgk.get("tile_w_sb", 1) != 1 or qidx % 4 or qidx > 244:
             continue
-        p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs,
+        p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, cq_level=qidx // 4,
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_cdef=cfgk.get("enable_cdef", 1))
+        assert av1mi.cq_to_qindex(qidx // 4) == qidx
         p.intra_mode_mask = cfgk.get("mode_mask", 0)
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         p.enable_lr = cfgk.get("enable_lr", 0)
@@ -370,6 +374,36 @@ def test_qm_is_validated(av1mi, ctx):
         p = av1mi.default_params(64, 64, 8, enable_qm=1, **bad)
         with pytest.raises(av1mi.EncodeFailed):
             ctx.encode_chunk(p, bytes(64 * 64 * 3 // 2), 1)
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(subpel=1, enable_qm=1, qm_min=1, qm_max=15, deblock=1, enable_lr=2, film_grain=20)])
+def test_1080p_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle, extra):
+    """BASELINE config 3 at its own size (1920x1080, 10-bit, IPPP): 30 x 17 superblocks whose bottom row is 56 samples tall
+    (a 32 / 16 / 8 mix of leaf sizes through recon_inter_pre_kernel and the tile walk).  One key frame and two P frames,
+    plain and with every optional tool on - every temporal unit and every reconstruction bit-exact against the oracle."""
+    w, h, bd, n = 1920, 1080, 10, 3
+    frames = [oracle.synthclip_frame(w, h, bd, seed=1080, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, keyint=240, **extra)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    kw = dict(min_bs_log2=5, max_bs_log2=5)
+    if extra:
+        lvl = oracle.qm_level(av1mi.cq_to_qindex(30), 1, 15)
+        kw.update(subpel=1, enable_qm=1, qm_y=lvl, qm_uv=lvl, deblock=1, enable_lr=2, film_grain=1, fg_y_scaling=40, fg_c_scaling=20)
+    tus, recs, ref, prev = [], [], None, None
+    for t, f in enumerate(frames):
+        if extra:
+            kw["fg_seed"] = (7391 + 173 * t) & 0xFFFF
+        cfg = oracle.default_config(w, h, bd, **kw)
+        tu, rec, st = oracle.encode_frame(cfg, f, with_seq_hdr=(t == 0), ref=ref, prev_src=prev)
+        tus.append(tu)
+        recs.append(rec)
+        ref, prev = rec, f
+    assert list(sizes) == [len(t) for t in tus]
+    for i, tu in enumerate(tus):
+        assert data[sum(sizes[:i]):sum(sizes[:i + 1])] == tu, "frame %d" % i
+    fb = w * h * 3
+    for i, rec in enumerate(recs):
+        assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
 
 
 def test_4k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):

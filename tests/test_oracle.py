@@ -329,6 +329,13 @@ def test_bench_synthclip_equals_the_oracle_generator(oracle):
         a = bench.synthclip_frame(w, h, bd, seed, t)
         b = oracle.synthclip_frame(w, h, bd, seed=seed, t=t)
         assert all((a[i] == b[i]).all() for i in range(3)), (w, h, bd, seed, t)
+    # the torch generator (what bench.py runs on the GPU to put the clip into HBM), here on the CPU device: whole clips
+    for (w, h, bd, n, seed) in [(200, 120, 8, 3, 1080), (72, 56, 10, 2, 1083), (328, 248, 10, 2, 7)]:
+        clip = bench.make_clip_torch(w, h, bd, n, seed, "cpu").numpy().tobytes()
+        assert clip == bench.make_clip(w, h, bd, n, seed), (w, h, bd, n, seed)
+        dt = np.uint8 if bd == 8 else np.dtype("<u2")
+        last = oracle.synthclip_frame(w, h, bd, seed=seed, t=n - 1)
+        assert clip[-(w * h * 3 // 2 * dt.itemsize if bd > 8 else w * h * 3 // 2):] == b"".join(p.astype(dt).tobytes() for p in last)
 
 
 def test_quantiser_matrix_level_rule_and_effect(oracle):

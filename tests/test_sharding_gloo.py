@@ -1,13 +1,11 @@
-"""Multi-process (gloo, world_size 2) test of the N>1 path on CPU: scene-chunks shard over ranks
-with no data-path collective; the only collectives are the timing barrier / MAX
-and the host-side gather of per-chunk streams in chunk order.  The encode itself is stood in for
-by the oracle here (no GPU in this container) - what is tested is the sharding, the ordering and
-that concatenated chunk streams equal the single-process result."""
+"""Multi-process (gloo, world_size 2) test of the N>1 path on CPU: scene-chunks shard over ranks with no data-path
+collective; the only collectives are the timing barrier / MAX and the host-side gather of per-chunk streams in
+chunk order.  The PLACEMENT is the product's: every rank asks libav1mi (av1mi_chunk_owner through av1mi.chunks_of_rank, the
+function bench.py's ranks and av1mi_encode_file's worker pool use) which chunks are its own, so the test fails if that rule loses,
+duplicates or misorders a chunk.  Only the per-chunk encode is stood in for by the oracle (no GPU in this container)."""
 import os
 import socket
 import sys
-
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,18 +20,18 @@ def _free_port():
 
 def _worker(rank, world, port, n_chunks, q):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "av1-base_amd"))
     import torch
     import torch.distributed as dist
     import av1o
+    import av1mi   # the product's host mirror: loads libav1mi.so (placement functions need no GPU)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     w, h, frames = 72, 56, 2
     cfg = av1o.default_config(w, h, 8, min_bs_log2=5, max_bs_log2=5)
     mine = {}
-    for c in range(n_chunks):
-        if c % world != rank:          # chunk i -> rank i mod G
-            continue
+    for c in av1mi.chunks_of_rank(n_chunks, world, rank):
         data = b""
         for t in range(frames):
             tu, _, _ = av1o.encode_frame(cfg, av1o.synthclip_frame(w, h, 8, seed=100 + c, t=t))
@@ -45,10 +43,11 @@ def _worker(rank, world, port, n_chunks, q):
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     if rank == 0:
+        owners = [sorted(g) for g in gathered]
         merged = {}
         for g in gathered:
             merged.update(g)
-        q.put((float(t.item()), b"".join(merged[c] for c in sorted(merged)), sorted(merged)))
+        q.put((float(t.item()), b"".join(merged[c] for c in sorted(merged)), sorted(merged), owners))
     dist.destroy_process_group()
 
 
@@ -63,11 +62,12 @@ def test_two_rank_chunk_sharding():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_chunks, q)) for r in range(2)]
     for p in procs:
         p.start()
-    tmax, stream, order = q.get(timeout=120)
+    tmax, stream, order, owners = q.get(timeout=120)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     assert tmax == 2.0 and order == list(range(n_chunks))
+    assert owners == [[0, 2, 4], [1, 3]]   # every chunk exactly once, balanced
     cfg = av1o.default_config(72, 56, 8, min_bs_log2=5, max_bs_log2=5)
     ref = b""
     for c in range(n_chunks):
@@ -75,3 +75,19 @@ def test_two_rank_chunk_sharding():
             tu, _, _ = av1o.encode_frame(cfg, av1o.synthclip_frame(72, 56, 8, seed=100 + c, t=t))
             ref += tu
     assert stream == ref
+
+
+def test_worker_placement_rule():
+    """av1mi_plan_workers / av1mi_chunk_owner (include/av1mi.h): what av1mi_encode_file builds its contexts from."""
+    sys.path.insert(0, os.path.join(ROOT, "av1-base_amd"))
+    import av1mi
+    assert av1mi.plan_workers(0, 0, 8) == [d for _ in range(4) for d in range(8)]          # default: 4 chunks in flight per GPU
+    assert av1mi.plan_workers(8, 0, 8) == list(range(8))                                   # the reference's `--workers 8`
+    assert av1mi.plan_workers(5, 0b1010, 4) == [1, 3, 1, 3, 1]                             # only the allowed GPUs, round-robin
+    assert av1mi.plan_workers(3, 0, 1) == [0, 0, 0] and av1mi.plan_workers(0, 0, 1) == [0] * 4
+    assert av1mi.plan_workers(2, 0b100, 2) == [] and av1mi.plan_workers(1, 0, 0) == []     # nothing allowed / no device
+    assert len(av1mi.plan_workers(1000, 0, 8)) == 64
+    for world in (1, 2, 3, 8):
+        got = sorted(c for r in range(world) for c in av1mi.chunks_of_rank(64, world, r))
+        assert got == list(range(64))
+        assert max(len(av1mi.chunks_of_rank(64, world, r)) for r in range(world)) - min(len(av1mi.chunks_of_rank(64, world, r)) for r in range(world)) <= 1

@@ -285,6 +285,85 @@ def libaom_encode_rgb420(rgb, cq=30, speed=8, threads=1, extra=None):
     return bio.getvalue()
 
 
+class _AvifRWData(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("size", C.c_size_t)]
+
+
+class _AvifEncoderHead(C.Structure):
+    # leading (public, settable) fields of `struct avifEncoder` (libavif 1.x avif.h); the defaults read back from
+    # avifEncoderCreate() are checked against the documented ones before anything is written (libaom_encode_yuv420)
+    _fields_ = [("codecChoice", C.c_int), ("maxThreads", C.c_int), ("speed", C.c_int), ("keyframeInterval", C.c_int), ("timescale", C.c_uint64),
+                ("repetitionCount", C.c_int), ("extraLayerCount", C.c_uint32), ("quality", C.c_int), ("qualityAlpha", C.c_int),
+                ("minQuantizer", C.c_int), ("maxQuantizer", C.c_int), ("minQuantizerAlpha", C.c_int), ("maxQuantizerAlpha", C.c_int),
+                ("tileRowsLog2", C.c_int), ("tileColsLog2", C.c_int), ("autoTiling", C.c_int)]
+
+
+def libaom_encode_yuv420(frames, depth=8, cq=30, speed=8, threads=1, keyint=1, extra=None):
+    """Encode I420 frames ([Y, U, V] numpy planes each, 8 or 10 bit) with libaom through libavif's C API: `end-usage=q`,
+    `cq-level=cq` (-> base_q_idx 120 at 30), no RGB conversion anywhere.  One frame -> an AVIF still; several ->
+    an AVIF image sequence, key frame every `keyint` frames (1 = all key frames, 0 = only the first: libaom decides).
+    Returns the AVIF bytes; decode_yuv / decode_sequence give the exact planes back."""
+    lib = _load()
+    lib.avifEncoderCreate.restype = C.c_void_p
+    lib.avifEncoderDestroy.argtypes = [C.c_void_p]
+    lib.avifImageCreate.restype = C.c_void_p
+    lib.avifImageCreate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    lib.avifImageAllocatePlanes.argtypes = [C.c_void_p, C.c_uint32]
+    lib.avifEncoderAddImage.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    lib.avifEncoderFinish.argtypes = [C.c_void_p, C.POINTER(_AvifRWData)]
+    lib.avifEncoderSetCodecSpecificOption.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    lib.avifRWDataFree.argtypes = [C.POINTER(_AvifRWData)]
+    lib.avifCodecChoiceFromName.argtypes = [C.c_char_p]
+    enc = lib.avifEncoderCreate()
+    if not enc:
+        raise RuntimeError("avifEncoderCreate failed")
+    out = _AvifRWData(None, 0)
+    imgs = []
+    try:
+        h = _AvifEncoderHead.from_address(enc)
+        if (h.codecChoice, h.maxThreads, h.speed, h.timescale, h.minQuantizer, h.maxQuantizer) != (0, 1, -1, 1, 0, 63):
+            raise RuntimeError("unexpected avifEncoder layout (libavif %s)" % lib.avifVersion().decode())
+        h.codecChoice = lib.avifCodecChoiceFromName(b"aom")
+        h.maxThreads, h.speed, h.timescale = int(threads), int(speed), 30
+        h.keyframeInterval = int(keyint)
+        h.minQuantizer, h.maxQuantizer = 0, 63
+        adv = {"end-usage": "q", "cq-level": str(cq)}
+        if extra:
+            adv.update(extra)
+        for k, v in adv.items():
+            r = lib.avifEncoderSetCodecSpecificOption(enc, k.encode(), str(v).encode())
+            if r != 0:
+                raise RuntimeError("avifEncoderSetCodecSpecificOption(%s): %s" % (k, lib.avifResultToString(r).decode()))
+        single = len(frames) == 1
+        for t, planes in enumerate(frames):
+            hh, ww = planes[0].shape
+            img = lib.avifImageCreate(ww, hh, depth, 3)   # AVIF_PIXEL_FORMAT_YUV420
+            imgs.append(img)
+            if lib.avifImageAllocatePlanes(img, 1) != 0:   # AVIF_PLANES_YUV
+                raise RuntimeError("avifImageAllocatePlanes failed")
+            ih = _AvifImageHead.from_address(img)
+            ih.yuvRange = 0   # limited, as the Y4M input of the GPU path
+            for p in range(3):
+                a = np.ascontiguousarray(planes[p].astype(np.uint8 if depth == 8 else "<u2"))
+                ph, rb = a.shape[0], ih.yuvRowBytes[p]
+                dst = np.frombuffer((C.c_uint8 * (rb * ph)).from_address(ih.yuvPlanes[p]), dtype=np.uint8).reshape(ph, rb)
+                dst[:, :a.shape[1] * a.itemsize] = a.view(np.uint8).reshape(ph, -1)
+            flags = 2 if single else (1 if (keyint == 1 or t == 0) else 0)   # SINGLE | FORCE_KEYFRAME
+            r = lib.avifEncoderAddImage(enc, img, 1, flags)
+            if r != 0:
+                raise RuntimeError("avifEncoderAddImage: %s" % lib.avifResultToString(r).decode())
+        r = lib.avifEncoderFinish(enc, C.byref(out))
+        if r != 0:
+            raise RuntimeError("avifEncoderFinish: %s" % lib.avifResultToString(r).decode())
+        return C.string_at(out.data, out.size)
+    finally:
+        if out.data:
+            lib.avifRWDataFree(C.byref(out))
+        for img in imgs:
+            lib.avifImageDestroy(img)
+        lib.avifEncoderDestroy(enc)
+
+
 if __name__ == "__main__":
     lib = _load()
     print("libavif", lib.avifVersion().decode())
