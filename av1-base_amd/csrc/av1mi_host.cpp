@@ -38,7 +38,7 @@ hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void 
                            unsigned long long *unit_sse, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
-                                const uint8_t *lr_choice, uint32_t *tile_order,
+                                const uint8_t *lr_choice, uint32_t *tile_order, int frame0, int count,
                                 hipStream_t s, hipEvent_t mid);
 hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t s);
 hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
@@ -400,8 +400,10 @@ struct av1mi_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // CDEF + SSE run here, beside the entropy kernels on `stream`
+  hipStream_t stream3 = nullptr;  // inter chunks: entropy coding of finished groups of frames, beside the frame-by-frame chain
   hipEvent_t ev[12] = {};
   std::vector<hipEvent_t> me_ev;       // per frame: its motion search has finished (second stream -> main stream)
+  std::vector<hipEvent_t> grp_ev;      // per group of frames of an inter chunk: reconstructed (main stream -> third stream)
   std::string err;
   // workspace (device)
   size_t cap_frames = 0;
@@ -633,7 +635,10 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device_id) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
     return AV1MI_E_NO_DEVICE;
   }
@@ -649,8 +654,10 @@ void av1mi_ctx_destroy(av1mi_ctx *c) {
   free_workspace(c);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->me_ev) (void)hipEventDestroy(e);
+  for (auto &e : c->grp_ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   delete c;
 }
 
@@ -794,6 +801,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   const bool inter_chunk = P.keyint > 1 && n_frames > 1;
   const bool lr = P.enable_lr != 0;
+  uint32_t entropy_from = 0;      // inter chunks: frames before this one are entropy-coded on the third stream, beside the chain
+  bool entropy_joined = false;
   void *cdef_out = lr ? c->d_cd : c->d_fin;   // with loop restoration CDEF writes d_cd and the restored frame goes to d_fin
   if (!inter_chunk) {
     HIPCHK(c, av1mi_launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
@@ -826,6 +835,13 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       if (P.subpel) HIPCHK(c, av1mi_launch_subpel_refine(&P, d_src, c->d_me, c->d_me_sub, P.me_range, (int)f, 1, c->stream2));
       HIPCHK(c, hipEventRecord(c->me_ev[f], c->stream2));
     }
+    // Entropy coding beside the chain: every frame starts from the default CDFs, so a group of frames can be symbolized and
+    // range-coded (third stream) as soon as its last frame is reconstructed (and, with restoration on, its unit choices are
+    // known) while the chain reconstructs the following frames; only the last group's entropy coding is left after the chain.
+    // (AV1MI_ENTROPY_GROUP=k: groups of k frames - tests force small groups on short chunks; 0 = no overlap)
+    uint32_t grp = n_frames <= 8 ? n_frames : ((n_frames + 5) / 6 < 8 ? 8 : (n_frames + 5) / 6);
+    if (const char *eg = getenv("AV1MI_ENTROPY_GROUP")) { const int k = atoi(eg); grp = k > 0 ? (uint32_t)k : n_frames; }
+    uint32_t n_grp = 0;
     for (uint32_t f = 0; f < n_frames; f++) {
       const uint8_t *srcf = (const uint8_t *)d_src + f * fbytes;
       uint8_t *recf = (uint8_t *)c->d_rec + f * fbytes, *finf = (uint8_t *)c->d_fin + f * fbytes, *cdf_ = (uint8_t *)cdef_out + f * fbytes;
@@ -847,7 +863,24 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         const int upf = ((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
         HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, c->d_lrsse + (size_t)f * upf * 8, s));
       }
+      if ((f + 1) % grp == 0 && f + 1 < n_frames) {   // a full group that is not the last: hand it to the third stream
+        if (c->grp_ev.size() <= n_grp) {
+          hipEvent_t e;
+          HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          c->grp_ev.push_back(e);
+        }
+        HIPCHK(c, hipEventRecord(c->grp_ev[n_grp], s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream3, c->grp_ev[n_grp], 0));
+        HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
+                                       c->d_tile_off, (int)(f + 1 - grp), (int)grp, c->stream3, nullptr));
+        n_grp++;
+      }
     }
+    entropy_from = n_grp * grp;
+    if (n_grp) {  // join: packing (main stream) needs every group's tile sizes and bytes
+      HIPCHK(c, hipEventRecord(c->ev[10], c->stream3));
+    }
+    entropy_joined = n_grp != 0;
   }
   HIPCHK(c, hipEventRecord(c->ev[2], s));
   // CDEF (+SSE) depends only on the reconstruction.  The range-coding kernel is a latency-bound
@@ -856,7 +889,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   hipStream_t s2 = getenv("AV1MI_SERIAL") ? c->stream : c->stream2;  // AV1MI_SERIAL: single-stream timing experiments
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
-                                 c->d_tile_off /* scratch until the packing kernels fill it */, s, c->ev[7]));
+                                 c->d_tile_off /* scratch until the packing kernels fill it */, (int)entropy_from, (int)(n_frames - entropy_from), s, c->ev[7]));
+  if (entropy_joined) HIPCHK(c, hipStreamWaitEvent(s, c->ev[10], 0));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   if (!inter_chunk && !lr && P.lf_level[0]) {  // deblocking reads only the reconstruction and block info: beside symbolize
     HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));

@@ -522,10 +522,12 @@ template <bool FULL, bool INTER, int TSB>
 __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, const uint16_t *__restrict__ cdf_init,
                                                            const int16_t *__restrict__ levels, const Av1miBlkInfo *__restrict__ blk,
                                                            uint32_t *__restrict__ streams, uint32_t *__restrict__ stream_len,
-                                                           uint32_t *__restrict__ tile_combos, const uint8_t *__restrict__ lr_choice) {
+                                                           uint32_t *__restrict__ tile_combos, const uint8_t *__restrict__ lr_choice,
+                                                           int tile0 /* chunk-wide index of this launch's first tile: launches cover whole frames */) {
   // one wave per TILE of TSB x TSB superblocks (raster order inside the tile)
   const int tiles_per_frame = P.tile_rows * P.tile_cols, sbs_per_frame = P.sb_rows * P.sb_cols;
-  const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
+  const int gt = (int)blockIdx.x + tile0;
+  const int f = gt / tiles_per_frame, tile = gt % tiles_per_frame;
   const int tr = tile / P.tile_cols, tc = tile % P.tile_cols;
   const int lane = threadIdx.x;
   {
@@ -556,7 +558,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   }
   __syncthreads();
   Sym y;
-  y.out = streams + (size_t)blockIdx.x * P.stream_cap;
+  y.out = streams + (size_t)gt * P.stream_cap;
   y.pos = 0; y.cap = P.stream_cap;
   y.combo0 = -1; y.combo1 = -1;
   const int adapt = !P.disable_cdf_update;
@@ -733,8 +735,8 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
 #undef INFO
   }  // superblocks of the tile
   if (lane == 0) {
-    stream_len[blockIdx.x] = (uint32_t)y.pos;
-    tile_combos[blockIdx.x] = (uint32_t)((y.combo0 & 0xFF) | ((y.combo1 & 0xFF) << 8));
+    stream_len[gt] = (uint32_t)y.pos;
+    tile_combos[gt] = (uint32_t)((y.combo0 & 0xFF) | ((y.combo1 & 0xFF) << 8));
   }
 }
 #undef S
@@ -781,13 +783,14 @@ __shared__ RcLds g_rc;
 __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, int n_tiles, const uint16_t *__restrict__ cdf_init,
                                                              const uint32_t *__restrict__ streams, const uint32_t *__restrict__ stream_len,
                                                              const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
-                                                             uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ order) {
+                                                             uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ order,
+                                                             int tile0 /* chunk-wide index of the launch's first tile; n_tiles and `order` are launch-local */) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // order != nullptr (more tiles than the chip holds workgroups for at once): the 64 tiles of a workgroup are neighbours in
   // the order of decreasing stream length (tile_order_kernel) - a wave lasts as long as its longest tile, so similar lengths
   // waste the fewest lane-cycles, and the long ones start first
   const bool live = (int)(blockIdx.x * 64 + lane) < n_tiles;
-  const int tile = live ? (order ? (int)order[blockIdx.x * 64 + lane] : (int)(blockIdx.x * 64 + lane)) : n_tiles;
+  const int tile = live ? tile0 + (order ? (int)order[blockIdx.x * 64 + lane] : (int)(blockIdx.x * 64 + lane)) : 0;
   const int count_raw = live ? (int)stream_len[tile] : 0;
   const bool overflow = count_raw > P.stream_cap;
   const int count = overflow ? 0 : count_raw;
@@ -950,17 +953,20 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
 extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels,
                                            const Av1miBlkInfo *blk, uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos,
                                            uint8_t *slots, uint32_t *tile_bytes, const uint8_t *lr_choice, uint32_t *tile_order /* n_tiles entries of scratch */,
+                                           int frame0, int count /* frames [frame0, frame0 + count) of the chunk: all arrays are chunk-wide */,
                                            hipStream_t stream, hipEvent_t mid) {
-  const int n_tiles = P->n_frames * P->tile_rows * P->tile_cols;
-  const bool has_inter = P->keyint > 1 && P->n_frames > 1;
+  const int tpf = P->tile_rows * P->tile_cols;
+  const int n_tiles = count * tpf, tile0 = frame0 * tpf;
+  bool has_inter = false, has_key = false;
+  for (int f = frame0; f < frame0 + count; f++) { if (av1mi_frame_is_inter(*P, f)) has_inter = true; else has_key = true; }
 #define SYM_LAUNCH(FULLV, INTERV, TSBV)                                                                                                   \
   hipLaunchKernelGGL((symbolize_tile_kernel<FULLV, INTERV, TSBV>), dim3(n_tiles), dim3(64), 0, stream, *P, cdf_init, levels, blk, streams, \
-                     stream_len, tile_combos, lr_choice)
+                     stream_len, tile_combos, lr_choice, tile0)
   if (P->tile_sb == 1) {
-    SYM_LAUNCH(false, false, 1); SYM_LAUNCH(true, false, 1);
+    if (has_key) { SYM_LAUNCH(false, false, 1); SYM_LAUNCH(true, false, 1); }
     if (has_inter) { SYM_LAUNCH(false, true, 1); SYM_LAUNCH(true, true, 1); }
   } else {
-    SYM_LAUNCH(false, false, 2); SYM_LAUNCH(true, false, 2);
+    if (has_key) { SYM_LAUNCH(false, false, 2); SYM_LAUNCH(true, false, 2); }
     if (has_inter) { SYM_LAUNCH(false, true, 2); SYM_LAUNCH(true, true, 2); }
   }
 #undef SYM_LAUNCH
@@ -970,8 +976,8 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   // one long tile among short ones - measured 1.1 -> 2.1 ms).  Beyond it the workgroups run in rounds, and what counts is
   // the sum over workgroups of their longest tile: sorted order (4K, 30 frames: 3.9 -> 2.9 ms).
   const bool sorted = (n_tiles + 63) / 64 > 2 * 256;
-  if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len, tile_order);
+  if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len + tile0, tile_order + tile0);
   hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
-                     tile_combos, slots, tile_bytes, sorted ? tile_order : (uint32_t *)nullptr);
+                     tile_combos, slots, tile_bytes, sorted ? tile_order + tile0 : (uint32_t *)nullptr, tile0);
   return hipGetLastError();
 }

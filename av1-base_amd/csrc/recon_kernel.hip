@@ -75,6 +75,30 @@ struct SbLds {
 };
 __shared__ SbLds g_sb;
 #define S (&g_sb)
+
+// ---- diagnostic build only (-DAV1MI_STAMPS, tools/stamp_recon.py): where a transform item spends its cycles.  Lane 0 adds the
+// s_memtime difference of every phase to LDS sums per item class; the wave adds them to g_stamp_sum when it ends.  The
+// product build compiles none of this.
+#ifdef AV1MI_STAMPS
+#define STAMP_CLASSES 6
+#define STAMP_PHASES 8
+__device__ unsigned long long g_stamp_sum[STAMP_CLASSES * STAMP_PHASES + 3];   // + wave cycles, waves, wave time in 100 MHz ticks
+struct StampLds { unsigned long long last, acc[STAMP_CLASSES * STAMP_PHASES]; };
+__shared__ StampLds g_stamp;
+__device__ __forceinline__ void stamp_phase(int cls, int phase) {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0);   // everything the phase issued has landed
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x == 0) {
+    if (phase >= 0) g_stamp.acc[cls * STAMP_PHASES + phase] += t - g_stamp.last;
+    g_stamp.last = t;
+  }
+}
+#define STAMP(phase) stamp_phase(NPL == 1 ? 5 - LOG2N : 7 - LOG2N, (phase))
+#else
+#define STAMP(phase) do { } while (0)
+#endif
 // motion compensation at sub-sample positions (inter instantiations only): reference window and horizontal-pass output
 struct McLds {
   uint16_t win[39 * 39 + 7];
@@ -336,6 +360,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   if constexpr (PH == 2) {
     if (plane0 > 0 && ii.is_inter) { inter_done(); return; }
   }
+  STAMP(-1);
   // ---- source block -> LDS (coalesced rows)
   {
     const PIX *pl = frame + poff;
@@ -380,6 +405,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     if (lane < N) S->smw[lane] = c_sm_weights[WOFF + lane];
   }
   __syncthreads();
+  STAMP(0);   // source -> LDS, edges from the line buffers
   // ---- DC value (sum within the lane group)
   {
     int s = 0;
@@ -413,6 +439,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     if (s_h < best_sad) { best_sad = s_h; best_mode = H_PRED; }
     first = 13;
   }
+  STAMP(1);   // DC value + the default candidates' SADs
 #pragma nounroll
   for (int m = first; m <= 13; m++) {
     const bool final_trip = m == 13;
@@ -478,6 +505,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   }
   mode_io = best_mode;
   __syncthreads();
+  STAMP(2);   // other candidates, decision, prediction + residual
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
   const int txt = (LOG2N <= 4 && !(INTER && ii.is_inter)) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
   const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
@@ -494,6 +522,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     for (int i = 0; i < N; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
   }
   __syncthreads();
+  STAMP(3);   // forward columns
   int my_key = -1;  // (anti-diagonal << 6 | position inside it) of the last nonzero level in scan order
   int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk) + po;  // source block is dead: reuse for the levels
   // dead-zone quantiser + normative dequantiser (§7.12.3) of this lane's coefficient row.  QM: the step of every position
@@ -550,6 +579,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     for (int j = 0; j < N; j++) S->scratch[so + sl * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
   }
   __syncthreads();
+  STAMP(4);   // forward rows, quantiser, dequantiser, eob, inverse rows
   if (tx_lane && eob) {
     const int maxv = (1 << bd) - 1;
 #pragma unroll
@@ -567,6 +597,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
     for (int i = sl; i < WORDS; i += G) d32[i] = (uint32_t)(uint16_t)lvl[2 * i] | ((uint32_t)(uint16_t)lvl[2 * i + 1] << 16);
   }
   __syncthreads();
+  STAMP(5);   // inverse columns, levels -> HBM
   // ---- reconstruction -> HBM (coalesced rows) and -> line buffers for the neighbours to come
   {
     PIX *pl = rec_frame + poff;
@@ -587,6 +618,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   }
   if (sl == 0) eob_out[grp] = eob;
   __syncthreads();
+  STAMP(6);   // reconstruction -> HBM, line buffers, decoded-block map
 }
 
 // Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
@@ -677,6 +709,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // structure (0.6 KB) to scratch at the start of the kernel and read its fields back from there.  Loads through a
   // uniform const pointer are scalar loads.
   const Av1miDevParams &P = *Pd;
+#ifdef AV1MI_STAMPS
+  if (threadIdx.x < STAMP_CLASSES * STAMP_PHASES) g_stamp.acc[threadIdx.x] = 0;
+  const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // one wave per TILE: TSB x TSB superblocks in raster order (TSB = 1 unless the frame needs more than 64 x 64 tiles)
   const int tiles_per_frame = P.tile_rows * P.tile_cols, sbs_per_frame = P.sb_rows * P.sb_cols;
   const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
@@ -719,6 +755,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     encode_superblock<PIX, INTER, TSB, QM>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
                                            me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
   }
+#ifdef AV1MI_STAMPS
+  __syncthreads();
+  if (threadIdx.x < STAMP_CLASSES * STAMP_PHASES && g_stamp.acc[threadIdx.x]) atomicAdd(&g_stamp_sum[threadIdx.x], g_stamp.acc[threadIdx.x]);
+  if (threadIdx.x == 0) { atomicAdd(&g_stamp_sum[STAMP_CLASSES * STAMP_PHASES], __builtin_amdgcn_s_memtime() - stamp_t0); atomicAdd(&g_stamp_sum[STAMP_CLASSES * STAMP_PHASES + 1], 1ull);
+                          atomicAdd(&g_stamp_sum[STAMP_CLASSES * STAMP_PHASES + 2], __builtin_amdgcn_s_memrealtime() - stamp_r0); }
+#endif
 }
 
 // First launch of an inter frame: every leaf block coded as an INTER block - motion compensation with the search's vector,
@@ -785,6 +827,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #undef S
 
 }  // namespace
+
+#ifdef AV1MI_STAMPS
+// diagnostic build: read (and clear) the phase sums.  out[class * 8 + phase] cycles, then total wave cycles, then waves
+extern "C" int av1mi_debug_stamps(unsigned long long *out, int reset) {
+  unsigned long long z[STAMP_CLASSES * STAMP_PHASES + 3] = {};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_sum), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 
 // ref == nullptr: P->n_frames key frames in one launch.  ref != nullptr: ONE inter frame (P->n_frames must be 1),
 // predicted from `ref` with the motion search results `me_best` of that frame.

@@ -1472,11 +1472,14 @@ static void encode_partition(Enc *e, int mi_r, int mi_c, int bsl) {
   if (mi_r >= g->mi_rows || mi_c >= g->mi_cols) return;
   has_rows = (mi_r + half) < g->mi_rows;
   has_cols = (mi_c + half) < g->mi_cols;
-  /* encoder decision: a block may be a leaf only if it lies fully inside the frame */
+  /* encoder decision: a node is a leaf iff its size is <= max_bs and the syntax lets it be one, i.e. its
+   * half point lies inside the frame both ways (has_rows && has_cols).  Such a block may OVERHANG the frame edge by less
+   * than half its size (1080 = 16 x 64 + 56: the bottom 32x32 blocks cover rows 1056..1087); the decoder reconstructs the
+   * whole block and keeps what is inside, the encoder sees the source extended by replication there. */
   if (bsl <= cfg->min_bs_log2 || bsl == 3) split = 0;
   else if (bsl > cfg->max_bs_log2) split = 1;
   else split = 0;
-  if (mi_r + n4 > g->mi_rows || mi_c + n4 > g->mi_cols) split = 1;
+  if (!has_rows || !has_cols) split = 1;
   if (bsl == 3) split = 0;
   /* context (§8.3.2 partition): neighbours' block sizes */
   {
@@ -1567,6 +1570,34 @@ long av1o_encode_frame(const Av1oConfig *cfg, const Av1oFrame *src, int with_seq
   return av1o_encode_frame2(cfg, src, NULL, NULL, with_seq_hdr, out, out_cap, recon, stats);
 }
 
+/* a frame of logical size w x h whose planes are allocated up to the next multiple of 64 both ways: blocks that overhang the
+ * frame edge (encode_partition) read the replicated source and write their reconstruction there */
+static Av1oFrame *frame_alloc_overhang(int w, int h) {
+  Av1oFrame *f = (Av1oFrame *)calloc(1, sizeof(*f));
+  const int aw = (w + 63) & ~63, ah = (h + 63) & ~63;
+  int p;
+  f->w = w;
+  f->h = h;
+  for (p = 0; p < 3; p++) {
+    f->stride[p] = p ? aw / 2 : aw;
+    f->p[p] = (uint16_t *)calloc((size_t)f->stride[p] * (p ? ah / 2 : ah), sizeof(uint16_t));
+  }
+  return f;
+}
+/* `in` (w x h) copied into such a frame, its last column / row replicated over the allocated margin */
+static Av1oFrame *frame_extend_overhang(const Av1oFrame *in, int w, int h) {
+  Av1oFrame *o = frame_alloc_overhang(w, h);
+  const int aw = (w + 63) & ~63, ah = (h + 63) & ~63;
+  int p, x, y;
+  for (p = 0; p < 3; p++) {
+    int ss = p > 0, pw = w >> ss, ph = h >> ss, paw = aw >> ss, pah = ah >> ss;
+    for (y = 0; y < pah; y++)
+      for (x = 0; x < paw; x++)
+        o->p[p][(size_t)y * o->stride[p] + x] = in->p[p][(size_t)(y < ph ? y : ph - 1) * in->stride[p] + (x < pw ? x : pw - 1)];
+  }
+  return o;
+}
+
 /* copy `in` (iw x ih luma) into a new frame of ow x oh, replicating the last column / row */
 static Av1oFrame *pad_frame(const Av1oFrame *in, int iw, int ih, int ow, int oh) {
   Av1oFrame *o = av1o_frame_alloc(ow, oh);
@@ -1605,6 +1636,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   }
   Geom g;
   Enc *e;
+  Av1oFrame *src_ext = NULL;
   Av1oLrUnit *lr_units = NULL;
   Av1oFrame *lr_out = NULL;
   size_t pos = 0, payload_cap, hdr_bits, n_mi;
@@ -1620,8 +1652,9 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   e = (Enc *)calloc(1, sizeof(Enc));
   e->cfg = cfg;
   e->g = &g;
-  e->src = src;
-  e->rec = av1o_frame_alloc(cfg->width, cfg->height);
+  src_ext = frame_extend_overhang(src, cfg->width, cfg->height);
+  e->src = src_ext;
+  e->rec = frame_alloc_overhang(cfg->width, cfg->height);
   n_mi = (size_t)g.mi_rows * g.mi_cols;
   e->mi_bsl = (uint8_t *)calloc(n_mi, 1);
   e->mi_skip = (uint8_t *)calloc(n_mi, 1);
@@ -1743,6 +1776,7 @@ done:
   free(e->mi_bsl); free(e->mi_skip); free(e->mi_ymode); free(e->cdef_idx_sb);
   free(e->mi_is_inter); free(e->mi_newmv); free(e->mi_mv);
   free(lr_units); av1o_frame_free(lr_out);
+  av1o_frame_free(src_ext);
   av1o_frame_free(e->rec);
   free(e);
   return ret;

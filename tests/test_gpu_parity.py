@@ -290,6 +290,27 @@ def test_inter_chunk_bitstream_and_recon_equal_oracle(av1mi, ctx, oracle, w, h, 
         assert rb[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
 
 
+@pytest.mark.parametrize("w,h,bd,n,group,extra", [(200, 120, 8, 7, 2, dict()), (328, 248, 10, 5, 1, dict(enable_lr=2, deblock=1)), (136, 136, 8, 6, 4, dict(subpel=1, keyint=3))])
+def test_entropy_coding_in_groups_beside_the_chain(av1mi, oracle, monkeypatch, w, h, bd, n, group, extra):
+    """Inter chunks entropy-code finished groups of frames on a third stream while the chain reconstructs the next ones
+    (production chunks: groups of >= 8 frames).  Forced to small groups here: streams and reconstructions must not depend on
+    the grouping - bit-exact against the oracle, and equal to the ungrouped run."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=600 + w, t=t) for t in range(n)]
+    raw = b"".join(raw_of(f, bd) for f in frames)
+    keyint = extra.pop("keyint", 240)
+    p = av1mi.default_params(w, h, bd, keyint=keyint, **extra)
+    outs = []
+    for g in (group, 0):
+        monkeypatch.setenv("AV1MI_ENTROPY_GROUP", str(g))
+        with av1mi.Context(0) as c:
+            data, sizes, rep, recon = c.encode_chunk(p, raw, n, want_recon=True)
+        outs.append((data, list(sizes), recon.tobytes()))
+    assert outs[0] == outs[1]
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5, enable_lr=extra.get("enable_lr", 0), deblock=extra.get("deblock", 0), subpel=extra.get("subpel", 0))
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert outs[0][0] == b"".join(tus) and outs[0][2] == b"".join(raw_of(r, bd) for r in recs)
+
+
 def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_sequences):
     """The dav1d-pinned inter sequences the GPU path can express (decision-driven, one-superblock tiles)."""
     n = 0

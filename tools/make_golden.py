@@ -75,6 +75,13 @@ CASES = [
     ("k72x56_qm15_flat", 72, 56, 8, 11, 0, dict(min_bs_log2=5, max_bs_log2=5, enable_qm=1, qm_y=15, qm_uv=15)),
     ("fuzz_qm_y3_uv11_bs6_10b", 136, 136, 10, 63, 0, dict(min_bs_log2=6, max_bs_log2=6, enable_qm=1, qm_y=3, qm_uv=11, fuzz_coeffs=63, fuzz_density=6, fuzz_maxlevel=12, fuzz_modes=2)),
     ("fuzz_qm_y14_uv0_bs4", 136, 72, 8, 64, 0, dict(min_bs_log2=4, max_bs_log2=4, enable_qm=1, qm_y=14, qm_uv=0, fuzz_coeffs=64, fuzz_density=3, fuzz_maxlevel=20, mode_mask=0x1FFF)),
+    # blocks that overhang the frame edge (a node is a leaf when its half point is inside: remainders of 56 / 24 samples with
+    # 32x32 blocks, 40..56 with 64x64): right edge, bottom edge, the corner; decision-driven and fuzzed, with the loop filters
+    ("k248x216_overhang", 248, 216, 8, 71, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF)),
+    ("k184x176_overhang_bs6_10b", 184, 176, 10, 72, 1, dict(min_bs_log2=6, max_bs_log2=6, deblock=1, enable_lr=2)),
+    ("k88x120_overhang_lr_deblock", 88, 120, 8, 73, 0, dict(min_bs_log2=5, max_bs_log2=5, deblock=1, enable_lr=1, cdef_y_sec=2, cdef_uv_sec=1)),
+    ("fuzz_overhang_bs5", 216, 248, 10, 74, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_modes=74, fuzz_coeffs=74, fuzz_density=6, fuzz_maxlevel=30)),
+    ("fuzz_overhang_bs6_onetile", 248, 184, 8, 75, 0, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=75, tile_w_sb=64, tile_h_sb=64, enable_lr=2)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -114,6 +121,11 @@ SEQ_CASES = [
     ("pfuzz_subpel_onetile_bs5", 264, 200, 8, 30, 3, dict(min_bs_log2=5, max_bs_log2=5, subpel=1, fuzz_modes=6, tile_w_sb=64, tile_h_sb=64, enable_lr=1)),
     ("p200x120_lr2", 200, 120, 8, 1080, 3, dict(min_bs_log2=5, max_bs_log2=5, enable_lr=2)),
     ("pfuzz_lr2_10b", 200, 120, 10, 26, 3, dict(min_bs_log2=4, max_bs_log2=4, enable_lr=2, fuzz_modes=12)),
+    # inter frames with blocks that overhang the frame edge: motion compensation, the candidate list and the filters at the edge
+    ("p248x216_overhang", 248, 216, 8, 76, 3, dict(min_bs_log2=5, max_bs_log2=5)),
+    ("p216x120_overhang_subpel_deblock_lr2_10b", 216, 120, 10, 77, 3, dict(min_bs_log2=5, max_bs_log2=5, subpel=1, deblock=1, enable_lr=2, me_range=16)),
+    ("pfuzz_overhang_bs6_subpel", 184, 248, 8, 78, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=11, subpel=1)),
+    ("pfuzz_overhang_bs5_onetile", 248, 184, 10, 79, 3, dict(min_bs_log2=5, max_bs_log2=5, fuzz_modes=13, tile_w_sb=64, tile_h_sb=64, deblock=1)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
