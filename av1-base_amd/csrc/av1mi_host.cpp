@@ -634,9 +634,19 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   // taking its slots
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device_id) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+  // experiment knob: AV1MI_AUX_CU_MASK=<hex word> restricts the two auxiliary streams (bulk work beside the chain) to the CUs whose bit
+  // is set in the word, repeated over the chip's 256 CUs (0x55555555: every other CU)
+  bool aux_ok = true;
+  if (const char *m = getenv("AV1MI_AUX_CU_MASK")) {
+    uint32_t mask[8];
+    const uint32_t word = (uint32_t)strtoul(m, nullptr, 16);
+    for (auto &w : mask) w = word;
+    aux_ok = hipSetDevice(device_id) == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream2, 8, mask) == hipSuccess &&
+             hipExtStreamCreateWithCUMask(&c->stream3, 8, mask) == hipSuccess;
+  }
+  if (!aux_ok || hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      (!c->stream2 && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess) ||
+      (!c->stream3 && hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo) != hipSuccess)) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;

@@ -510,7 +510,7 @@ __device__ __forceinline__ bool node_split(const Av1miDevParams &P, int sb_x, in
   if (bsl <= P.min_bs_log2 || bsl == 3) split = false;
   else if (bsl > P.max_bs_log2) split = true;
   else split = false;
-  if (sb_y + oy + n > P.height || sb_x + ox + n > P.width) split = true;
+  if (sb_y + oy + (n >> 1) >= P.height || sb_x + ox + (n >> 1) >= P.width) split = true;   // has_rows / has_cols
   if (bsl == 3) split = false;
   return split;
 }

@@ -36,7 +36,8 @@ __device__ __forceinline__ int leaf_bsl_cell(const Av1miDevParams &P, int cx, in
   for (int bsl = 5; bsl >= 3; bsl--) {
     const int n = 1 << bsl;
     const int ox = x & ~(n - 1), oy = y & ~(n - 1);
-    const bool split = (bsl > P.max_bs_log2 && bsl > 3) || ((oy + n > P.height || ox + n > P.width) && bsl > 3);
+    // (a node splits where its half point is outside the frame; a leaf may overhang the frame edge by less than half its size)
+    const bool split = (bsl > P.max_bs_log2 && bsl > 3) || ((oy + (n >> 1) >= P.height || ox + (n >> 1) >= P.width) && bsl > 3);
     if (!split) return (ox == x && oy == y) ? bsl : 0;
   }
   return 0;
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
   const int cx = (cell % cells_x) * 32, cy = (cell / cells_x) * 32;
   const int lane = threadIdx.x, r = lane >> 1, half = lane & 1;
   const int W = P.width, H = P.height;
-  // ---- source: 16 samples of row cy + r (zeros outside the frame: those sub-blocks are never used), reference: samples
+  // ---- source: 16 samples of row cy + r (edge samples replicated outside the frame), reference: samples
   // x0 - R .. x0 + 15 + R of row cy + r + dy (coordinates clamped to the frame); both packed two samples per register:
   // s2[k] = source (2k, 2k+1); rE[k] = reference (2k, 2k+1), rO[k] = (2k+1, 2k+2): the source pair k meets rE[k + dx/2]
   // for even dx and rO[k + (dx-1)/2] for odd dx, compared with v_sad_u16 (4 instructions per 8 samples).
@@ -78,8 +79,9 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
     } else {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
+        // source outside the frame: its last column / row replicated (srow is clamped), what an overhanging leaf is compared with
         const int xa = xs + 2 * k;
-        const uint32_t p0 = (y < H && xa < W) ? (uint32_t)srow[xa] : 0u, p1 = (y < H && xa + 1 < W) ? (uint32_t)srow[xa + 1] : 0u;
+        const uint32_t p0 = (uint32_t)srow[xa < W ? xa : W - 1], p1 = (uint32_t)srow[xa + 1 < W ? xa + 1 : W - 1];
         s2[k] = p0 | (p1 << 16);
       }
 #pragma unroll
@@ -207,7 +209,12 @@ __device__ __forceinline__ void refine_leaf(const Av1miDevParams &P, const PIX *
     }
     uint16_t sv[RPL];
 #pragma unroll
-    for (int k = 0; k < RPL; k++) { const int p = lane + 64 * k; sv[k] = (uint16_t)src[(size_t)(y + (p >> LOG2N)) * P.stride_y + x + (p & (n - 1))]; }
+    for (int k = 0; k < RPL; k++) {   // (source of an overhanging leaf: last row / column replicated)
+      const int p = lane + 64 * k;
+      int yy = y + (p >> LOG2N), xx = x + (p & (n - 1));
+      yy = yy > H - 1 ? H - 1 : yy; xx = xx > W - 1 ? W - 1 : xx;
+      sv[k] = (uint16_t)src[(size_t)yy * P.stride_y + xx];
+    }
 #pragma unroll
     for (int k = 0; k < K; k++) { const int p = lane + 64 * k, i = p / WW, j = p - i * WW; if (p < TOT) win[i * WS + j] = v[k]; }
 #pragma unroll

@@ -21,6 +21,16 @@
 #include "av1mi_dev.h"
 #include "av1_tables.h"
 #define AV1_TXFM_FN static __device__ __forceinline__
+// Round2(w0 * a + w1 * b, 12) of the butterfly rotations with 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24: full rate; the
+// generic form's two 64-bit multiply-adds run at a quarter of it and were 474 of a 32x32 block's 7.6 k instructions).  Exact
+// whenever the operands have at most 24 bits and the sum fits 32: the weights have 13 bits (|w| <= 4096, w0^2 + w1^2 = 4096^2),
+// the data stays below 2^19 - inverse transforms: the spec's conformance bound of 8 + BitDepth bits on every intermediate
+// (§7.13.2.1), which the dequantiser's clamp enforces at the input; forward transforms: residual << 2 through a 32-point network
+// (tools/gen_txfm.py's bound) - so |w0 * a + w1 * b| <= 4096 * sqrt(2) * 2^18.5 < 2^31.
+#define AV1_HALF_BTF_DEFINED
+static __device__ __forceinline__ int32_t av1_half_btf(int32_t w0, int32_t a, int32_t w1, int32_t b) {
+  return (__mul24(w0, a) + __mul24(w1, b) + 2048) >> 12;
+}
 #include "txfm_gen.h"
 
 namespace {
@@ -311,9 +321,26 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
 // PH = 1 codes the block as an inter block, no neighbours involved (no edges, no mode decision, no line buffers);
 // PH = 2 takes the intra/inter decision with the neighbours in place and, when motion compensation wins, only moves the
 // finished block's edges from HBM into the line buffers - the block is coded here only if intra prediction wins.
+// Everything comes BY VALUE and the decision goes back in the return value ((is_inter << 8) | mode): a structure passed by
+// reference to a `noinline` function lives in scratch memory, and every field access was a per-lane scratch load (the P-frame
+// tile walk carried 348 B of scratch per lane for it).  The wave-uniform arguments are laundered through readfirstlane so that
+// the compiler keeps them - and everything derived from them: addresses, edge availability, loop bounds - on the scalar unit.
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *uniform_p(T *p) {
+  const unsigned long long a = (unsigned long long)p;
+  return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+}
 template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM, int PH>
-__device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
-                                                  int &mode_io, InterInfo &ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
+__device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
+                                                 int mode_io, InterInfo ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
+  cx.P = uniform_p(cx.P); cx.sb_x = uniform_i(cx.sb_x); cx.sb_y = uniform_i(cx.sb_y); cx.tox = uniform_i(cx.tox); cx.toy = uniform_i(cx.toy);
+  frame = uniform_p(frame); rec_frame = uniform_p(rec_frame); plane0 = uniform_i(plane0); x0 = uniform_i(x0); y0 = uniform_i(y0);
+  mode_io = uniform_i(mode_io); lv_out0 = uniform_p(lv_out0); lv_out1 = uniform_p(lv_out1); eob_out = uniform_p(eob_out);
+  if (INTER) {
+    ii.ref = uniform_p(ii.ref); ii.mv_row = uniform_i(ii.mv_row); ii.mv_col = uniform_i(ii.mv_col); ii.sad_inter = uniform_i(ii.sad_inter);
+    ii.is_inter = uniform_i(ii.is_inter); ii.pre_eob[0] = uniform_i(ii.pre_eob[0]); ii.pre_eob[1] = uniform_i(ii.pre_eob[1]); ii.pre_eob[2] = uniform_i(ii.pre_eob[2]);
+  }
   constexpr int N = 1 << LOG2N;
   constexpr int ST = N + 1;
   constexpr int G = 64 / NPL;              // lanes per group
@@ -338,34 +365,45 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   // tile-local plane coordinates of the block: what the line buffers and edge availability are indexed by
   const int lx = (plane0 ? cx.tox >> 1 : cx.tox) + x0, ly = (plane0 ? cx.toy >> 1 : cx.toy) + y0;
   const int have_above = ly > 0, have_left = lx > 0;
+  // a block may overhang the right / bottom frame edge (by less than half its size): the source is read with its last column /
+  // row replicated, the reconstruction is stored only inside the plane
+  const int pw_lim = (plane0 ? P->width >> 1 : P->width) - gx, ph_lim = (plane0 ? P->height >> 1 : P->height) - gy;   // samples of the block inside
+  const bool overhang = pw_lim < N || ph_lim < N;
   // PH == 2, motion compensation won: the block is already reconstructed in HBM - bottom row, right column and corners go to
   // the line buffers, the decoded-block map and the eob are set, nothing else happens
   auto inter_done = [&]() {
     if constexpr (PH == 2) {
       const PIX *pl = rec_frame + poff;
+      // (positions of an overhanging block that lie outside the plane are never read back - intra edges stop at the frame
+      // limit - they only have to be loaded from inside the buffer)
+      const int rb = N - 1 < ph_lim ? N - 1 : ph_lim - 1, cb = N - 1 < pw_lim ? N - 1 : pw_lim - 1;   // last row / column inside
       if (sl < N) {
-        LN.above[plane][lx + sl] = (uint16_t)pl[(size_t)(gy + N - 1) * gs + gx + sl];
-        LN.left[plane][ly + sl] = (uint16_t)pl[(size_t)(gy + sl) * gs + gx + N - 1];
+        LN.above[plane][lx + sl] = (uint16_t)pl[(size_t)(gy + rb) * gs + gx + (sl < pw_lim ? sl : pw_lim - 1)];
+        LN.left[plane][ly + sl] = (uint16_t)pl[(size_t)(gy + (sl < ph_lim ? sl : ph_lim - 1)) * gs + gx + cb];
       }
       if (sl < step) {
-        const int j = sl + 1;
-        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = (uint16_t)pl[(size_t)(gy + N - 1) * gs + gx + 4 * j - 1];
-        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = (uint16_t)pl[(size_t)(gy + 4 * j - 1) * gs + gx + N - 1];
+        const int j = sl + 1, q = 4 * j - 1;
+        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = (uint16_t)pl[(size_t)(gy + rb) * gs + gx + (q < pw_lim ? q : pw_lim - 1)];
+        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = (uint16_t)pl[(size_t)(gy + (q < ph_lim ? q : ph_lim - 1)) * gs + gx + cb];
       }
       for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
-      if (sl == 0) eob_out[grp] = ii.pre_eob[plane];
+      if (sl == 0) eob_out[grp] = plane == 0 ? ii.pre_eob[0] : (plane == 1 ? ii.pre_eob[1] : ii.pre_eob[2]);   // (no dynamic index: the array stays in registers)
       __syncthreads();
     }
   };
   if constexpr (PH == 2) {
-    if (plane0 > 0 && ii.is_inter) { inter_done(); return; }
+    if (plane0 > 0 && ii.is_inter) { inter_done(); return (ii.is_inter << 8) | mode_io; }
   }
   STAMP(-1);
   // ---- source block -> LDS (coalesced rows)
   {
     const PIX *pl = frame + poff;
 #pragma unroll   // all of the block's loads in flight together (N*N/G <= 16 per lane)
-    for (int p = sl; p < N * N; p += G) S->srcblk[po + p] = (uint16_t)pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))];
+    for (int p = sl; p < N * N; p += G) {
+      int r = p >> LOG2N, c = p & (N - 1);
+      if (overhang) { r = r < ph_lim ? r : ph_lim - 1; c = c < pw_lim ? c : pw_lim - 1; }
+      S->srcblk[po + p] = (uint16_t)pl[(size_t)(gy + r) * gs + gx + c];
+    }
   }
   // ---- edges from the line buffers (spec §7.11.2; tile == superblock: nothing outside it is available)
   int dcv = 0;
@@ -449,7 +487,7 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
       // inter frames: motion compensation wins when its luma SAD is not larger
       if (INTER) ii.is_inter = ii.sad_inter <= best_sad;
       if constexpr (PH == 2) {
-        if (ii.is_inter) { mode_io = best_mode; inter_done(); return; }
+        if (ii.is_inter) { inter_done(); return (1 << 8) | best_mode; }
       }
     }
     const int mode = final_trip ? best_mode : m;
@@ -503,7 +541,6 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
       else if (sad < best_sad) { best_sad = sad; best_mode = m; }
     }
   }
-  mode_io = best_mode;
   __syncthreads();
   STAMP(2);   // other candidates, decision, prediction + residual
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
@@ -602,7 +639,10 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   {
     PIX *pl = rec_frame + poff;
 #pragma unroll 4
-    for (int p = sl; p < N * N; p += G) pl[(size_t)(gy + (p >> LOG2N)) * gs + gx + (p & (N - 1))] = (PIX)S->blkpix[po + p];
+    for (int p = sl; p < N * N; p += G) {
+      const int r = p >> LOG2N, c = p & (N - 1);
+      if (!overhang || (r < ph_lim && c < pw_lim)) pl[(size_t)(gy + r) * gs + gx + c] = (PIX)S->blkpix[po + p];
+    }
     if constexpr (PH != 1) {
       if (sl < N) {
         LN.above[plane][lx + sl] = S->blkpix[po + (N - 1) * N + sl];
@@ -619,11 +659,12 @@ __device__ __attribute__((noinline)) void tx_item(const SbCtx &cx, const PIX *fr
   if (sl == 0) eob_out[grp] = eob;
   __syncthreads();
   STAMP(6);   // reconstruction -> HBM, line buffers, decoded-block map
+  return ((INTER ? ii.is_inter : 0) << 8) | best_mode;
 }
 
 // Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
-// not the origin of a leaf.  The tree is a pure function of geometry: a block is
-// a leaf iff it lies inside the frame and its size is <= max_bs (never below 8x8).
+// not the origin of a leaf.  The tree is a pure function of geometry: a node is a leaf iff
+// its size is <= max_bs and its half point lies inside the frame both ways (never below 8x8).
 __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, int sb_y, int bx, int by) {
   for (int bsl = 6; bsl >= 3; bsl--) {
     const int n = 1 << bsl;
@@ -632,7 +673,9 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
     if (bsl <= P.min_bs_log2 || bsl == 3) split = false;
     else if (bsl > P.max_bs_log2) split = true;
     else split = false;
-    if (sb_y + oy + n > P.height || sb_x + ox + n > P.width) split = true;
+    // the syntax forces a split where the node's half point is outside the frame (has_rows / has_cols of §5.11.4); a leaf may
+    // overhang the frame edge by less than half its size
+    if (sb_y + oy + (n >> 1) >= P.height || sb_x + ox + (n >> 1) >= P.width) split = true;
     if (bsl == 3) split = false;
     if (!split) return (ox == bx && oy == by) ? bsl : 0;
   }
@@ -674,11 +717,14 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
     int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
     // luma (mode decision inside), then U and V together
+    int dec;
     switch (bsl) {
-      case 5: tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      case 4: tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      default: tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 5: dec = tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      case 4: dec = tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+      default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
     }
+    dec = uniform_i(dec);
+    mode = dec & 0xFF; ii.is_inter = dec >> 8;   // the luma pass decides; the chroma pass follows it
     switch (bsl) {
       case 5: tx_item<PIX, 4, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
       case 4: tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
@@ -690,10 +736,11 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
         const int i = cx.lane / n8, j = cx.lane - i * n8;
         Av1miBlkInfo bi;
+        const bool unit_inside = cx.sb_y + by + 8 * i < P.height && cx.sb_x + bx + 8 * j < P.width;   // an overhanging block's units beyond the frame have no entry
         bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)((e0 | e1 | e2) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
         bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2;
         bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0); bi.pad = 0;
-        info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
+        if (unit_inside) info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
       }
     }
   }

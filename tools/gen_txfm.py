@@ -359,8 +359,9 @@ def main():
            " * place.  av1_half_btf(w0,a,w1,b) = Round2(w0*a + w1*b, 12) with 4096*cos(k*pi/128) weights. */",
            "#ifndef AV1MI_TXFM_GEN_H", "#define AV1MI_TXFM_GEN_H", "#include <stdint.h>",
            "#ifndef AV1_TXFM_FN", "#define AV1_TXFM_FN static inline", "#endif",
+           "#ifndef AV1_HALF_BTF_DEFINED  /* an includer may bring its own (the HIP kernels: 24-bit multiplies) */",
            "AV1_TXFM_FN int32_t av1_half_btf(int32_t w0, int32_t a, int32_t w1, int32_t b) {",
-           "  return (int32_t)(((int64_t)w0 * a + (int64_t)w1 * b + 2048) >> 12);", "}", ""]
+           "  return (int32_t)(((int64_t)w0 * a + (int64_t)w1 * b + 2048) >> 12);", "}", "#endif", ""]
     for name, st in nets.items():
         emit_straightline(name, st, hdr)
     hdr.append("#endif")
