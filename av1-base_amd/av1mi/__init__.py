@@ -36,7 +36,7 @@ E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_OOM, E_OVERFLOW, E_FORMAT, E_UNSUPPORTED = 
 
 # every symbol include/av1mi.h declares
 ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", "av1mi_last_error", "av1mi_encode_chunk",
-               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute", "av1mi_probe_y4m", "av1mi_chunk_owner", "av1mi_plan_workers"]
+               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute", "av1mi_probe_y4m", "av1mi_chunk_owner", "av1mi_plan_workers", "av1mi_release_caches"]
 
 
 class Params(C.Structure):
@@ -164,6 +164,11 @@ def plan_workers(workers, gpu_mask, n_devices):
     buf = (C.c_int32 * 64)()
     n = _lib.av1mi_plan_workers(workers, gpu_mask, n_devices, buf, 64)
     return [int(buf[i]) for i in range(min(n, 64))]
+
+
+def release_caches():
+    """give back the idle contexts and pinned host buffers av1mi_encode_file keeps between jobs"""
+    _lib.av1mi_release_caches()
 
 
 def probe_y4m(path):

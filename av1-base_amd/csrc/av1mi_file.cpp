@@ -11,9 +11,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -34,6 +37,9 @@ struct Y4m {
   int color_range = -1;       // XCOLORRANGE tag: 0 LIMITED, 1 FULL, -1 absent
   size_t frame_bytes = 0;
   uint64_t total_frames = 0;  // from the file size (plain "FRAME\n" markers); 0 = unknown (pipe)
+  long data_off = 0;          // file offset of the first FRAME marker
+  uint64_t next_frame = 0;    // frames handed out so far (regular files: position of the next frame)
+  bool regular = false;       // seekable regular file: frames can be read in parallel with pread
 };
 
 int y4m_open(const char *path, Y4m *y) {
@@ -69,8 +75,11 @@ int y4m_open(const char *path, Y4m *y) {
   {  // frame count of a regular file: every frame is "FRAME\n" + frame_bytes (frame parameters would only make this an over-estimate)
     const long pos = ftell(y->f);
     struct stat sb;
-    if (pos >= 0 && fstat(fileno(y->f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > pos)
+    if (pos >= 0 && fstat(fileno(y->f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > pos) {
       y->total_frames = (uint64_t)(sb.st_size - pos) / (6 + y->frame_bytes);
+      y->data_off = pos;
+      y->regular = true;
+    }
   }
   return 0;
 }
@@ -218,9 +227,165 @@ struct Muxer {
   uint32_t bit_depth = 8;
 };
 
+// ---- host staging (BASELINE config 5 "per-GPU multi-stream overlap"; SURVEY.md §8e limiter "PCIe H2D of source frames") -------
+// Chunks are read straight into PINNED host buffers (hipHostMalloc, portable across the job's GPUs) from a small pool: a
+// context's upload of its next chunk is then a true asynchronous DMA at PCIe rate that runs beside the kernels of the other
+// contexts on the same GPU (several contexts per GPU by default), instead of the runtime staging pageable memory through its
+// own bounce buffer.  A slot goes back to the pool as soon as its chunk is encoded.
+struct PinnedPool {
+  struct Slot { uint8_t *p = nullptr; size_t cap = 0; bool busy = false, pinned = false; };
+  std::vector<Slot> slots;
+  std::mutex mu;
+  std::condition_variable cv;
+  int device = 0;
+  bool pinned_ok = true;   // falls back to plain memory if the runtime refuses to pin (the encode still works, only slower)
+  void init(int n, int dev);   // takes idle buffers from the process-wide cache
+  void retire();               // gives them back
+  Slot *acquire(size_t bytes) {
+    std::unique_lock<std::mutex> lk(mu);
+    Slot *s = nullptr;
+    cv.wait(lk, [&] { for (auto &x : slots) if (!x.busy) { s = &x; return true; } return false; });
+    s->busy = true;
+    lk.unlock();
+    if (s->cap < bytes) {
+      release_mem(s);
+      const size_t want = bytes + (bytes >> 3);
+      s->pinned = pinned_ok && hipSetDevice(device) == hipSuccess && hipHostMalloc((void **)&s->p, want, hipHostMallocPortable) == hipSuccess;
+      if (!s->pinned) { pinned_ok = false; s->p = (uint8_t *)malloc(want); }
+      s->cap = s->p ? want : 0;
+    }
+    return s;
+  }
+  void release(Slot *s) {
+    { std::lock_guard<std::mutex> lk(mu); s->busy = false; }
+    cv.notify_all();
+  }
+  void release_mem(Slot *s) {
+    if (!s->p) return;
+    if (s->pinned) (void)hipHostFree(s->p); else free(s->p);
+    s->p = nullptr; s->cap = 0; s->pinned = false;
+  }
+  ~PinnedPool() { retire(); }
+};
+
+// ---- process-wide caches ---------------------------------------------------------------------------------------------------
+// The daemon is a long-lived process that encodes job after job (JobExecutor::execute, job_executor.rs:266-437): creating
+// contexts (streams, several GB of HBM workspace each) and pinning host buffers per job cost more than a short clip's whole
+// encode (measured: 4 contexts 50 ms, 6 pinned 373 MB slots ~60 ms to allocate and ~60 ms to free, against 18 ms of GPU work
+// for 240 1080p frames).  Idle contexts and pinned slots are therefore kept between calls - "the per-GPU context owns its
+// frame pool"  - bounded, and released by av1mi_release_caches().
+struct GlobalCache {
+  std::mutex mu;
+  std::vector<std::pair<int, av1mi_ctx *>> ctxs;   // idle contexts (device, context)
+  std::vector<PinnedPool::Slot> slots;             // idle host buffers
+  size_t slot_bytes = 0;
+};
+GlobalCache &cache() { static GlobalCache *g = new GlobalCache(); return *g; }   // never destroyed: no HIP calls at process exit
+const size_t kMaxCachedCtxPerDev = 8, kMaxCachedSlotBytes = (size_t)24 << 30;
+
+void PinnedPool::init(int n, int dev) {
+  slots.resize((size_t)n);
+  device = dev;
+  GlobalCache &g = cache();
+  std::lock_guard<std::mutex> lk(g.mu);
+  for (auto &s : slots) {
+    if (g.slots.empty()) break;
+    s = g.slots.back();
+    s.busy = false;
+    g.slot_bytes -= s.cap;
+    g.slots.pop_back();
+  }
+}
+void PinnedPool::retire() {
+  GlobalCache &g = cache();
+  for (auto &s : slots) {
+    if (!s.p) continue;
+    bool kept = false;
+    {
+      std::lock_guard<std::mutex> lk(g.mu);
+      if (s.pinned && g.slot_bytes + s.cap <= kMaxCachedSlotBytes) { g.slots.push_back(s); g.slot_bytes += s.cap; kept = true; }
+    }
+    if (!kept) release_mem(&s);
+    s.p = nullptr; s.cap = 0;
+  }
+  slots.clear();
+}
+
+int take_ctx(int dev, av1mi_ctx **out) {
+  {
+    GlobalCache &g = cache();
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (size_t i = 0; i < g.ctxs.size(); i++)
+      if (g.ctxs[i].first == dev) { *out = g.ctxs[i].second; g.ctxs.erase(g.ctxs.begin() + (long)i); return AV1MI_OK; }
+  }
+  return av1mi_ctx_create(dev, out);
+}
+void give_ctx(int dev, av1mi_ctx *c) {
+  if (!c) return;
+  GlobalCache &g = cache();
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    size_t n = 0;
+    for (auto &e : g.ctxs) n += e.first == dev;
+    if (n < kMaxCachedCtxPerDev) { g.ctxs.emplace_back(dev, c); return; }
+  }
+  av1mi_ctx_destroy(c);
+}
+
+// Reads frames [first, first + count) of a Y4M into dst (tight I420, frame after frame).  Regular files: the frames sit at
+// known offsets, so up to `threads` readers pread() them in parallel - one thread copies page cache to the destination at a few
+// GB/s, which at 6 MB per 1080p 10-bit frame is ~1 k frames/s, a tenth of what one GPU encodes.  Pipes: sequential fread.
+// Returns the number of whole frames read (short at end of file); *err receives a format / IO error.
+uint32_t y4m_read_frames(Y4m *y, uint8_t *dst, uint32_t count, int threads, int *err) {
+  *err = 0;
+  if (!y->regular) {
+    uint32_t n = 0;
+    int r = 1;
+    while (n < count && (r = y4m_read_frame(y, dst + (size_t)n * y->frame_bytes)) == 1) n++;
+    if (r != 0 && r != 1) *err = r;
+    return n;
+  }
+  const uint64_t left = y->total_frames > y->next_frame ? y->total_frames - y->next_frame : 0;
+  uint32_t n = (uint32_t)(left < count ? left : count);
+  if (n == 0) {   // a trailing partial frame is a malformed file, not a clean end
+    struct stat sb;
+    if (fstat(fileno(y->f), &sb) == 0 && (uint64_t)sb.st_size > (uint64_t)y->data_off + y->next_frame * (6 + y->frame_bytes)) *err = AV1MI_E_FORMAT;
+    return 0;
+  }
+  const int fd = fileno(y->f);
+  const uint64_t first = y->next_frame;
+  std::atomic<uint32_t> next(0);
+  std::atomic<int> bad(0);
+  auto work = [&] {
+    for (;;) {
+      const uint32_t k = next.fetch_add(1);
+      if (k >= n || bad.load()) return;
+      const off_t off = (off_t)((uint64_t)y->data_off + (first + k) * (6 + y->frame_bytes));
+      char mark[6];
+      if (pread(fd, mark, 6, off) != 6 || memcmp(mark, "FRAME\n", 6) != 0) { bad.store(AV1MI_E_FORMAT); return; }   // frame parameters are not supported
+      uint8_t *d = dst + (size_t)k * y->frame_bytes;
+      size_t got = 0;
+      while (got < y->frame_bytes) {
+        const ssize_t r = pread(fd, d + got, y->frame_bytes - got, off + 6 + (off_t)got);
+        if (r <= 0) { bad.store(r < 0 ? -errno : AV1MI_E_FORMAT); return; }
+        got += (size_t)r;
+      }
+    }
+  };
+  const int nt = threads < 1 ? 1 : ((uint32_t)threads > n ? (int)n : threads);
+  std::vector<std::thread> th;
+  for (int i = 1; i < nt; i++) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+  if (bad.load()) { *err = bad.load(); return 0; }
+  y->next_frame += n;
+  // a clip whose size is not a whole number of frames: the tail shows up as an error once the whole frames are consumed
+  return n;
+}
+
 struct Chunk {
   uint32_t index = 0, n_frames = 0, first_frame = 0;
-  std::vector<uint8_t> frames;
+  PinnedPool::Slot *slot = nullptr;   // the chunk's frames: slot->p, pinned
   av1mi_buf out = { nullptr, 0 };
   std::vector<uint32_t> sizes;
   av1mi_report rep = {};
@@ -245,6 +410,20 @@ extern "C" int av1mi_plan_workers(uint32_t workers, int32_t gpu_mask, int n_devi
   return (int)w;
 }
 
+extern "C" void av1mi_release_caches(void) {
+  GlobalCache &g = cache();
+  std::vector<std::pair<int, av1mi_ctx *>> cs;
+  std::vector<PinnedPool::Slot> ss;
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    cs.swap(g.ctxs);
+    ss.swap(g.slots);
+    g.slot_bytes = 0;
+  }
+  for (auto &e : cs) av1mi_ctx_destroy(e.second);
+  for (auto &s : ss) if (s.p) { if (s.pinned) (void)hipHostFree(s.p); else free(s.p); }
+}
+
 extern "C" int av1mi_probe_y4m(const char *path, av1mi_clip_info *info) {
   if (!path || !info) return AV1MI_E_INVALID_ARG;
   Y4m y;
@@ -259,6 +438,11 @@ extern "C" int av1mi_probe_y4m(const char *path, av1mi_clip_info *info) {
 
 extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total) {
   if (!job || !job->input_path || !job->output_path) return AV1MI_E_INVALID_ARG;
+  const bool timing = getenv("AV1MI_TIMING") != nullptr;   // phase times on stderr (diagnostics)
+  const auto tt0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (timing) fprintf(stderr, "[av1mi_encode_file] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count(), what);
+  };
   Y4m y;
   int rc = y4m_open(job->input_path, &y);
   if (rc) { if (y.f) fclose(y.f); return rc; }
@@ -276,27 +460,39 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   const uint32_t workers = (uint32_t)planned;
   std::vector<av1mi_ctx *> ctxs(workers, nullptr);
   for (uint32_t i = 0; i < workers; i++) {
-    rc = av1mi_ctx_create(dev_of[i], &ctxs[i]);
-    if (rc) { for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
+    rc = take_ctx(dev_of[i], &ctxs[i]);
+    if (rc) { for (uint32_t k = 0; k < i; k++) give_ctx(dev_of[k], ctxs[k]); fclose(y.f); return rc; }
   }
+  std::vector<int> ctx_dev(dev_of, dev_of + workers);
+  auto give_all = [&] { for (size_t k = 0; k < ctxs.size(); k++) give_ctx(ctx_dev[k], ctxs[k]); ctxs.clear(); };
+  lap("contexts created");
   av1mi_ctx *det_ctx = nullptr;  // the reader thread's own context for the scene-cut pass
   if (scene_mode) {
-    rc = av1mi_ctx_create(dev_of[0], &det_ctx);
-    if (rc) { for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
-    ctxs.push_back(det_ctx);  // destroyed with the others; gets no worker thread
+    rc = take_ctx(dev_of[0], &det_ctx);
+    if (rc) { give_all(); fclose(y.f); return rc; }
+    ctxs.push_back(det_ctx);  // returned with the others; gets no worker thread
+    ctx_dev.push_back(dev_of[0]);
   }
   std::string tmp = std::string(job->output_path) + ".tmp." + std::to_string((long)getpid());
   FILE *fo = fopen(tmp.c_str(), "wb");
-  if (!fo) { int e = -errno; for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return e; }
+  if (!fo) { int e = -errno; give_all(); fclose(y.f); return e; }
   Muxer mux;
   mux.fo = fo; mux.w = y.w; mux.h = y.h; mux.fps_n = y.fps_n; mux.fps_d = y.fps_d; mux.bit_depth = y.bd;
   {
     uint8_t sh[64]; size_t shn = sizeof(sh);
     rc = av1mi_write_headers(&prm, sh, &shn, nullptr, nullptr);
-    if (rc) { fclose(fo); unlink(tmp.c_str()); for (auto c : ctxs) av1mi_ctx_destroy(c); fclose(y.f); return rc; }
+    if (rc) { fclose(fo); unlink(tmp.c_str()); give_all(); fclose(y.f); return rc; }
     mux.begin(job->output_path, std::vector<uint8_t>(sh, sh + shn));
   }
 
+  // pinned staging: one slot being filled by the reader, one waiting, one per worker being uploaded / encoded
+  PinnedPool pool;
+  pool.init((int)workers + 2, dev_of[0]);
+  int hc = 0;
+  { cpu_set_t cs; if (sched_getaffinity(0, sizeof(cs), &cs) == 0) hc = CPU_COUNT(&cs); }   // the cores this process may use, not the host's
+  if (hc <= 0) hc = (int)std::thread::hardware_concurrency();
+  int read_threads = hc >= 16 ? 12 : (hc >= 8 ? 6 : (hc >= 4 ? 3 : 1));
+  if (const char *e = getenv("AV1MI_READ_THREADS")) { const int k = atoi(e); if (k > 0 && k <= 64) read_threads = k; }
   std::mutex mu;
   std::condition_variable cv_work, cv_done;
   std::deque<Chunk *> queue;
@@ -316,8 +512,11 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
       ck->sizes.resize(ck->n_frames);
       av1mi_params cp = prm;
       cp.first_frame = prm.first_frame + ck->first_frame;
-      ck->rc = av1mi_encode_chunk(ctx, &cp, ck->frames.data(), ck->n_frames, 0, &ck->out, ck->sizes.data(), nullptr, &ck->rep);
-      std::vector<uint8_t>().swap(ck->frames);
+      ck->rc = av1mi_encode_chunk(ctx, &cp, ck->slot->p, ck->n_frames, 0, &ck->out, ck->sizes.data(), nullptr, &ck->rep);
+      if (timing) fprintf(stderr, "[av1mi_encode_file] %8.2f ms  chunk %u encoded (h2d %.2f total %.2f ms on the device)\n",
+                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count(), ck->index, ck->rep.ms_h2d, ck->rep.ms_total);
+      pool.release(ck->slot);   // (av1mi_encode_chunk returns after its upload has completed)
+      ck->slot = nullptr;
       {
         std::lock_guard<std::mutex> lk(mu);
         done[ck->index] = ck;
@@ -394,52 +593,71 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
     // reader: fixed-length chunks (every chunk starts with a key frame)
     for (;;) {
       Chunk *ck = new Chunk();
-      ck->frames.resize((size_t)chunk_frames * y.frame_bytes);
-      int r = 1;
-      while (ck->n_frames < chunk_frames && (r = y4m_read_frame(&y, ck->frames.data() + (size_t)ck->n_frames * y.frame_bytes)) == 1) ck->n_frames++;
-      if (r != 0 && r != 1 && !first_err) first_err = r;  // a malformed or truncated frame (AV1MI_E_FORMAT) or an I/O error
-      if (ck->n_frames == 0) { delete ck; break; }
+      ck->slot = pool.acquire((size_t)chunk_frames * y.frame_bytes);
+      if (!ck->slot->p) { pool.release(ck->slot); delete ck; if (!first_err) first_err = AV1MI_E_OOM; break; }
+      int rerr = 0;
+      ck->n_frames = y4m_read_frames(&y, ck->slot->p, chunk_frames, read_threads, &rerr);
+      if (rerr && !first_err) first_err = rerr;  // a malformed or truncated frame (AV1MI_E_FORMAT) or an I/O error
+      if (ck->n_frames == 0) { pool.release(ck->slot); delete ck; break; }
+      lap("chunk read");
       enqueue(ck);
-      if (r != 1 || first_err) break;
+      if (first_err) break;
     }
   } else {
     // reader: chunks end at scene cuts (GPU luma-SAD pass per window of frames, include/av1mi.h: av1mi_scene_cuts)
     const uint32_t WIN = 32, MIN_SCENE = 12;
-    uint64_t cap = ((uint64_t)4 << 30) / y.frame_bytes;  // keep a chunk's frames under 4 GiB of host memory
-    const uint32_t max_len = (uint32_t)(cap < MIN_SCENE ? MIN_SCENE : (cap > 240 ? 240 : cap));
-    std::vector<uint8_t> win((size_t)WIN * y.frame_bytes), prev(y.frame_bytes);
+    // a chunk's frames plus the window being examined stay under 4 GiB of pinned host memory
+    const uint64_t cap = ((uint64_t)4 << 30) / y.frame_bytes;
+    const uint32_t max_len = (uint32_t)(cap < MIN_SCENE + WIN ? MIN_SCENE : (cap - WIN > 240 ? 240 : cap - WIN));
+    const size_t slot_bytes = (size_t)(max_len + WIN) * y.frame_bytes;
+    std::vector<uint8_t> prev(y.frame_bytes);
     std::vector<uint8_t> cuts(WIN);
-    bool has_prev = false;
+    bool has_prev = false, oom = false;
     av1mi_scene_state st = {};
+    // Windows are read straight behind the current chunk's frames in its pinned slot and examined there; only where a chunk
+    // ends inside a window do the frames after the cut move to the next chunk's slot.
     Chunk *cur = new Chunk();
-    for (;;) {
-      uint32_t nw = 0;
-      int r = 1;
-      while (nw < WIN && (r = y4m_read_frame(&y, win.data() + (size_t)nw * y.frame_bytes)) == 1) nw++;
-      if (r != 0 && r != 1 && !first_err) first_err = r;  // a malformed or truncated frame (AV1MI_E_FORMAT) or an I/O error
+    cur->slot = pool.acquire(slot_bytes);
+    oom = !cur->slot->p;
+    while (!oom && !first_err) {
+      uint8_t *win = cur->slot->p + (size_t)cur->n_frames * y.frame_bytes;
+      int rerr = 0;
+      uint32_t nw = y4m_read_frames(&y, win, WIN, read_threads, &rerr);
+      if (rerr && !first_err) first_err = rerr;  // a malformed or truncated frame (AV1MI_E_FORMAT) or an I/O error
       if (nw == 0) break;
-      int src = av1mi_scene_cuts(det_ctx, &prm, win.data(), nw, 0, has_prev ? prev.data() : nullptr, &st, MIN_SCENE, nullptr, cuts.data());
-      if (src && !first_err) { first_err = src; break; }
-      for (uint32_t t = 0; t < nw; t++) {
-        if ((cuts[t] && cur->n_frames > 0) || cur->n_frames == max_len) { enqueue(cur); cur = new Chunk(); }
-        const uint8_t *f = win.data() + (size_t)t * y.frame_bytes;
-        cur->frames.insert(cur->frames.end(), f, f + y.frame_bytes);
-        cur->n_frames++;
-      }
-      memcpy(prev.data(), win.data() + (size_t)(nw - 1) * y.frame_bytes, y.frame_bytes);
+      const int src = av1mi_scene_cuts(det_ctx, &prm, win, nw, 0, has_prev ? prev.data() : nullptr, &st, MIN_SCENE, nullptr, cuts.data());
+      if (src) { if (!first_err) first_err = src; break; }
+      memcpy(prev.data(), win + (size_t)(nw - 1) * y.frame_bytes, y.frame_bytes);
       has_prev = true;
-      if (r != 1 || first_err) break;
+      for (uint32_t t = 0; t < nw; t++) {
+        if ((cuts[t] && cur->n_frames > 0) || cur->n_frames == max_len) {
+          // frame t starts the next chunk: it and the rest of the window move to a slot of their own
+          Chunk *nx = new Chunk();
+          nx->slot = pool.acquire(slot_bytes);
+          if (!nx->slot->p) { pool.release(nx->slot); delete nx; oom = true; break; }
+          memcpy(nx->slot->p, cur->slot->p + (size_t)cur->n_frames * y.frame_bytes, (size_t)(nw - t) * y.frame_bytes);
+          enqueue(cur);
+          cur = nx;
+        }
+        cur->n_frames++;   // (the frame already sits in place: the window was read behind the chunk's frames)
+      }
     }
-    if (cur->n_frames > 0 && !first_err) enqueue(cur); else delete cur;
+    if (oom && !first_err) first_err = AV1MI_E_OOM;
+    if (cur->n_frames > 0 && !first_err) enqueue(cur); else { if (cur->slot) pool.release(cur->slot); delete cur; }
   }
   {
     std::lock_guard<std::mutex> lk(mu);
     eof = true;
   }
   cv_work.notify_all();
+  lap("input consumed");
   drain(true);
+  lap("all chunks written");
   for (auto &t : threads) t.join();
-  for (auto c : ctxs) av1mi_ctx_destroy(c);
+  if (first_err) { for (auto c : ctxs) av1mi_ctx_destroy(c); ctxs.clear(); }   // a context that saw a failure is not reused
+  give_all();
+  pool.retire();
+  lap("contexts and host buffers back in the cache");
   fclose(y.f);
   // patch frame count, finish atomically
   int io_err = 0;

@@ -178,6 +178,11 @@ int av1mi_probe_y4m(const char *path, av1mi_clip_info *info);
 
 int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, void *user, av1mi_report *total);
 
+/* av1mi_encode_file keeps its idle contexts (streams + HBM workspace) and pinned host buffers for the next job of the process -
+ * the daemon encodes job after job (job_executor.rs:266-437), and setting them up costs more than a short clip's encode.
+ * Bounded (8 contexts per GPU, 24 GiB of host buffers); this returns everything that is idle. */
+void av1mi_release_caches(void);
+
 /* ---- chunk -> GPU placement (independent chunks, no exchange step) -----------------------------------------
  * Replaces the placement av1an does implicitly by forking `--workers N` encoder processes on one host (av1an.rs:100-101;
  * ConcurrencyPlan.av1an_workers, concurrency.rs:9-18, 67-73).  Two pure functions, so the rule can be tested without a GPU and
