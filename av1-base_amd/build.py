@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libav1mi.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["recon_kernel.hip", "entropy_kernel.hip", "cdef_pack_kernels.hip", "scene_kernels.hip", "me_kernel.hip", "lr_kernel.hip", "deblock_kernel.hip", "av1mi_host.cpp", "av1mi_file.cpp", "av1mi_exec.cpp"]
+SOURCES = ["recon_kernel.hip", "recon64_kernel.hip", "entropy_kernel.hip", "cdef_pack_kernels.hip", "scene_kernels.hip", "me_kernel.hip", "lr_kernel.hip", "deblock_kernel.hip", "av1mi_host.cpp", "av1mi_file.cpp", "av1mi_exec.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-missing-braces", "-Wno-pass-failed"]
 
 
@@ -26,7 +26,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
-        os.path.join(HERE, "..", "include", "av1mi.h")]
+        os.path.join(HERE, "..", "include", "av1mi.h"), os.path.join(CSRC, "recon_kernel.hip")]   # (recon64_kernel.hip includes recon_kernel.hip)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs = []
     objs = []

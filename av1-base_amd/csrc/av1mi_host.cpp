@@ -27,10 +27,12 @@
 extern "C" {
 hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
                               const unsigned long long *me_best, hipStream_t s);
+hipError_t av1mi_launch_recon64(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
+                                const unsigned long long *me_best, hipStream_t s);
 hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, const unsigned long long *best, unsigned long long *refined,
                                       int me_range, int frame0, int count, hipStream_t stream);
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
-                                      int count, hipStream_t s);
+                                      int count, uint32_t *acc64, hipStream_t s);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
 hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop, hipStream_t s);
 hipError_t av1mi_launch_deblock(const Av1miDevParams *P, void *rec, const Av1miBlkInfo *blk, hipStream_t s);
@@ -101,7 +103,7 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.me_range == 0) p.me_range = 8;
   if (p.me_range != 8 && p.me_range != 16) return AV1MI_E_INVALID_ARG;
   if (p.block_log2 == 0) p.block_log2 = 5;
-  if (p.block_log2 < 3 || p.block_log2 > 5) return AV1MI_E_INVALID_ARG;
+  if (p.block_log2 < 3 || p.block_log2 > 6) return AV1MI_E_INVALID_ARG;
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
@@ -424,6 +426,8 @@ struct av1mi_ctx {
   void *d_stage = nullptr;             // sizes that are not multiples of 8: frames in the caller's tight layout (input / reconstruction out)
   void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
   unsigned long long *d_me_sub = nullptr;  // sub-sample refinement: refined [frame][8x8 unit] keys (me_kernel.hip)
+  uint32_t *d_me64 = nullptr;              // 64x64 leaves: the search's [frame][superblock][candidate] SAD table
+  size_t me64_bytes = 0;
   Av1miQmEntry *d_qm = nullptr;        // quantiser-matrix steps (Av1miDevParams::qm_tab), valid for qm_key = (level, qidx, bit depth)
   std::vector<Av1miQmEntry> h_qm;
   int qm_key = -1;
@@ -458,11 +462,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params, c->d_me64 };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr; c->d_me64 = nullptr; c->me64_bytes = 0;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -522,6 +526,15 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc(&c->d_stage, c->cap_frames * (size_t)p.width * p.height * 3 / 2 * bps));
   if (p.subpel && !c->d_me_sub)   // output of the sub-sample refinement
     HIPCHK(c, hipMalloc((void **)&c->d_me_sub, (size_t)c->cap_frames * (r.cw / 8) * (r.ch / 8) * 8));
+  if (p.block_log2 >= 6 && p.keyint > 1) {   // candidate table of the 64x64 leaves' motion search
+    const size_t nc = 2 * (size_t)(p.me_range ? p.me_range : 8) + 1, need = c->cap_frames * nsb * nc * nc * sizeof(uint32_t);
+    if (c->me64_bytes < need) {
+      if (c->d_me64) (void)hipFree(c->d_me64);
+      c->d_me64 = nullptr; c->me64_bytes = 0;
+      HIPCHK(c, hipMalloc((void **)&c->d_me64, need));
+      c->me64_bytes = need;
+    }
+  }
   if (p.enable_lr && !c->d_cd) {
     const size_t nf = c->cap_frames;
     HIPCHK(c, hipMalloc(&c->d_cd, nf * frame_samples * bps));
@@ -810,12 +823,14 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   const bool inter_chunk = P.keyint > 1 && n_frames > 1;
+  // 64x64 leaf blocks run the kernels of recon64_kernel.hip (64-point transforms, larger LDS tiles)
+  auto launch_recon = P.max_bs_log2 >= 6 ? av1mi_launch_recon64 : av1mi_launch_recon;
   const bool lr = P.enable_lr != 0;
   uint32_t entropy_from = 0;      // inter chunks: frames before this one are entropy-coded on the third stream, beside the chain
   bool entropy_joined = false;
   void *cdef_out = lr ? c->d_cd : c->d_fin;   // with loop restoration CDEF writes d_cd and the restored frame goes to d_fin
   if (!inter_chunk) {
-    HIPCHK(c, av1mi_launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
+    HIPCHK(c, launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
     if (lr) {  // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
       if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
       HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, s));
@@ -832,6 +847,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     // beside the chain below; the first inter frame's reconstruction waits for it.
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[1], 0));  // the source frames are in HBM
     HIPCHK(c, hipMemsetAsync(c->d_me, 0xFF, (size_t)n_frames * nb8 * 8, c->stream2));
+    uint32_t *acc64 = P.max_bs_log2 >= 6 ? c->d_me64 : nullptr;
+    if (acc64) HIPCHK(c, hipMemsetAsync(acc64, 0, (size_t)n_frames * nsb * (2 * P.me_range + 1) * (2 * P.me_range + 1) * sizeof(uint32_t), c->stream2));
     // one launch + one event per frame: the chain starts as soon as the first vectors exist and the search of the later
     // frames fills the SIMDs the chain's one-frame kernels leave idle
     while (c->me_ev.size() < n_frames) {
@@ -841,7 +858,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     }
     for (uint32_t f = 0; f < n_frames; f++) {
       if (!av1mi_frame_is_inter(P, (int)f)) continue;
-      HIPCHK(c, av1mi_launch_motion_search(&P, d_src, c->d_me, P.me_range, (int)f, 1, c->stream2));
+      HIPCHK(c, av1mi_launch_motion_search(&P, d_src, c->d_me, P.me_range, (int)f, 1, acc64, c->stream2));
       if (P.subpel) HIPCHK(c, av1mi_launch_subpel_refine(&P, d_src, c->d_me, c->d_me_sub, P.me_range, (int)f, 1, c->stream2));
       HIPCHK(c, hipEventRecord(c->me_ev[f], c->stream2));
     }
@@ -858,12 +875,12 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       Av1miBlkInfo *blkf = c->d_blk + f * nb8;
       int16_t *lvf = c->d_levels + f * nsb * AV1MI_SB_LEVELS;
       if (!av1mi_frame_is_inter(P, (int)f)) {
-        HIPCHK(c, av1mi_launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, nullptr, nullptr, s));
+        HIPCHK(c, launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, nullptr, nullptr, s));
       } else {
         const uint8_t *reff = (const uint8_t *)c->d_fin + (f - 1) * fbytes;
         unsigned long long *mef = (P.subpel ? c->d_me_sub : c->d_me) + f * nb8;
         HIPCHK(c, hipStreamWaitEvent(s, c->me_ev[f], 0));
-        HIPCHK(c, av1mi_launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, reff, mef, s));
+        HIPCHK(c, launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, reff, mef, s));
       }
       if (!av1mi_frame_is_inter(P, (int)f)) { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level[i]; }
       else { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level_inter[i]; }

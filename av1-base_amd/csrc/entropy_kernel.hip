@@ -175,7 +175,11 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
                                            int y4, int eob, int ymode, int is_inter, const int16_t *lv_global) {
   const int ptype = plane > 0;
   const int txs = log2n - 2;
-  const int n = 1 << log2n, w4 = n >> 2;
+  const int w4 = (1 << log2n) >> 2;
+  // a 64-point transform codes only its 32x32 low-frequency corner: contexts of the size class TX_64X64 (txs 4), scan, eob and
+  // neighbourhoods of a 32x32 area
+  const int bwl = log2n > 5 ? 5 : log2n;
+  const int n = 1 << bwl;
   const int max_x4 = plane ? tg.max_x4_c : tg.max_x4_y, max_y4 = plane ? tg.max_y4_c : tg.max_y4_y;
   const int aoff = (plane ? tg.tox >> 3 : tg.tox >> 2);  // above contexts are indexed by tile-local 4x4 column
 #define a_lvl (TI.above_lvl[plane] + aoff)
@@ -187,7 +191,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
     if (x4 + lane < max_x4) { nb_or |= (a_lvl[x4 + lane] | a_dc[x4 + lane]) ? 1 : 0; int sg = a_dc[x4 + lane]; dsum += sg == 1 ? -1 : (sg == 2 ? 1 : 0); }
     if (y4 + lane < max_y4) { nb_or |= (l_lvl[y4 + lane] | l_dc[y4 + lane]) ? 2 : 0; int sg = l_dc[y4 + lane]; dsum += sg == 1 ? -1 : (sg == 2 ? 1 : 0); }
   }
-  for (int o = 4; o > 0; o >>= 1) { nb_or |= __shfl_xor(nb_or, o, 64); dsum += __shfl_xor(dsum, o, 64); }
+  for (int o = 8; o > 0; o >>= 1) { nb_or |= __shfl_xor(nb_or, o, 64); dsum += __shfl_xor(dsum, o, 64); }   // w4 <= 16 lanes hold values
   nb_or = uni(nb_or); dsum = uni(dsum);
   // luma: TX_MODE_LARGEST with square blocks => transform == block => ctx 0
   const int zctx = plane == 0 ? 0 : 7 + (nb_or & 1) + (nb_or >> 1);
@@ -203,7 +207,8 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       // inter_tx_type: every inter block is DCT_DCT = symbol 7 / 3 / 1 of TX_SET_INTER_1 / _2 / _3 (§5.11.47)
       if (log2n <= 3) sym_wide<1>(y, lane, adapt, 7, CL::INTER_TX1 + (log2n - 2) * 17, 16);
       else if (log2n == 4) sym_wide<1>(y, lane, adapt, 3, CL::INTER_TX2, 12);
-      else sym_wide<1>(y, lane, adapt, 1, CL::INTER_TX3 + 3 * 3, 2);
+      else if (log2n == 5) sym_wide<1>(y, lane, adapt, 1, CL::INTER_TX3 + 3 * 3, 2);
+      // (TX_64X64: the transform set is DCT only, nothing is coded)
     } else if (plane == 0 && log2n <= 4) {
       const int tt = c_mode_txfm[ymode];
       if (log2n <= 3) sym_wide(y, lane, adapt, c_txsym_set1[tt], CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
@@ -213,7 +218,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       const int eob_pt = eob <= 2 ? eob : floor_log2((unsigned)(eob - 1)) + 2;
       const int base = eob_pt < 2 ? eob_pt : ((1 << (eob_pt - 2)) + 1);
       const int extra = eob - base;
-      const int msz = 2 * log2n - 4;
+      const int msz = 2 * bwl - 4;
       const int nsy = 5 + msz;
       const int eoff = CL::EOB16 + 4 * (msz * 6 + (msz * (msz - 1)) / 2);
       sym_wide(y, lane, adapt, eob_pt - 1, eoff + (ptype * 2 + 0) * (nsy + 1), nsy);
@@ -223,7 +228,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
         for (int i = 1; i < nbits; i++) emit1(y, lane, ENT_LITERAL((extra >> (nbits - 1 - i)) & 1));
       }
     }
-#define scan(i_) scan_pos((i_), log2n)
+#define scan(i_) scan_pos((i_), bwl)
     // slot range of this (tx size, plane type): the first MAX_COMBOS combinations met in a tile
     // adapt per lane in K4; any further combination is resolved here (cooperatively, slowly).
     const int combo = txs * 2 + ptype;
@@ -249,8 +254,8 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       int level = 0, cb = 0, cbr = 0, cnt = 0;
       if (c >= 0) {
         const int pos = scan(c);
-        const int row = pos >> log2n, col = pos & (n - 1);
-#define LVA(r_, c_) (((r_) < n && (c_) < n) ? iabs((int)S->lv[((r_) << log2n) + (c_)]) : 0)
+        const int row = pos >> bwl, col = pos & (n - 1);
+#define LVA(r_, c_) (((r_) < n && (c_) < n) ? iabs((int)S->lv[((r_) << bwl) + (c_)]) : 0)
         const int a01 = LVA(row, col + 1), a10 = LVA(row + 1, col), a11 = LVA(row + 1, col + 1), a02 = LVA(row, col + 2), a20 = LVA(row + 2, col);
 #undef LVA
         const int mag = imin(a01, 3) + imin(a10, 3) + imin(a11, 3) + imin(a02, 3) + imin(a20, 3);

@@ -43,10 +43,17 @@ __device__ __forceinline__ int leaf_bsl_cell(const Av1miDevParams &P, int cx, in
   return 0;
 }
 
+// The 32x32 cell at (cx, cy) lies in a 64x64 LEAF (block_log2 = 6): the node of its superblock is a leaf when its half point is
+// inside the frame both ways (it may overhang the edge by less than 32 samples).
+__device__ __forceinline__ bool cell_in_leaf64(const Av1miDevParams &P, int cx, int cy) {
+  return P.max_bs_log2 >= 6 && (cx & ~63) + 32 < P.width && (cy & ~63) + 32 < P.height;
+}
+
 template <typename PIX, int R>
 __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, const PIX *__restrict__ frames,
                                                           unsigned long long *__restrict__ best_all /* [frame][8x8 unit] */, int frame0,
-                                                          int vec_ok /* frames are 16-byte aligned */) {
+                                                          int vec_ok /* frames are 16-byte aligned */,
+                                                          uint32_t *__restrict__ acc64 /* 64x64 leaves: [frame][superblock][candidate] SAD sums, zeroed */) {
   constexpr int NC = 2 * R + 1;
   __shared__ uint32_t sad8[NC][16];  // [dx][8x8 sub-block of the cell, raster]
   const int f = frame0 + blockIdx.z;
@@ -115,6 +122,18 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
     }
   }
   __syncthreads();
+  // ---- a cell of a 64x64 leaf: the leaf's SAD of a candidate is the sum over its four cells - every (cell, dy) wave adds its
+  // cell sums to the leaf's candidate table; me64_reduce_kernel takes the minimum afterwards
+  if (cell_in_leaf64(P, cx, cy)) {
+    if (lane < NC) {
+      uint32_t sad = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) sad += sad8[lane][i];
+      const size_t leaf = (size_t)f * P.sb_rows * P.sb_cols + (size_t)(cy >> 6) * P.sb_cols + (cx >> 6);
+      atomicAdd(&acc64[(leaf * NC + dyi) * NC + lane], sad);
+    }
+    return;
+  }
   // ---- the usual cell: one 32x32 leaf.  Lane = dx candidate: each sums the 16 sub-block SADs of its dx, a wave minimum
   // over (cost, candidate) picks the best of this dy (as one lane looping over the candidates it was a third of the kernel)
   if (leaf_bsl_cell(P, cx, cy, 0, 0) == 5) {
@@ -160,6 +179,28 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
   }
 }
 
+// One wave per superblock that is a 64x64 leaf: cost and minimum over the candidate table the search filled (same rule: cost =
+// SAD + 64 * (|dx| + |dy|), the displaced block within 16 samples of the frame, ties to the first candidate in raster order).
+__global__ void __launch_bounds__(64) me64_reduce_kernel(Av1miDevParams P, const uint32_t *__restrict__ acc64,
+                                                        unsigned long long *__restrict__ best_all, int frame0, int R) {
+  const int f = frame0 + blockIdx.y;
+  if (!av1mi_frame_is_inter(P, f)) return;
+  const int sb = blockIdx.x, x = (sb % P.sb_cols) * 64, y = (sb / P.sb_cols) * 64;
+  if (!cell_in_leaf64(P, x, y)) return;
+  const int NC = 2 * R + 1, lane = threadIdx.x;
+  const uint32_t *tab = acc64 + ((size_t)f * P.sb_rows * P.sb_cols + sb) * NC * NC;
+  unsigned long long key = ~0ull;
+  for (int c = lane; c < NC * NC; c += 64) {
+    const int dy = c / NC - R, dx = c % NC - R;
+    if (x + dx < -16 || x + dx + 64 > P.width + 16 || y + dy < -16 || y + dy + 64 > P.height + 16) continue;
+    const unsigned long long cost = (unsigned long long)tab[c] + (unsigned long long)(64 * (iabs(dx) + iabs(dy)));
+    const unsigned long long k = (cost << 16) | (unsigned long long)c;
+    key = k < key ? k : key;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = t < key ? t : key; }
+  if (lane == 0) best_all[(size_t)f * P.b8_rows * P.b8_cols + (size_t)(y >> 3) * P.b8_cols + (x >> 3)] = key;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Sub-sample refinement (subpel = 1; oracle/av1o_enc.c motion_search, second half).
 // Around the full search's winner: the 8 half-sample neighbours, then the 8 quarter-sample neighbours of that stage's
@@ -189,39 +230,143 @@ __device__ __forceinline__ void hadamard8(int *v) {
   for (int i = 0; i < 8; i++) v[i] = t[i];
 }
 
+// The (n + 8)^2 reference window at (wx, wy) and the n x n source block at (x, y) -> LDS, all loads in flight together
+// (coordinates clamped to the frame: the reference as motion compensation clamps it, the source of an overhanging leaf with its
+// last row / column replicated).
+template <typename PIX, int LOG2N>
+__device__ __forceinline__ void refine_stage(const Av1miDevParams &P, const PIX *__restrict__ src, const PIX *__restrict__ ref, int x, int y,
+                                             int wx, int wy, uint16_t *win, uint16_t *srcb) {
+  constexpr int n = 1 << LOG2N, WW = n + 8, WS = n + 16;   // window width, row stride (rows stay 16-byte aligned)
+  constexpr int RPL = n * n / 64;
+  const int lane = threadIdx.x, W = P.width, H = P.height;
+  constexpr int TOT = WW * WW, K = (TOT + 63) / 64;
+  uint16_t v[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int p = lane + 64 * k, i = p / WW, j = p - i * WW;
+    int yy = wy + i, xx = wx + j;
+    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+    xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+    v[k] = p < TOT ? (uint16_t)ref[(size_t)yy * P.stride_y + xx] : 0;
+  }
+  uint16_t sv[RPL];
+#pragma unroll
+  for (int k = 0; k < RPL; k++) {
+    const int p = lane + 64 * k;
+    int yy = y + (p >> LOG2N), xx = x + (p & (n - 1));
+    yy = yy > H - 1 ? H - 1 : yy; xx = xx > W - 1 ? W - 1 : xx;
+    sv[k] = (uint16_t)src[(size_t)yy * P.stride_y + xx];
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) { const int p = lane + 64 * k, i = p / WW, j = p - i * WW; if (p < TOT) win[i * WS + j] = v[k]; }
+#pragma unroll
+  for (int k = 0; k < RPL; k++) srcb[lane + 64 * k] = sv[k];
+  __syncthreads();
+}
+
+// One candidate (mr, mc) of the n x n block at (x, y) from the staged window: interpolation (EIGHTTAP, both roundings), then the
+// wave sums of the absolute differences and of the absolute 8x8 Hadamard coefficients (not yet >> 3) against the source block.
+template <typename PIX, int LOG2N>
+__device__ __forceinline__ void refine_eval(const Av1miDevParams &P, int x, int y, int wx, int wy, int mr, int mc,
+                                            const uint16_t *win, int16_t *mid, const uint16_t *srcb, int16_t *dif, int &sad_out, int &satd_out) {
+  constexpr int n = 1 << LOG2N, WS = n + 16;
+  constexpr int RPL = n * n / 64;                            // vertical pass: output rows per lane
+  const int lane = threadIdx.x;
+  const int maxv = (1 << P.bit_depth) - 1;
+  const int px = (x << 4) + 2 * mc, py = (y << 4) + 2 * mr;
+  const int ix = (px >> 4) - 3 - wx, iy = (py >> 4) - 3 - wy, fx = px & 15, fy = py & 15;   // 0 <= ix, iy <= 1
+  int fh[8], fv[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) { fh[t] = c_subpel_me[0][fx][t]; fv[t] = c_subpel_me[0][fy][t]; }
+  // horizontal pass: task = (row r of mid, segment of 8 outputs)
+  constexpr int SEGS = n / 8, TASKS = (n + 7) * SEGS;
+  for (int task = lane; task < TASKS; task += 64) {
+    const int r = task / SEGS, sg = task - r * SEGS;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(win + (iy + r) * WS + 8 * sg);
+    const uint4 q0 = wp[0], q1 = wp[1];
+    const uint32_t d[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+    int a[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[2 * i] = (int)(d[i] & 0xFFFF); a[2 * i + 1] = (int)(d[i] >> 16); }
+    int o[8];
+    if (ix) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += fh[t] * a[1 + j + t];
+        o[j] = (sum + 4) >> 3; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += fh[t] * a[j + t];
+        o[j] = (sum + 4) >> 3; }
+    }
+    uint4 w;
+    w.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); w.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+    w.z = (uint32_t)(uint16_t)o[4] | ((uint32_t)(uint16_t)o[5] << 16); w.w = (uint32_t)(uint16_t)o[6] | ((uint32_t)(uint16_t)o[7] << 16);
+    *reinterpret_cast<uint4 *>(mid + r * n + 8 * sg) = w;
+  }
+  __syncthreads();
+  // vertical pass: lane = column c, rows r0 .. r0 + RPL - 1
+  int sad = 0;
+  {
+    const int c = lane & (n - 1), r0 = (lane >> LOG2N) * RPL;
+    int m[RPL + 7];
+#pragma unroll
+    for (int i = 0; i < RPL + 7; i++) m[i] = mid[(r0 + i) * n + c];
+#pragma unroll
+    for (int j = 0; j < RPL; j++) {
+      int sum = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) sum += fv[t] * m[j + t];
+      int v = (sum + 1024) >> 11;
+      v = v < 0 ? 0 : (v > maxv ? maxv : v);
+      const int d = (int)srcb[(r0 + j) * n + c] - v;
+      sad += iabs(d);
+      dif[(r0 + j) * n + c] = (int16_t)d;
+    }
+  }
+  __syncthreads();
+  // SATD: 8x8 Hadamard of the difference, rows (8 values of a row of a sub-block per task, written back), then
+  // columns (absolute sum); n^2/64 sub-blocks x 8 tasks each
+  constexpr int NB = n / 8, HT = NB * NB * 8;
+  for (int task = lane; task < HT; task += 64) {
+    const int b = task >> 3, i = task & 7;
+    int16_t *rowp = dif + ((b / NB) * 8 + i) * n + (b % NB) * 8;
+    const uint4 q = *reinterpret_cast<const uint4 *>(rowp);
+    int v[8] = { (int16_t)(q.x & 0xFFFF), (int16_t)(q.x >> 16), (int16_t)(q.y & 0xFFFF), (int16_t)(q.y >> 16),
+                 (int16_t)(q.z & 0xFFFF), (int16_t)(q.z >> 16), (int16_t)(q.w & 0xFFFF), (int16_t)(q.w >> 16) };
+    hadamard8(v);
+    uint4 w;
+    w.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16); w.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+    w.z = (uint32_t)(uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16); w.w = (uint32_t)(uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
+    *reinterpret_cast<uint4 *>(rowp) = w;
+  }
+  __syncthreads();
+  int satd = 0;
+  for (int task = lane; task < HT; task += 64) {
+    const int b = task >> 3, j = task & 7;
+    const int16_t *colp = dif + (b / NB) * 8 * n + (b % NB) * 8 + j;
+    int v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = colp[i * n];
+    hadamard8(v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) satd += iabs(v[i]);
+  }
+  for (int o = 32; o > 0; o >>= 1) { sad += __shfl_xor(sad, o, 64); satd += __shfl_xor(satd, o, 64); }
+  __syncthreads();
+  sad_out = sad; satd_out = satd;
+}
+
 template <typename PIX, int LOG2N>
 __device__ __forceinline__ void refine_leaf(const Av1miDevParams &P, const PIX *__restrict__ src, const PIX *__restrict__ ref, int x, int y,
                                             int &best_row, int &best_col, int &best_sad, uint16_t *win, int16_t *mid, uint16_t *srcb, int16_t *dif) {
-  constexpr int n = 1 << LOG2N, WW = n + 8, WS = n + 16;   // window width, row stride (rows stay 16-byte aligned)
-  constexpr int RPL = n * n / 64;                            // vertical pass: output rows per lane
-  const int lane = threadIdx.x, W = P.width, H = P.height;
+  constexpr int n = 1 << LOG2N;
+  const int W = P.width, H = P.height;
   const int wx = x + (best_col >> 3) - 4, wy = y + (best_row >> 3) - 4;   // window origin (the integer winner is a multiple of 8)
-  {
-    constexpr int TOT = WW * WW, K = (TOT + 63) / 64;
-    uint16_t v[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int p = lane + 64 * k, i = p / WW, j = p - i * WW;
-      int yy = wy + i, xx = wx + j;
-      yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-      xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-      v[k] = p < TOT ? (uint16_t)ref[(size_t)yy * P.stride_y + xx] : 0;
-    }
-    uint16_t sv[RPL];
-#pragma unroll
-    for (int k = 0; k < RPL; k++) {   // (source of an overhanging leaf: last row / column replicated)
-      const int p = lane + 64 * k;
-      int yy = y + (p >> LOG2N), xx = x + (p & (n - 1));
-      yy = yy > H - 1 ? H - 1 : yy; xx = xx > W - 1 ? W - 1 : xx;
-      sv[k] = (uint16_t)src[(size_t)yy * P.stride_y + xx];
-    }
-#pragma unroll
-    for (int k = 0; k < K; k++) { const int p = lane + 64 * k, i = p / WW, j = p - i * WW; if (p < TOT) win[i * WS + j] = v[k]; }
-#pragma unroll
-    for (int k = 0; k < RPL; k++) srcb[lane + 64 * k] = sv[k];
-  }
-  __syncthreads();
-  const int maxv = (1 << P.bit_depth) - 1;
+  refine_stage<PIX, LOG2N>(P, src, ref, x, y, wx, wy, win, srcb);
   long best_cost = 0;
   // step 8 = the integer winner itself, re-costed in SATD (phase 0: the filters copy); then half and quarter samples
   for (int step = 8; step >= 2; step >>= 1) {
@@ -230,92 +375,50 @@ __device__ __forceinline__ void refine_leaf(const Av1miDevParams &P, const PIX *
       if ((k == 4) != (step == 8)) continue;
       const int mr = base_row + (step == 8 ? 0 : (k / 3 - 1) * step), mc = base_col + (step == 8 ? 0 : (k % 3 - 1) * step);
       if (x * 8 + mc < -128 || (x + n) * 8 + mc > (W + 16) * 8 || y * 8 + mr < -128 || (y + n) * 8 + mr > (H + 16) * 8) continue;
-      const int px = (x << 4) + 2 * mc, py = (y << 4) + 2 * mr;
-      const int ix = (px >> 4) - 3 - wx, iy = (py >> 4) - 3 - wy, fx = px & 15, fy = py & 15;   // 0 <= ix, iy <= 1
-      int fh[8], fv[8];
-#pragma unroll
-      for (int t = 0; t < 8; t++) { fh[t] = c_subpel_me[0][fx][t]; fv[t] = c_subpel_me[0][fy][t]; }
-      // horizontal pass: task = (row r of mid, segment of 8 outputs)
-      constexpr int SEGS = n / 8, TASKS = (n + 7) * SEGS;
-      for (int task = lane; task < TASKS; task += 64) {
-        const int r = task / SEGS, sg = task - r * SEGS;
-        const uint4 *wp = reinterpret_cast<const uint4 *>(win + (iy + r) * WS + 8 * sg);
-        const uint4 q0 = wp[0], q1 = wp[1];
-        const uint32_t d[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
-        int a[16];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { a[2 * i] = (int)(d[i] & 0xFFFF); a[2 * i + 1] = (int)(d[i] >> 16); }
-        int o[8];
-        if (ix) {
-#pragma unroll
-          for (int j = 0; j < 8; j++) { int sum = 0;
-#pragma unroll
-            for (int t = 0; t < 8; t++) sum += fh[t] * a[1 + j + t];
-            o[j] = (sum + 4) >> 3; }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; j++) { int sum = 0;
-#pragma unroll
-            for (int t = 0; t < 8; t++) sum += fh[t] * a[j + t];
-            o[j] = (sum + 4) >> 3; }
-        }
-        uint4 w;
-        w.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); w.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
-        w.z = (uint32_t)(uint16_t)o[4] | ((uint32_t)(uint16_t)o[5] << 16); w.w = (uint32_t)(uint16_t)o[6] | ((uint32_t)(uint16_t)o[7] << 16);
-        *reinterpret_cast<uint4 *>(mid + r * n + 8 * sg) = w;
-      }
-      __syncthreads();
-      // vertical pass: lane = column c, rows r0 .. r0 + RPL - 1
-      int sad = 0;
-      {
-        const int c = lane & (n - 1), r0 = (lane >> LOG2N) * RPL;
-        int m[RPL + 7];
-#pragma unroll
-        for (int i = 0; i < RPL + 7; i++) m[i] = mid[(r0 + i) * n + c];
-#pragma unroll
-        for (int j = 0; j < RPL; j++) {
-          int sum = 0;
-#pragma unroll
-          for (int t = 0; t < 8; t++) sum += fv[t] * m[j + t];
-          int v = (sum + 1024) >> 11;
-          v = v < 0 ? 0 : (v > maxv ? maxv : v);
-          const int d = (int)srcb[(r0 + j) * n + c] - v;
-          sad += iabs(d);
-          dif[(r0 + j) * n + c] = (int16_t)d;
-        }
-      }
-      __syncthreads();
-      // SATD: 8x8 Hadamard of the difference, rows (8 values of a row of a sub-block per task, written back), then
-      // columns (absolute sum); n^2/64 sub-blocks x 8 tasks each
-      constexpr int NB = n / 8, HT = NB * NB * 8;
-      for (int task = lane; task < HT; task += 64) {
-        const int b = task >> 3, i = task & 7;
-        int16_t *rowp = dif + ((b / NB) * 8 + i) * n + (b % NB) * 8;
-        const uint4 q = *reinterpret_cast<const uint4 *>(rowp);
-        int v[8] = { (int16_t)(q.x & 0xFFFF), (int16_t)(q.x >> 16), (int16_t)(q.y & 0xFFFF), (int16_t)(q.y >> 16),
-                     (int16_t)(q.z & 0xFFFF), (int16_t)(q.z >> 16), (int16_t)(q.w & 0xFFFF), (int16_t)(q.w >> 16) };
-        hadamard8(v);
-        uint4 w;
-        w.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16); w.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
-        w.z = (uint32_t)(uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16); w.w = (uint32_t)(uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
-        *reinterpret_cast<uint4 *>(rowp) = w;
-      }
-      __syncthreads();
-      int satd = 0;
-      for (int task = lane; task < HT; task += 64) {
-        const int b = task >> 3, j = task & 7;
-        const int16_t *colp = dif + (b / NB) * 8 * n + (b % NB) * 8 + j;
-        int v[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = colp[i * n];
-        hadamard8(v);
-#pragma unroll
-        for (int i = 0; i < 8; i++) satd += iabs(v[i]);
-      }
-      for (int o = 32; o > 0; o >>= 1) { sad += __shfl_xor(sad, o, 64); satd += __shfl_xor(satd, o, 64); }
-      __syncthreads();
+      int sad, satd;
+      refine_eval<PIX, LOG2N>(P, x, y, wx, wy, mr, mc, win, mid, srcb, dif, sad, satd);
       const long cost = (long)(satd >> 3) + (((long)n * (iabs(mr) + iabs(mc))) >> 3);
       if (step == 8 || cost < best_cost) { best_cost = cost; best_sad = sad; best_row = mr; best_col = mc; }
+    }
+  }
+}
+
+// A 64x64 leaf (block_log2 = 6): SAD and SATD are sums over 8x8 sub-blocks, so the leaf is evaluated as its four 32x32 quadrants with
+// the same LDS tiles - per stage every quadrant is staged once (window around the leaf's integer winner) and gives its share
+// of every candidate of the stage; the decision is taken on the sums.  Same candidates, order and costs as the smaller leaves.
+template <typename PIX>
+__device__ __forceinline__ void refine_leaf64(const Av1miDevParams &P, const PIX *__restrict__ src, const PIX *__restrict__ ref, int x, int y,
+                                              int &best_row, int &best_col, int &best_sad, uint16_t *win, int16_t *mid, uint16_t *srcb, int16_t *dif) {
+  constexpr int n = 64;
+  const int W = P.width, H = P.height;
+  const int irow = best_row, icol = best_col;   // the integer winner: every quadrant's window sits around it
+  long best_cost = 0;
+  for (int step = 8; step >= 2; step >>= 1) {
+    const int base_row = best_row, base_col = best_col;
+    int sad_acc[9], satd_acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { sad_acc[k] = 0; satd_acc[k] = 0; }
+    for (int q = 0; q < 4; q++) {
+      const int qx = x + (q & 1) * 32, qy = y + (q >> 1) * 32;
+      const int wx = qx + (icol >> 3) - 4, wy = qy + (irow >> 3) - 4;
+      refine_stage<PIX, 5>(P, src, ref, qx, qy, wx, wy, win, srcb);
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        if ((k == 4) != (step == 8)) continue;
+        const int mr = base_row + (step == 8 ? 0 : (k / 3 - 1) * step), mc = base_col + (step == 8 ? 0 : (k % 3 - 1) * step);
+        if (x * 8 + mc < -128 || (x + n) * 8 + mc > (W + 16) * 8 || y * 8 + mr < -128 || (y + n) * 8 + mr > (H + 16) * 8) continue;
+        int sad, satd;
+        refine_eval<PIX, 5>(P, qx, qy, wx, wy, mr, mc, win, mid, srcb, dif, sad, satd);
+        sad_acc[k] += sad; satd_acc[k] += satd;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      if ((k == 4) != (step == 8)) continue;
+      const int mr = base_row + (step == 8 ? 0 : (k / 3 - 1) * step), mc = base_col + (step == 8 ? 0 : (k % 3 - 1) * step);
+      if (x * 8 + mc < -128 || (x + n) * 8 + mc > (W + 16) * 8 || y * 8 + mr < -128 || (y + n) * 8 + mr > (H + 16) * 8) continue;
+      const long cost = (long)(satd_acc[k] >> 3) + (((long)n * (iabs(mr) + iabs(mc))) >> 3);
+      if (step == 8 || cost < best_cost) { best_cost = cost; best_sad = sad_acc[k]; best_row = mr; best_col = mc; }
     }
   }
 }
@@ -334,8 +437,18 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
   const int NC = 2 * R + 1;
   // this wave's cell of the largest block size: one leaf inside the frame, a few smaller ones where it straddles the edge
   const int u = 1 << (cell_log2 - 3);
+  if (cell_log2 == 6 && cell_in_leaf64(P, blockIdx.x * 64, blockIdx.y * 64)) {   // this wave's cell is one 64x64 leaf
+    const size_t slot = (size_t)f * P.b8_rows * P.b8_cols + (size_t)(blockIdx.y * 8) * P.b8_cols + blockIdx.x * 8;
+    const int cand = (int)(in_all[slot] & 0xFFFF);
+    int best_row = (cand / NC - R) * 8, best_col = (cand % NC - R) * 8, best_sad = 0;
+    refine_leaf64<PIX>(P, src, ref, blockIdx.x * 64, blockIdx.y * 64, best_row, best_col, best_sad, win, mid, srcb, dif);
+    if (threadIdx.x == 0)
+      out_all[slot] = ((unsigned long long)(uint32_t)best_sad << 36) | ((unsigned long long)(uint16_t)(int16_t)best_row << 16) | (uint16_t)(int16_t)best_col;
+    return;
+  }
   for (int uy = blockIdx.y * u; uy < (int)(blockIdx.y + 1) * u; uy++)
     for (int ux = blockIdx.x * u; ux < (int)(blockIdx.x + 1) * u; ux++) {
+      if (ux * 8 >= P.width || uy * 8 >= P.height) continue;
       const int bsl = leaf_bsl_cell(P, (ux >> 2) * 32, (uy >> 2) * 32, ux & 3, uy & 3);
       if (!bsl) continue;
       const size_t slot = (size_t)f * P.b8_rows * P.b8_cols + (size_t)uy * P.b8_cols + ux;
@@ -361,7 +474,7 @@ extern "C" hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const 
                                                  unsigned long long *refined, int me_range, int frame0, int count, hipStream_t stream) {
   // one wave per cell of the largest block size (every wave has work, and consecutive workgroups - which the dispatcher deals
   // round-robin to the 8 XCDs - are all active: a wave per 8x8 unit left 6 of 8 XCDs without a single leaf)
-  const int g = P->max_bs_log2 > 5 ? 5 : P->max_bs_log2, cell = 1 << g;
+  const int g = P->max_bs_log2 > 6 ? 6 : P->max_bs_log2, cell = 1 << g;
   dim3 grid((P->width + cell - 1) / cell, (P->height + cell - 1) / cell, count);
   if (P->bit_depth == 8) hipLaunchKernelGGL((subpel_refine_kernel<uint8_t>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, refined, frame0, me_range, g);
   else hipLaunchKernelGGL((subpel_refine_kernel<uint16_t>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, refined, frame0, me_range, g);
@@ -372,16 +485,19 @@ extern "C" hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const 
 // (P->n_frames of them); every inter frame is searched against the source frame before it.  R must be 8 or 16.
 // Searches frames [frame0, frame0 + count) of the chunk.
 extern "C" hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range,
-                                                 int frame0, int count, hipStream_t stream) {
+                                                 int frame0, int count, uint32_t *acc64 /* block_log2 = 6: zeroed [frame][superblock][candidate] table, else null */,
+                                                 hipStream_t stream) {
   const int cells = ((P->width + 31) >> 5) * ((P->height + 31) >> 5);
   dim3 grid(cells, 2 * me_range + 1, count);
   const int vec_ok = ((uintptr_t)frames & 15) == 0;  // frame size in bytes is a multiple of 32
   if (P->bit_depth == 8) {
-    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint8_t, 8>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok);
-    else hipLaunchKernelGGL((motion_search_kernel<uint8_t, 16>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok);
+    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint8_t, 8>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok, acc64);
+    else hipLaunchKernelGGL((motion_search_kernel<uint8_t, 16>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok, acc64);
   } else {
-    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint16_t, 8>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok);
-    else hipLaunchKernelGGL((motion_search_kernel<uint16_t, 16>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok);
+    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint16_t, 8>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok, acc64);
+    else hipLaunchKernelGGL((motion_search_kernel<uint16_t, 16>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok, acc64);
   }
+  if (P->max_bs_log2 >= 6)
+    hipLaunchKernelGGL(me64_reduce_kernel, dim3(P->sb_rows * P->sb_cols, count), dim3(64), 0, stream, *P, acc64, best, frame0, me_range);
   return hipGetLastError();
 }

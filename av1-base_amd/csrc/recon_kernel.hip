@@ -20,6 +20,13 @@
 #include <type_traits>
 #include "av1mi_dev.h"
 #include "av1_tables.h"
+// This file is compiled twice: as is (leaf blocks up to 32x32: the kernels keep their 10 KB of LDS and 4 waves per SIMD), and
+// through recon64_kernel.hip with AV1MI_RECON_BIG = 1 (block_log2 = 6: 64x64 luma blocks with the 64-point transform, 32x32
+// chroma; 64x64 tiles of LDS per wave and the 64-point networks' registers, so 2 waves per SIMD).
+#ifndef AV1MI_RECON_BIG
+#define AV1MI_RECON_BIG 0
+#endif
+#define MAXN (AV1MI_RECON_BIG ? 64 : 32)   /* largest transform block side */
 #define AV1_TXFM_FN static __device__ __forceinline__
 // Round2(w0 * a + w1 * b, 12) of the butterfly rotations with 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24: full rate; the
 // generic form's two 64-bit multiply-adds run at a quarter of it and were 474 of a 32x32 block's 7.6 k instructions).  Exact
@@ -74,9 +81,9 @@ template <> struct LinesSel<1> { static __device__ __forceinline__ LineLds<1> &g
 template <> struct LinesSel<2> { static __device__ __forceinline__ LineLds<2> &get() { return g_lines2; } };
 #define LN (LinesSel<TSB>::get())
 struct SbLds {
-  uint16_t blkpix[32 * 32];     // prediction, then reconstruction, of the current transform block
-  uint16_t srcblk[32 * 32];     // source pixels of the block; reused for the quantised levels
-  int16_t scratch[32 * 33];     // 2-D transform staging (every intermediate fits 16 bits)
+  uint16_t blkpix[MAXN * MAXN];     // prediction, then reconstruction, of the current transform block
+  uint16_t srcblk[MAXN * MAXN];     // source pixels of the block; reused for the quantised levels
+  int16_t scratch[MAXN * (MAXN + 1)];     // 2-D transform staging (every intermediate fits 16 bits)
   uint16_t edge_a[2 * 64 + 8];  // [0] = element -1
   uint16_t edge_l[2 * 64 + 8];
   uint8_t blkdec[2][19][19];    // luma, chroma (U and V decode together)
@@ -111,8 +118,8 @@ __device__ __forceinline__ void stamp_phase(int cls, int phase) {
 #endif
 // motion compensation at sub-sample positions (inter instantiations only): reference window and horizontal-pass output
 struct McLds {
-  uint16_t win[39 * 39 + 7];
-  int16_t mid[39 * 32];
+  uint16_t win[(MAXN + 7) * (MAXN + 7) + 7];
+  int16_t mid[(MAXN + 7) * MAXN];
 };
 __shared__ McLds g_mc;
 __constant__ int16_t c_subpel[2][16][8] = AV1_SUBPEL_FILTERS_INIT;  // EIGHTTAP, and its 4-tap form for 4-sample blocks
@@ -166,6 +173,12 @@ template <> struct Tx1d<5> {
   static __device__ __forceinline__ void fwd(int32_t *x, int) { av1_fdct32(x); }
   static __device__ __forceinline__ void inv(int32_t *x, int) { av1_idct32(x); }
 };
+#if AV1MI_RECON_BIG
+template <> struct Tx1d<6> {
+  static __device__ __forceinline__ void fwd(int32_t *x, int) { av1_fdct64(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int) { av1_idct64(x); }
+};
+#endif
 
 // position of (row, col) in the default zig-zag scan of an n x n block:
 // odd anti-diagonals run with increasing row, even ones with increasing column.
@@ -271,8 +284,8 @@ template <typename PIX, int LOG2N, int NPL>
 __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int last_x, int last_y, int px0, int py0, int maxv,
                                               int grp, int sl, uint16_t *dst) {
   constexpr int N = 1 << LOG2N, WN = N + 7, G = 64 / NPL;
-  uint16_t *win = g_mc.win + grp * (NPL == 1 ? 0 : 23 * 23 + 3);
-  int16_t *mid = g_mc.mid + grp * (NPL == 1 ? 0 : 23 * 16);
+  uint16_t *win = g_mc.win + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 39 + 3 : 23 * 23 + 3));
+  int16_t *mid = g_mc.mid + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 32 : 23 * 16));
   const int ix0 = (px0 >> 4) - 3, iy0 = (py0 >> 4) - 3;
   const int16_t *fh = c_subpel[N <= 4][px0 & 15], *fv = c_subpel[N <= 4][py0 & 15];
   {  // all loads of the window in flight together (a loop of dependent load -> LDS store pairs paid the latency 24 times)
@@ -344,8 +357,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   constexpr int N = 1 << LOG2N;
   constexpr int ST = N + 1;
   constexpr int G = 64 / NPL;              // lanes per group
-  constexpr int PIXO = NPL == 1 ? 0 : 512; // per-group offset inside srcblk / blkpix (N*N <= 256 when NPL == 2)
-  constexpr int SCRO = NPL == 1 ? 0 : 16 * 17;
+  constexpr int PIXO = NPL == 1 ? 0 : (N > 16 ? 1024 : 512); // per-group offset inside srcblk / blkpix (NPL == 2: N <= 16, or 32 in the 64x64 build)
+  constexpr int SCRO = NPL == 1 ? 0 : (N > 16 ? 32 * 33 : 16 * 17);
   constexpr int EDGO = NPL == 1 ? 0 : 68;
   const Av1miDevParams *P = cx.P;
   const int lane = cx.lane;
@@ -546,17 +559,20 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
   const int txt = (LOG2N <= 4 && !(INTER && ii.is_inter)) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
   const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
-  constexpr int SH0 = 2, SH1 = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : (LOG2N == 4 ? 2 : 4));
+  // 64-point transforms (64x64 build): only the 32x32 low-frequency corner is coded (CW = 32) - the column pass keeps its first
+  // 32 outputs, the row pass runs on 32 lanes and keeps 32, the inverse passes take 32 inputs (zeros beyond) and give 64 outputs
+  constexpr int CW = N > 32 ? 32 : N;
+  constexpr int SH0 = LOG2N == 6 ? 0 : 2, SH1 = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : (LOG2N == 4 ? 2 : (LOG2N == 5 ? 4 : 2))), SH2 = LOG2N == 6 ? 2 : 0;
   constexpr int RS = LOG2N == 2 ? 0 : (LOG2N == 3 ? 1 : 2);
-  constexpr int TSH = LOG2N == 5 ? 1 : 0;  // dequant shift of the size class (§7.12.3)
+  constexpr int TSH = LOG2N == 6 ? 2 : (LOG2N == 5 ? 1 : 0);  // dequant shift of the size class (§7.12.3)
   int32_t x[N];
-  const bool tx_lane = sl < N;
+  const bool tx_lane = sl < N, row_lane = sl < CW;
   if (tx_lane) {
 #pragma unroll
     for (int i = 0; i < N; i++) x[i] = (int)S->scratch[so + i * ST + sl] << SH0;
     Tx1d<LOG2N>::fwd(x, vt);
 #pragma unroll
-    for (int i = 0; i < N; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
+    for (int i = 0; i < CW; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
   }
   __syncthreads();
   STAMP(3);   // forward columns
@@ -565,7 +581,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // dead-zone quantiser + normative dequantiser (§7.12.3) of this lane's coefficient row.  QM: the step of every position
   // comes from the context's quantiser-matrix table {Round2(q * Quantizer_Matrix, 5), ceil(2^32 / that)}; the matrices are
   // symmetric, so lanes read entry [j][row] (consecutive addresses across the wave).
-  if (tx_lane) {
+  if (row_lane) {
 #pragma unroll
     for (int j = 0; j < N; j++) x[j] = S->scratch[so + sl * ST + j];
     Tx1d<LOG2N>::fwd(x, ht);
@@ -573,24 +589,24 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
     const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row : nullptr;
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-      const int v = x[j];
+    for (int j = 0; j < CW; j++) {
+      const int v = rshift_round(x[j], SH2);
       uint32_t q, recip;
       if constexpr (QM) {
-        const Av1miQmEntry e = tab[j * N];
+        const Av1miQmEntry e = tab[j * CW];
         q = e.q; recip = e.recip;
       } else {
         const bool dc = (row | j) == 0;
         q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
         recip = dc ? P->dc_recip : P->ac_recip;
       }
-      // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above
+      // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above (n = the coded width)
       const int d0 = row + j;
-      const uint32_t rnd = d0 < (N >> 2) ? (3 * q) >> 3 : (d0 < (N >> 1) ? (q >> 2) : (q >> 3));
+      const uint32_t rnd = d0 < (CW >> 2) ? (3 * q) >> 3 : (d0 < (CW >> 1) ? (q >> 2) : (q >> 3));
       const uint32_t a = ((uint32_t)iabs(v) << TSH) + rnd;
       uint32_t lv = __umulhi(a, recip);
       if (lv > 0x7FFF) lv = 0x7FFF;
-      lvl[row * N + j] = (int16_t)(v < 0 ? -(int)lv : (int)lv);
+      lvl[row * CW + j] = (int16_t)(v < 0 ? -(int)lv : (int)lv);
       int d = 0;
       if (lv) {
         // scan order: by anti-diagonal, odd ones by increasing row, even ones by increasing column
@@ -603,14 +619,16 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       }
       x[j] = d;
     }
+#pragma unroll
+    for (int j = CW; j < N; j++) x[j] = 0;
   }
   for (int o = G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(my_key, o, 64); my_key = t > my_key ? t : my_key; }
   int eob = 0;
   if (my_key >= 0) {
     const int d0 = my_key >> 6, w = my_key & 63;
-    eob = scan_index((d0 & 1) ? w : d0 - w, (d0 & 1) ? d0 - w : w, N) + 1;
+    eob = scan_index((d0 & 1) ? w : d0 - w, (d0 & 1) ? d0 - w : w, CW) + 1;
   }
-  if (tx_lane && eob) {
+  if (row_lane && eob) {
     Tx1d<LOG2N>::inv(x, ht);
 #pragma unroll
     for (int j = 0; j < N; j++) S->scratch[so + sl * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
@@ -620,7 +638,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   if (tx_lane && eob) {
     const int maxv = (1 << bd) - 1;
 #pragma unroll
-    for (int i = 0; i < N; i++) x[i] = S->scratch[so + i * ST + sl];
+    for (int i = 0; i < N; i++) x[i] = i < CW ? (int)S->scratch[so + i * ST + sl] : 0;
     Tx1d<LOG2N>::inv(x, vt);
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -629,7 +647,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
   }
   if (eob) {  // levels out (32-bit words, coalesced inside the group)
-    constexpr int WORDS = N * N / 2;
+    constexpr int WORDS = CW * CW / 2;
     uint32_t *d32 = reinterpret_cast<uint32_t *>(grp ? lv_out1 : lv_out0);
     for (int i = sl; i < WORDS; i += G) d32[i] = (uint32_t)(uint16_t)lvl[2 * i] | ((uint32_t)(uint16_t)lvl[2 * i + 1] << 16);
   }
@@ -719,6 +737,9 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     // luma (mode decision inside), then U and V together
     int dec;
     switch (bsl) {
+#if AV1MI_RECON_BIG
+      case 6: dec = tx_item<PIX, 6, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+#endif
       case 5: dec = tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
       case 4: dec = tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
       default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
@@ -726,6 +747,9 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     dec = uniform_i(dec);
     mode = dec & 0xFF; ii.is_inter = dec >> 8;   // the luma pass decides; the chroma pass follows it
     switch (bsl) {
+#if AV1MI_RECON_BIG
+      case 6: tx_item<PIX, 5, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+#endif
       case 5: tx_item<PIX, 4, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
       case 4: tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
       default: tx_item<PIX, 2, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
@@ -747,7 +771,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
 }
 
 template <typename PIX, bool INTER, int TSB, bool QM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : 4, AV1MI_RECON_BIG ? 2 : 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
                                                      const unsigned long long *__restrict__ me_best) {
@@ -817,7 +841,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // that does depend on neighbours - the intra SAD of the decision and the blocks intra prediction wins.
 // (As one kernel a P frame was 510 waves of six serial block passes: 290 us of latency on the chunk's serial chain.)
 template <typename PIX, bool QM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) recon_inter_pre_kernel(const Av1miDevParams *__restrict__ Pd,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : 4, AV1MI_RECON_BIG ? 2 : 4))) recon_inter_pre_kernel(const Av1miDevParams *__restrict__ Pd,
                                                      const PIX *__restrict__ src, PIX *__restrict__ rec, int16_t *__restrict__ levels,
                                                      Av1miBlkInfo *__restrict__ blk, const PIX *__restrict__ ref,
                                                      const unsigned long long *__restrict__ me_best, int cell_log2) {
@@ -856,6 +880,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       Av1miBlkInfo *bi = &blk[(size_t)uy * P.b8_cols + ux];
       if (blockIdx.z == 0) {
         switch (bsl) {
+#if AV1MI_RECON_BIG
+          case 6: tx_item<PIX, 6, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+#endif
           case 5: tx_item<PIX, 5, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
           case 4: tx_item<PIX, 4, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
           default: tx_item<PIX, 3, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
@@ -863,6 +890,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         if (threadIdx.x == 0) bi->eob[0] = (uint16_t)S->eobs[0];
       } else {
         switch (bsl) {
+#if AV1MI_RECON_BIG
+          case 6: tx_item<PIX, 5, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+#endif
           case 5: tx_item<PIX, 4, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
           case 4: tx_item<PIX, 3, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
           default: tx_item<PIX, 2, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
@@ -875,7 +905,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 }  // namespace
 
-#ifdef AV1MI_STAMPS
+#if defined(AV1MI_STAMPS) && !AV1MI_RECON_BIG
 // diagnostic build: read (and clear) the phase sums.  out[class * 8 + phase] cycles, then total wave cycles, then waves
 extern "C" int av1mi_debug_stamps(unsigned long long *out, int reset) {
   unsigned long long z[STAMP_CLASSES * STAMP_PHASES + 3] = {};
@@ -888,12 +918,17 @@ extern "C" int av1mi_debug_stamps(unsigned long long *out, int reset) {
 // ref == nullptr: P->n_frames key frames in one launch.  ref != nullptr: ONE inter frame (P->n_frames must be 1),
 // predicted from `ref` with the motion search results `me_best` of that frame.
 // dP: the same parameters in device memory (what the kernel reads; n_frames and the loop-filter levels are not used by it).
-extern "C" hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels,
+#if AV1MI_RECON_BIG
+#define AV1MI_LAUNCH_RECON av1mi_launch_recon64   /* leaf blocks up to 64x64 (P->max_bs_log2 == 6) */
+#else
+#define AV1MI_LAUNCH_RECON av1mi_launch_recon     /* leaf blocks up to 32x32 */
+#endif
+extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels,
                                          Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, hipStream_t stream) {
   const int grid = P->n_frames * P->tile_rows * P->tile_cols;
   const bool inter = ref != nullptr;
   if (inter) {  // first launch of an inter frame: every block as an inter block, all at once (see recon_inter_pre_kernel)
-    const int g = P->max_bs_log2 > 5 ? 5 : P->max_bs_log2, cell = 1 << g;
+    const int g = P->max_bs_log2 > (AV1MI_RECON_BIG ? 6 : 5) ? (AV1MI_RECON_BIG ? 6 : 5) : P->max_bs_log2, cell = 1 << g;
     dim3 pgrid((P->width + cell - 1) / cell, (P->height + cell - 1) / cell, 2);   // z: luma | chroma
 #define PRE_LAUNCH(PIXT)                                                                                                                     \
     do {                                                                                                                                     \

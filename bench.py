@@ -497,6 +497,7 @@ def extra_configs(base):
     prod = dict(keyint=240, cq=8, qm=True, film_grain=20, subpel=True, deblock=True, sgr=True)
     return [
         mk("cfg2_1080p_intra_all13", mode_mask=0x1FFF),
+        mk("cfg2_1080p_intra_64x64", block_log2=6),
         mk("cfg3_1080p_ippp", keyint=240),
         mk("cfg3_1080p_ippp_x4", keyint=240, chunks_per_gpu=4),
         mk("cfg4_4k_ippp_chunk", width=3840, height=2160, frames=30, keyint=240, seed=2160),

@@ -47,7 +47,8 @@ typedef struct {
   uint32_t keyint;          /* "--keyint": 1 = every frame a key frame; N > 1 = a key frame every N frames of a chunk, the
                                frames between are INTER frames predicted from the previous reconstruction (one
                                reference, integer-pel full search; chunks always start with a key frame) */
-  uint32_t block_log2;      /* leaf block size log2: 3 (8x8) .. 5 (32x32); 0 = default (5) */
+  uint32_t block_log2;      /* leaf block size log2: 3 (8x8) .. 6 (64x64: 64-point luma transforms, of which AV1 codes the 32x32
+                               low-frequency corner); 0 = default (5) */
   uint32_t cdf_update;      /* 1 = adaptive CDFs (default), 0 = static CDFs (disable_cdf_update) */
   uint32_t enable_cdef;     /* 1 = CDEF on (default) */
   uint32_t cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping; /* 0s = defaults */

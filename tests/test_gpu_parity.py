@@ -38,7 +38,7 @@ def test_extension_is_the_hip_library(av1mi):
 
 
 def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
-    """Every fixture the GPU path can express (one-superblock tiles, 8..32 blocks, decision-driven
+    """Every fixture the GPU path can express (one-superblock tiles, 8..64 blocks, decision-driven
     modes): same bytes as the committed stream, reconstruction hash == dav1d's."""
     n = 0
     for m in golden_cases:
@@ -48,7 +48,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         qidx = cfgk.get("base_q_idx", 120)
         # what the C ABI cannot express stays with the oracle tests: fuzzed levels / modes, a film-grain seed other than the ABI's
         # rule, tile layouts other than 1x1 / 2x2 superblocks, quantiser indices no CQ level maps to
-        if bs > 5 or any(k.startswith("fuzz") for k in cfgk) or (cfgk.get("film_grain") and cfgk.get("fg_seed") != 7391) or cfgk.get("tile_w_sb", 1) != 1 or qidx % 4 or qidx > 244:
+        if any(k.startswith("fuzz") for k in cfgk) or (cfgk.get("film_grain") and cfgk.get("fg_seed") != 7391) or cfgk.get("tile_w_sb", 1) != 1 or qidx % 4 or qidx > 244:
             continue
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, cq_level=qidx // 4,
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_cdef=cfgk.get("enable_cdef", 1))
@@ -79,7 +79,10 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
     (328, 248, 10, 2, 5, 1), (136, 136, 8, 3, 4, 1), (640, 360, 8, 2, 5, 1),
     # widths whose remainder modulo 64 mixes block sizes side by side (24 = 16 + 8, 40, 48, 56): regression for the
     # level-buffer layout, which let horizontally adjacent blocks of different sizes overlap
-    (216, 72, 8, 1, 5, 1), (232, 120, 10, 2, 5, 1), (248, 88, 8, 1, 4, 1), (120, 184, 8, 2, 5, 0)])
+    (216, 72, 8, 1, 5, 1), (232, 120, 10, 2, 5, 1), (248, 88, 8, 1, 4, 1), (120, 184, 8, 2, 5, 0),
+    # 64x64 leaf blocks (64-point luma transforms, 32x32 chroma): whole superblocks, edge superblocks that split to smaller
+    # leaves, leaves that overhang the frame (remainders 40..56), static CDFs
+    (64, 64, 8, 1, 6, 1), (200, 120, 8, 2, 6, 1), (184, 176, 10, 2, 6, 1), (328, 248, 10, 2, 6, 0), (648, 360, 8, 2, 6, 1)])
 def test_chunk_bitstream_and_recon_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, cdf):
     frames = [oracle.synthclip_frame(w, h, bd, seed=1000 + w, t=t, scene_len=2) for t in range(n)]
     p = av1mi.default_params(w, h, bd, block_log2=bs, cdf_update=cdf)
@@ -270,7 +273,9 @@ def oracle_chunk(oracle, cfg, frames, keyint):
 
 @pytest.mark.parametrize("w,h,bd,n,bs,keyint,me,cdf", [
     (64, 64, 8, 3, 5, 8, 8, 1), (200, 120, 8, 5, 5, 4, 8, 1), (200, 120, 10, 4, 4, 240, 8, 1), (136, 136, 8, 3, 3, 3, 8, 1),
-    (328, 248, 10, 3, 5, 240, 16, 1), (72, 56, 8, 4, 4, 2, 16, 0), (648, 360, 8, 3, 5, 240, 8, 1)])
+    (328, 248, 10, 3, 5, 240, 16, 1), (72, 56, 8, 4, 4, 2, 16, 0), (648, 360, 8, 3, 5, 240, 8, 1),
+    # 64x64 leaves: the search sums four 32x32 cells per candidate, motion compensation and the candidate list at 64x64
+    (200, 120, 8, 4, 6, 240, 8, 1), (328, 248, 10, 3, 6, 240, 16, 1), (184, 248, 8, 3, 6, 2, 8, 0), (648, 360, 10, 3, 6, 240, 8, 1)])
 def test_inter_chunk_bitstream_and_recon_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, me, cdf):
     """keyint > 1: P frames (motion search, motion compensation, inter syntax incl. the motion-vector candidate
     list) - every temporal unit and every reconstructed frame bit-exact against the oracle."""
@@ -317,7 +322,7 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
     for m in golden_sequences:
         cfgk = dict(m["config"])
         bs = cfgk.get("min_bs_log2", 4)
-        if any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("film_grain") or bs > 5:
+        if any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("film_grain"):
             continue
         if m["width"] % 8 or m["height"] % 8:
             continue   # (covered by test_sizes_that_are_not_multiples_of_8: fixtures here are generated full-size)
@@ -369,7 +374,8 @@ def test_quantiser_matrices_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, cq
 
 @pytest.mark.parametrize("w,h,bd,n,bs,me,extra", [
     (64, 64, 8, 3, 5, 8, dict()), (200, 120, 8, 4, 5, 8, dict()), (200, 120, 10, 3, 4, 8, dict(deblock=1)), (136, 136, 8, 3, 3, 8, dict()),
-    (328, 248, 10, 3, 5, 16, dict(enable_lr=1)), (130, 66, 8, 3, 4, 8, dict()), (648, 360, 10, 3, 5, 8, dict(enable_qm=1, qm_min=4, qm_max=4))])
+    (328, 248, 10, 3, 5, 16, dict(enable_lr=1)), (130, 66, 8, 3, 4, 8, dict()), (648, 360, 10, 3, 5, 8, dict(enable_qm=1, qm_min=4, qm_max=4)),
+    (200, 120, 8, 3, 6, 8, dict()), (184, 248, 10, 3, 6, 16, dict(deblock=1, enable_lr=2)), (648, 360, 8, 3, 6, 8, dict(enable_qm=1, qm_min=2, qm_max=2))])
 def test_subsample_motion_vectors_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, me, extra):
     """subpel = 1: half- then quarter-sample refinement of the full search (EIGHTTAP-interpolated previous source),
     8-tap motion compensation of luma and chroma, fractional vectors in the candidate list and the NEWMV syntax,
@@ -425,6 +431,20 @@ def test_1080p_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle, extra):
     fb = w * h * 3
     for i, rec in enumerate(recs):
         assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
+
+
+def test_1080p_64x64_blocks_equal_oracle(av1mi, ctx, oracle):
+    """block_log2 = 6 at BASELINE's 1080p size: 64x64 leaves with the 64-point transform in 16 superblock rows, the bottom row
+    (56 samples) as 64x64 leaves that overhang the frame by 8 - key frame and P frame with sub-sample motion, bit-exact."""
+    w, h, bd, n = 1920, 1080, 10, 2
+    frames = [oracle.synthclip_frame(w, h, bd, seed=1081, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, keyint=240, block_log2=6, subpel=1)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=6, max_bs_log2=6, subpel=1)
+    tus, recs = oracle_chunk(oracle, cfg, frames, 240)
+    assert list(sizes) == [len(t) for t in tus]
+    assert data == b"".join(tus)
+    assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
 
 
 def test_4k_key_and_inter_frame_equal_oracle(av1mi, ctx, oracle):
@@ -650,7 +670,7 @@ def test_switchable_restoration_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, b
 
 
 @pytest.mark.parametrize("w,h,bd,n,bs,keyint,lr", [(328, 248, 8, 2, 4, 1, 0), (200, 120, 10, 3, 5, 240, 0), (264, 200, 8, 3, 3, 2, 1),
-                                                  (648, 360, 10, 2, 5, 2, 1), (136, 136, 8, 2, 5, 1, 0)])
+                                                  (648, 360, 10, 2, 5, 2, 1), (136, 136, 8, 2, 5, 1, 0), (312, 248, 8, 3, 6, 2, 0)])
 def test_tiles_of_two_by_two_superblocks_equal_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, lr):
     """tile_sb = 2 (what frames beyond 64 superblock rows/columns, i.e. 8K, need): intra edges, entropy contexts, CDF
     adaptation, motion-vector candidates and the restoration reference all run across the four superblocks of a
@@ -734,6 +754,8 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
         qmax = int(rng2.integers(qmin, 16))
         if lr and rng2.integers(0, 2):
             lr = 2   # RESTORE_SWITCHABLE
+        if rng2.integers(0, 2) and bs == 5:
+            bs = 6   # 64x64 leaves
         big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=3000 + it, t=t) for t in range(n)]
         frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
         p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
