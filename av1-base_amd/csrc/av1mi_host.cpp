@@ -42,7 +42,8 @@ hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_ini
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
                                 const uint8_t *lr_choice, uint32_t *tile_order, int frame0, int count,
                                 hipStream_t s, hipEvent_t mid);
-hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t s);
+hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, const uint16_t *dirtab, hipStream_t s);
+hipError_t av1mi_launch_cdef_dir(const Av1miDevParams *P, const void *rec, const Av1miBlkInfo *blk, uint16_t *dirtab, hipStream_t s);
 hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
 hipError_t av1mi_launch_pack(const Av1miDevParams *P, const uint8_t *slots, const uint32_t *tile_bytes, uint32_t *tile_off,
                              uint32_t *frame_size, uint32_t *payload_size, unsigned long long *frame_off, const uint8_t *hdr_blob,
@@ -403,6 +404,7 @@ struct av1mi_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // CDEF + SSE run here, beside the entropy kernels on `stream`
   hipStream_t stream3 = nullptr;  // inter chunks: entropy coding of finished groups of frames, beside the frame-by-frame chain
+  hipStream_t stream4 = nullptr;  // all-key-frame chunks pipelined over groups: the groups' entropy coding alternates between stream3 and this one
   hipEvent_t ev[12] = {};
   std::vector<hipEvent_t> me_ev;       // per frame: its motion search has finished (second stream -> main stream)
   std::vector<hipEvent_t> grp_ev;      // per group of frames of an inter chunk: reconstructed (main stream -> third stream)
@@ -426,6 +428,7 @@ struct av1mi_ctx {
   void *d_stage = nullptr;             // sizes that are not multiples of 8: frames in the caller's tight layout (input / reconstruction out)
   void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
   unsigned long long *d_me_sub = nullptr;  // sub-sample refinement: refined [frame][8x8 unit] keys (me_kernel.hip)
+  uint16_t *d_cdefdir = nullptr;           // chunk-wide CDEF: {adjusted luma primary strength << 3 | direction} per 8x8 block (cdef_dir_kernel)
   uint32_t *d_me64 = nullptr;              // 64x64 leaves: the search's [frame][superblock][candidate] SAD table
   size_t me64_bytes = 0;
   Av1miQmEntry *d_qm = nullptr;        // quantiser-matrix steps (Av1miDevParams::qm_tab), valid for qm_key = (level, qidx, bit depth)
@@ -462,11 +465,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params, c->d_me64 };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params, c->d_me64, c->d_cdefdir };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr; c->d_me64 = nullptr; c->me64_bytes = 0;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr; c->d_me64 = nullptr; c->me64_bytes = 0; c->d_cdefdir = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -519,6 +522,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     HIPCHK(c, hipMalloc((void **)&c->d_sse, nf * 3 * 8));
     HIPCHK(c, hipMalloc((void **)&c->d_overflow, 4));
     HIPCHK(c, hipMalloc((void **)&c->d_me, nf * nb8 * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_cdefdir, nf * nsb * 64 * sizeof(uint16_t)));
     c->cap_frames = n_frames;
     c->ws_scale = c->cap_scale;
   }
@@ -530,7 +534,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     const size_t nc = 2 * (size_t)(p.me_range ? p.me_range : 8) + 1, need = c->cap_frames * nsb * nc * nc * sizeof(uint32_t);
     if (c->me64_bytes < need) {
       if (c->d_me64) (void)hipFree(c->d_me64);
-      c->d_me64 = nullptr; c->me64_bytes = 0;
+      c->d_me64 = nullptr; c->me64_bytes = 0; c->d_cdefdir = nullptr;
       HIPCHK(c, hipMalloc((void **)&c->d_me64, need));
       c->me64_bytes = need;
     }
@@ -659,7 +663,8 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   }
   if (!aux_ok || hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       (!c->stream2 && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess) ||
-      (!c->stream3 && hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo) != hipSuccess)) {
+      (!c->stream3 && hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo) != hipSuccess) ||
+      hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -681,6 +686,7 @@ void av1mi_ctx_destroy(av1mi_ctx *c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  if (c->stream4) (void)hipStreamDestroy(c->stream4);
   delete c;
 }
 
@@ -829,13 +835,48 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   uint32_t entropy_from = 0;      // inter chunks: frames before this one are entropy-coded on the third stream, beside the chain
   bool entropy_joined = false;
   void *cdef_out = lr ? c->d_cd : c->d_fin;   // with loop restoration CDEF writes d_cd and the restored frame goes to d_fin
-  if (!inter_chunk) {
+  if (!inter_chunk && lr) {
+    // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
     HIPCHK(c, launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
-    if (lr) {  // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
-      if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
-      HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, s));
-      HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, c->d_lrsse, s));
+    if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
+    HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, nullptr, s));
+    HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, c->d_lrsse, s));
+  } else if (!inter_chunk) {
+    // All-key-frame chunk: the frames are independent, so the chunk CAN run as a software pipeline over groups of frames
+    // (AV1MI_INTRA_GROUPS=k) - the main stream reconstructs group g + 1 while auxiliary streams symbolize and range-code group
+    // g.  Measured (1080p x 60, MI355X): 14.1 k frames/s as one group, 12.3 k as two, 10.7 k as three - the range coder holds
+    // 145 KB of LDS on every CU it sits on, which leaves the reconstruction (10 KB per wave) one wave there instead of sixteen.
+    // The default is therefore one group; the knob stays for the day the range coder's per-tile state leaves LDS.
+    uint32_t groups = 1;
+    if (const char *eg = getenv("AV1MI_INTRA_GROUPS")) { const int k = atoi(eg); if (k >= 1) groups = (uint32_t)k; }
+    if (groups > n_frames) groups = n_frames;
+    const uint32_t grp = (n_frames + groups - 1) / groups;
+    const size_t fbytes = (size_t)P.frame_samples * bps, nb8 = (size_t)P.b8_rows * P.b8_cols, nsb = (size_t)P.sb_rows * P.sb_cols;
+    uint32_t n_grp = 0;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += grp) {
+      const uint32_t cnt = f0 + grp < n_frames ? grp : n_frames - f0;
+      Av1miDevParams Pg = P;
+      Pg.n_frames = (int)cnt;
+      HIPCHK(c, launch_recon(&Pg, c->d_params, (const uint8_t *)d_src + f0 * fbytes, (uint8_t *)c->d_rec + f0 * fbytes,
+                             c->d_levels + f0 * nsb * AV1MI_SB_LEVELS, c->d_blk + f0 * nb8, nullptr, nullptr, s));
+      if (f0 + cnt < n_frames) {
+        if (c->grp_ev.size() <= n_grp) {
+          hipEvent_t e;
+          HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          c->grp_ev.push_back(e);
+        }
+        hipStream_t sg = (n_grp & 1) ? c->stream4 : c->stream3;   // alternate: group g's range coder runs beside group g + 1's symbolize
+        HIPCHK(c, hipEventRecord(c->grp_ev[n_grp], s));
+        HIPCHK(c, hipStreamWaitEvent(sg, c->grp_ev[n_grp], 0));
+        HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
+                                       c->d_tile_off, (int)f0, (int)cnt, sg, nullptr));
+        n_grp++;
+        entropy_from = f0 + cnt;
+      }
     }
+    if (n_grp) HIPCHK(c, hipEventRecord(c->ev[10], c->stream3));
+    if (n_grp > 1) { HIPCHK(c, hipEventRecord(c->ev[11], c->stream4)); HIPCHK(c, hipStreamWaitEvent(s, c->ev[11], 0)); }
+    entropy_joined = n_grp != 0;
   } else {
     // Inter chunk: a P frame needs the previous frame's final (post-CDEF) reconstruction, so motion search,
     // reconstruction and CDEF run frame by frame; entropy coding of ALL frames follows in one pass (every frame
@@ -885,7 +926,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       if (!av1mi_frame_is_inter(P, (int)f)) { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level[i]; }
       else { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level_inter[i]; }
       if (P1.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P1, recf, blkf, s));
-      HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, s));
+      HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, nullptr, s));
       if (lr) {
         const int upf = ((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
         HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, c->d_lrsse + (size_t)f * upf * 8, s));
@@ -919,14 +960,17 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
                                  c->d_tile_off /* scratch until the packing kernels fill it */, (int)entropy_from, (int)(n_frames - entropy_from), s, c->ev[7]));
   if (entropy_joined) HIPCHK(c, hipStreamWaitEvent(s, c->ev[10], 0));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
-  if (!inter_chunk && !lr && P.lf_level[0]) {  // deblocking reads only the reconstruction and block info: beside symbolize
+  // (AV1MI_CDEF_SPLIT: the direction search as a kernel of its own beside symbolize - measured slower overall: it takes symbolize's slots)
+  const bool split_cdef = !inter_chunk && !lr && P.enable_cdef && getenv("AV1MI_CDEF_SPLIT");
+  if (!inter_chunk && !lr) {  // deblocking and CDEF's direction search read only the reconstruction and block info: beside symbolize
     HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));
-    HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s2));
+    if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s2));
+    if (split_cdef) HIPCHK(c, av1mi_launch_cdef_dir(&P, c->d_rec, c->d_blk, c->d_cdefdir, s2));
   }
   HIPCHK(c, hipStreamWaitEvent(s2, c->ev[7], 0));  // ev[7]: recorded between symbolize and range-code (measured: starting CDEF
                                                    // right after the reconstruction, beside symbolize, costs 8 % overall)
   HIPCHK(c, hipEventRecord(c->ev[8], s2));
-  if (!inter_chunk && !lr) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, s2));
+  if (!inter_chunk && !lr) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, split_cdef ? c->d_cdefdir : nullptr, s2));
   HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s2));
   HIPCHK(c, hipEventRecord(c->ev[9], s2));
   // packing and the download of the bitstream need nothing from the second stream: they run beside the tail of CDEF / SSE;

@@ -11,6 +11,7 @@
 //     granularity: prefix sums over tile sizes, then every tile copies itself into the final
 //     Section-5 OBU stream (temporal delimiter, sequence header, OBU_FRAME with tile sizes).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "av1mi_dev.h"
 
 namespace {
@@ -55,109 +56,287 @@ __device__ __forceinline__ void cdef_dir_offsets(int dir, int &dy0, int &dx0, in
   dx1 = ((0x29C924 >> sh) & 7) - 2;   // 001 010 011 100 100 100 100 100
 }
 
-// filter the sample at (gx, gy) of a plane (w x h, row stride `stride`).  EDGE = false: the whole
-// tap neighbourhood of the superblock is inside the frame (no availability tests).
-template <typename PIX, bool EDGE>
-__device__ __forceinline__ int cdef_pixel(const PIX *pl, int stride, int w, int h, int gx, int gy, int x, int pri, int sec,
-                                          int pri_shift, int sec_shift, int dir, int coeff_shift) {
-  int sum = 0, mx = x, mn = x;
-  const int odd = (pri >> coeff_shift) & 1;
+// The constrained filter (§7.15.3) of BR consecutive rows of one column (this lane's) whose 8x8 (4x4 chroma) block is the same
+// for all of them: the direction - so the tap offsets - and the strengths are per-lane constants of the batch.  ALL loads of the
+// batch (centre + 4 primary taps, + 8 secondary taps when SEC) are issued before anything is computed: the row-at-a-time form
+// (load centre, branch on the block's filter flag, load taps, filter, store) paid two memory latencies per row - 192 per
+// superblock, ~600 k cycles per wave with 73 % of them parked on loads.  No branches: a block that is not filtered runs with both
+// strengths 0 (the filter then returns the sample itself), a tap outside the frame (EDGE superblocks only) is replaced by the
+// centre sample, which contributes nothing to the sum nor to the clamp range - exactly "not available" (§7.15.3).
+// sample `idx` of a plane: the byte offset is formed in 32 bits (a frame is far below 4 GB), so the load takes its address as
+// scalar base + 32-bit vector offset
+template <typename PIX>
+__device__ __forceinline__ int ld_px(const PIX *pl, int idx) {
+  return *reinterpret_cast<const PIX *>(reinterpret_cast<const char *>(pl) + (unsigned)idx * (unsigned)sizeof(PIX));
+}
+template <typename PIX>
+__device__ __forceinline__ void st_px(PIX *pl, int idx, int v) {
+  *reinterpret_cast<PIX *>(reinterpret_cast<char *>(pl) + (unsigned)idx * (unsigned)sizeof(PIX)) = (PIX)v;
+}
+template <typename PIX, bool EDGE, bool SEC, int BR>
+__device__ __forceinline__ void cdef_rows(const PIX *pl, PIX *out, int stride, int w, int h, int gx, int gy0, int pri, int sec, int pri_shift,
+                                          int sec_shift, int dir, int coeff_shift) {
   int oy[2], ox[2], sy[2][2], sx[2][2];
   cdef_dir_offsets(dir, oy[0], ox[0], oy[1], ox[1]);
-  if (sec) {
+  if (SEC) {
     cdef_dir_offsets((dir + 2) & 7, sy[0][0], sx[0][0], sy[0][1], sx[0][1]);
     cdef_dir_offsets((dir + 6) & 7, sy[1][0], sx[1][0], sy[1][1], sx[1][1]);
   }
+  constexpr int NT = SEC ? 12 : 4;
+  int ty[NT], tx[NT];   // tap offsets: primary k = 0, 1 (each with both signs), then the two secondary directions
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int ptap = k ? (odd ? 3 : 2) : (odd ? 3 : 4), stap = k ? 1 : 2;
+  for (int k = 0; k < 2; k++) { ty[2 * k] = oy[k]; tx[2 * k] = ox[k]; ty[2 * k + 1] = -oy[k]; tx[2 * k + 1] = -ox[k]; }
+  if (SEC) {
 #pragma unroll
-    for (int sg = -1; sg <= 1; sg += 2) {
-      // every available tap widens the clamp range, whatever its strength (spec §7.15.3)
-      {
-        const int yy = gy + sg * oy[k], xx = gx + sg * ox[k];
-        if (!EDGE || (yy >= 0 && xx >= 0 && yy < h && xx < w)) {
-          const int p = pl[(size_t)yy * stride + xx];
-          if (pri) sum += ptap * constrain(p - x, pri, pri_shift);
-          mx = p > mx ? p : mx;
-          mn = p < mn ? p : mn;
-        }
-      }
-      // with sec == 0 the secondary taps add nothing to the sum and cannot change the clamp either
-      // (|sum| / 16 <= 12/16 of the largest primary difference), so they are not even read
-      if (sec) {
+    for (int q = 0; q < 2; q++) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-          const int yy = gy + sg * sy[q][k], xx = gx + sg * sx[q][k];
-          if (!EDGE || (yy >= 0 && xx >= 0 && yy < h && xx < w)) {
-            const int s1 = pl[(size_t)yy * stride + xx];
-            sum += stap * constrain(s1 - x, sec, sec_shift);
-            mx = s1 > mx ? s1 : mx;
-            mn = s1 < mn ? s1 : mn;
-          }
-        }
+      for (int k = 0; k < 2; k++) {
+        ty[4 + 4 * q + 2 * k] = sy[q][k]; tx[4 + 4 * q + 2 * k] = sx[q][k];
+        ty[4 + 4 * q + 2 * k + 1] = -sy[q][k]; tx[4 + 4 * q + 2 * k + 1] = -sx[q][k];
       }
     }
   }
-  int v = x + ((8 + sum - (sum < 0)) >> 4);
-  return v < mn ? mn : (v > mx ? mx : v);
+  // 32-bit unsigned sample indices from the (wave-uniform) plane pointer: the loads take the scalar-base + 32-bit-offset form
+  // instead of a 64-bit address pair per tap
+  int toff[NT];
+#pragma unroll
+  for (int k = 0; k < NT; k++) toff[k] = ty[k] * stride + tx[k];
+  int c[BR], t[BR][NT];
+  unsigned okm[BR];   // EDGE: bit k = tap k of the row is inside the frame
+#pragma unroll
+  for (int r = 0; r < BR; r++) {
+    const int gy = EDGE ? (gy0 + r < h ? gy0 + r : h - 1) : gy0 + r;   // (rows below a partial superblock: loaded from the last row, never stored)
+    const int base = gy * stride + gx;
+    c[r] = ld_px(pl, base);
+    okm[r] = 0;
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+      if (EDGE) {
+        int yy = gy + ty[k], xx = gx + tx[k];
+        okm[r] |= (unsigned)(yy >= 0 && xx >= 0 && yy < h && xx < w) << k;
+        yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+        xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+        t[r][k] = ld_px(pl, yy * stride + xx);
+      } else {
+        t[r][k] = ld_px(pl, base + toff[k]);
+      }
+    }
+  }
+  const int odd = (pri >> coeff_shift) & 1;
+#pragma unroll
+  for (int r = 0; r < BR; r++) {
+    const int x = c[r];
+    int sum = 0, mx = x, mn = x;
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+      const int p = (EDGE && !((okm[r] >> k) & 1)) ? x : t[r][k];
+      // taps k = 0, 1: primary, distance 1 (weight 4 or 3); 2, 3: primary, distance 2 (2 or 3); 4 .. 11: secondary (2, 2, 1, 1 per direction)
+      const int wgt = k < 2 ? (odd ? 3 : 4) : (k < 4 ? (odd ? 3 : 2) : (((k - 4) & 3) < 2 ? 2 : 1));
+      sum += wgt * (k < 4 ? constrain(p - x, pri, pri_shift) : constrain(p - x, sec, sec_shift));
+      mx = p > mx ? p : mx;
+      mn = p < mn ? p : mn;
+    }
+    int v = x + ((8 + sum - (sum < 0)) >> 4);
+    v = v < mn ? mn : (v > mx ? mx : v);
+    if (!EDGE || gy0 + r < h) st_px(out, (gy0 + r) * stride + gx, v);
+  }
 }
 
-template <typename PIX, bool EDGE>
+template <typename PIX, bool EDGE, bool SEC>
 __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PIX *fr, PIX *fo, int x0, int y0, int w, int h, int lane,
                                                int row0, int row1 /* luma rows [row0, row1) of the superblock, multiples of 8 */) {
   const int coeff_shift = P.bit_depth - 8;
-  // ---- luma: lane = column, loop over rows (row-contiguous HBM loads and stores)
+  // ---- luma: lane = column, batches of the 8 rows of a block row (row-contiguous HBM loads and stores)
   {
     const int sec = (P.cdef_y_sec == 3 ? 4 : P.cdef_y_sec) << coeff_shift;
     const int damping = P.cdef_damping + coeff_shift;
     const int sec_shift = damp_shift(sec, damping);
-    const int ypri0 = P.cdef_y_pri;
     if (lane < w) {
-#pragma unroll 8
-      for (int r = row0; r < (row1 < h ? row1 : h); r++) {   // multiples of 8: the 8 rows of a block share the decisions and their loads overlap
+      for (int r = row0; r < (row1 < h ? row1 : h); r += 8) {
         const int b = (r >> 3) * 8 + (lane >> 3);
-        const int gx = x0 + lane, gy = y0 + r;
-        int v = fr[(size_t)gy * P.stride_y + gx];
-        const int pri = g_cdef.on[b] ? (int)g_cdef.pri_y[b] : 0;
-        if (g_cdef.on[b] && (pri | sec)) {
-          const int dir = ypri0 == 0 ? 0 : g_cdef.dir[b];
-          v = cdef_pixel<PIX, EDGE>(fr, P.stride_y, P.width, P.height, gx, gy, v, pri, sec, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
+        const bool on = g_cdef.on[b] != 0;
+        const int pri = on ? (int)g_cdef.pri_y[b] : 0, sec_b = on ? sec : 0;
+        const int dir = P.cdef_y_pri == 0 ? 0 : g_cdef.dir[b];
+        // batches: 8 rows with primary taps only in interior superblocks; 4 rows with the secondary taps or the frame-edge tests
+        if (SEC && sec) {
+          cdef_rows<PIX, EDGE, true, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, sec_b, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
+          cdef_rows<PIX, EDGE, true, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r + 4, pri, sec_b, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
+        } else if (EDGE) {
+          cdef_rows<PIX, true, false, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift);
+          cdef_rows<PIX, true, false, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r + 4, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift);
+        } else {
+          cdef_rows<PIX, false, false, 8>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift);
         }
-        fo[(size_t)gy * P.stride_y + gx] = (PIX)v;
       }
     }
   }
-  // ---- chroma: lanes 0-31 = columns of U, lanes 32-63 = columns of V
+  // ---- chroma: lanes 0-31 = columns of U, lanes 32-63 = columns of V; batches of the 4 rows of a block row
   {
     const int pl = lane >> 5, col = lane & 31;
     const PIX *cp = fr + (pl ? P.plane_off_v : P.plane_off_u);
     PIX *op = fo + (pl ? P.plane_off_v : P.plane_off_u);
-    const int pri = P.cdef_uv_pri << coeff_shift;
-    const int sec = (P.cdef_uv_sec == 3 ? 4 : P.cdef_uv_sec) << coeff_shift;
+    const int pri0 = P.cdef_uv_pri << coeff_shift;
+    const int sec0 = (P.cdef_uv_sec == 3 ? 4 : P.cdef_uv_sec) << coeff_shift;
     const int damping = P.cdef_damping + coeff_shift - 1;
-    const int pri_shift = damp_shift(pri, damping), sec_shift = damp_shift(sec, damping);
+    const int pri_shift = damp_shift(pri0, damping), sec_shift = damp_shift(sec0, damping);
     const int wc = w >> 1, hc = h >> 1;
     if (col < wc) {
-#pragma unroll 4
-      for (int r = row0 >> 1; r < ((row1 >> 1) < hc ? (row1 >> 1) : hc); r++) {
+      for (int r = row0 >> 1; r < ((row1 >> 1) < hc ? (row1 >> 1) : hc); r += 4) {
         const int b = (r >> 2) * 8 + (col >> 2);
-        const int gx = (x0 >> 1) + col, gy = (y0 >> 1) + r;
-        int v = cp[(size_t)gy * P.stride_c + gx];
-        if (g_cdef.on[b] && (pri | sec))
-          v = cdef_pixel<PIX, EDGE>(cp, P.stride_c, P.width >> 1, P.height >> 1, gx, gy, v, pri, sec, pri_shift, sec_shift,
-                                    pri == 0 ? 0 : (int)g_cdef.dir[b], coeff_shift);
-        op[(size_t)gy * P.stride_c + gx] = (PIX)v;
+        const bool on = g_cdef.on[b] != 0;
+        const int pri = on ? pri0 : 0, sec = on ? sec0 : 0;
+        const int dir = pri0 == 0 ? 0 : (int)g_cdef.dir[b];
+        if (SEC && sec0) cdef_rows<PIX, EDGE, true, 4>(cp, op, P.stride_c, P.width >> 1, P.height >> 1, (x0 >> 1) + col, (y0 >> 1) + r, pri, sec, pri_shift, sec_shift, dir, coeff_shift);
+        else cdef_rows<PIX, EDGE, false, 4>(cp, op, P.stride_c, P.width >> 1, P.height >> 1, (x0 >> 1) + col, (y0 >> 1) + r, pri, 0, pri_shift, 0, dir, coeff_shift);
       }
     }
   }
 }
 
+// Direction search §7.15.2 of one 8x8 block held in registers (px[i][j], already >> coeff_shift and - 128): direction and the
+// variance that scales the luma primary strength.  The eight directions' partial sums would need 120 registers at once; they
+// are built in two groups of four, which keeps the callers at 6 waves/SIMD without spilling.
+__device__ __forceinline__ void cdef_direction_8x8(const int (&px)[8][8], int &ydir, int &var) {
+  int cost[8];
+#pragma unroll
+  for (int a = 0; a < 8; a++) cost[a] = 0;
+#pragma unroll
+  for (int grp = 0; grp < 2; grp++) {
+    int partial[4][15];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+#pragma unroll
+      for (int b = 0; b < 15; b++) partial[a][b] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int x = px[i][j];
+        if (grp == 0) {
+          partial[0][i + j] += x;            // direction 0
+          partial[1][i + j / 2] += x;        // 1
+          partial[2][i] += x;                // 2
+          partial[3][3 + i - j / 2] += x;    // 3
+        } else {
+          partial[0][7 + i - j] += x;        // 4
+          partial[1][3 - i / 2 + j] += x;    // 5
+          partial[2][j] += x;                // 6
+          partial[3][i / 2 + j] += x;        // 7
+        }
+      }
+    }
+    const int d0 = grp * 4;
+    {  // directions 2 and 6: 8 sums
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) c += partial[2][i] * partial[2][i];
+      cost[d0 + 2] = c * 105;
+    }
+    {  // directions 0 and 4: 15 diagonals
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < 7; i++) c += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * c_div_table[i + 1];
+      cost[d0] = c + partial[0][7] * partial[0][7] * 105;
+    }
+#pragma unroll
+    for (int q = 1; q < 4; q += 2) {  // odd directions: 11 sums
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < 5; j++) c += partial[q][3 + j] * partial[q][3 + j];
+      c *= 105;
+#pragma unroll
+      for (int j = 0; j < 3; j++) c += (partial[q][j] * partial[q][j] + partial[q][10 - j] * partial[q][10 - j]) * c_div_table[2 * j + 2];
+      cost[d0 + q] = c;
+    }
+  }
+  int best = 0;
+  ydir = 0;
+#pragma unroll
+  for (int d = 0; d < 8; d++)
+    if (cost[d] > best) { best = cost[d]; ydir = d; }
+  int opp = 0;
+#pragma unroll
+  for (int d = 0; d < 8; d++)
+    if (d == ((ydir + 4) & 7)) opp = cost[d];
+  var = (best - opp) >> 10;
+}
+
+// variance-adjusted luma primary strength (§7.15.1)
+__device__ __forceinline__ int cdef_adjusted_pri(int pri_y, int var, int coeff_shift) {
+  int pri = pri_y << coeff_shift;
+  const int v6 = var >> 6;
+  const int var_str = v6 ? ((31 - __builtin_clz((unsigned)v6)) < 12 ? (31 - __builtin_clz((unsigned)v6)) : 12) : 0;
+  return var ? (pri * (4 + var_str) + 8) >> 4 : 0;
+}
+
+// Chunk-wide launches: the direction search in a kernel of its own.  A wave per superblock stages the 64x64 luma samples in LDS
+// with row-contiguous 16-byte loads (lane = 8 samples of a row: 1 KB per instruction) and every lane then reads its own 8x8
+// block from there - as one kernel with the filter each lane loaded its block straight from HBM, 64 lanes touching 64 different
+// 16-byte segments per instruction (8192 cache-line requests per superblock against 640 for the whole filter pass), and the
+// filter kernel cannot hold an LDS tile beside the range coder (145 KB of LDS per CU).  This kernel runs beside symbolize; the
+// filter kernel (beside the range coder) reads {adjusted primary strength << 3 | direction} per 8x8 block.
+template <typename PIX>
+__global__ void __launch_bounds__(64) cdef_dir_kernel(Av1miDevParams P, const PIX *__restrict__ rec, const Av1miBlkInfo *__restrict__ blk,
+                                                     uint16_t *__restrict__ dirtab /* [frame][superblock][64] */) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[64][72];   // row pitch 144 B: 16-byte aligned, block rows land on different bank halves
+  const int sbs_per_frame = P.sb_rows * P.sb_cols;
+  const int f = blockIdx.x / sbs_per_frame, sb = blockIdx.x % sbs_per_frame;
+  const int sbr = sb / P.sb_cols, sbc = sb % P.sb_cols, lane = threadIdx.x;
+  const PIX *fr = rec + (size_t)f * P.frame_samples;
+  const int x0 = sbc * 64, y0 = sbr * 64, coeff_shift = P.bit_depth - 8;
+  const int b8r = lane >> 3, b8c = lane & 7;
+  const bool inside = (sbr * 8 + b8r) < P.b8_rows && (sbc * 8 + b8c) < P.b8_cols;
+  int skip = 1;
+  if (inside) skip = blk[(size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8 + b8r) * P.b8_cols + sbc * 8 + b8c].skip;
+  const bool sb_on = __ballot(inside && !skip) != 0ull;
+  if (!P.enable_cdef || !sb_on) return;   // nothing of this superblock is filtered: the filter kernel does not read its entries
+  {
+    const int c8 = (lane & 7) * 8;
+    const bool col_in = x0 + c8 < P.width;   // (width is a multiple of 8: a group of 8 samples is inside or outside as a whole)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int row = k * 8 + (lane >> 3);
+      if (col_in && y0 + row < P.height) {
+        const PIX *p = fr + (size_t)(y0 + row) * P.stride_y + x0 + c8;
+        uint4 w;
+        if (sizeof(PIX) == 2) {
+          w = *reinterpret_cast<const uint4 *>(p);
+        } else {
+          const uint2 q = *reinterpret_cast<const uint2 *>(p);
+          w.x = (q.x & 0xFF) | ((q.x & 0xFF00) << 8); w.y = ((q.x >> 16) & 0xFF) | ((q.x >> 24) << 16);
+          w.z = (q.y & 0xFF) | ((q.y & 0xFF00) << 8); w.w = ((q.y >> 16) & 0xFF) | ((q.y >> 24) << 16);
+        }
+        *reinterpret_cast<uint4 *>(&tile[row][c8]) = w;
+      }
+    }
+  }
+  __syncthreads();
+  int ydir = 0, var = 0;
+  if (inside && !skip) {
+    int px[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(&tile[b8r * 8 + i][b8c * 8]);
+      const uint32_t d[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        px[i][2 * j] = (int)((d[j] & 0xFFFF) >> coeff_shift) - 128;
+        px[i][2 * j + 1] = (int)((d[j] >> 16) >> coeff_shift) - 128;
+      }
+    }
+    cdef_direction_8x8(px, ydir, var);
+  }
+  dirtab[(size_t)blockIdx.x * 64 + lane] = (uint16_t)((cdef_adjusted_pri(P.cdef_y_pri, var, coeff_shift) << 3) | ydir);
+}
+
 // NS = 1: one wave per superblock (chunk-wide launches: throughput).  NS = 4: one wave per 16-row strip of a superblock
 // (one-frame launches of inter chunks: 4x the waves and a quarter of the serial work per wave: latency).
-template <typename PIX, int NS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
-                                                    const Av1miBlkInfo *__restrict__ blk) {
+// TAB: directions and adjusted strengths come from cdef_dir_kernel's table instead of being searched here.
+// SEC: some secondary strength is non-zero (the default strengths have none: the instantiation without carries no secondary-tap code).
+template <typename PIX, int NS, bool TAB, bool SEC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
+                                                    const Av1miBlkInfo *__restrict__ blk, const uint16_t *__restrict__ dirtab) {
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
   const int strip = NS == 1 ? 0 : (int)(blockIdx.x % NS);
   const int item = blockIdx.x / NS;
@@ -179,83 +358,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
   const bool do_filter = P.enable_cdef && sb_on && inside && !skip;
   const bool mine = NS == 1 || (b8r >> 1) == strip;   // this wave decides (and filters) only the blocks of its strip
   {
-    int ydir = 0, var = 0;
-    if (do_filter && mine) {
-      // direction search §7.15.2 on the block's 8 rows of 8 samples.  The eight directions' partial sums would need
-      // 120 registers at once; they are built in two groups of four over the same 64 samples (the second read hits L1),
-      // which keeps the kernel at 6 waves/SIMD without spilling.
-      const PIX *ty = fr + (size_t)(y0 + b8r * 8) * P.stride_y + x0 + b8c * 8;
-      int cost[8];
-#pragma unroll
-      for (int a = 0; a < 8; a++) cost[a] = 0;
-#pragma unroll
-      for (int grp = 0; grp < 2; grp++) {
-        int partial[4][15];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-#pragma unroll
-          for (int b = 0; b < 15; b++) partial[a][b] = 0;
-        }
+    int ydir = 0, pri = 0;
+    if constexpr (TAB) {
+      if (do_filter && mine) { const int e = dirtab[(size_t)item * 64 + lane]; ydir = e & 7; pri = e >> 3; }
+    } else {
+      int var = 0;
+      if (do_filter && mine) {
+        // direction search §7.15.2 on the block's 8 rows of 8 samples (one-frame launches of inter chunks: the lane reads its block
+        // from L1/L2; the second group's reads hit L1)
+        const PIX *ty = fr + (size_t)(y0 + b8r * 8) * P.stride_y + x0 + b8c * 8;
+        int px[8][8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          PIX rowpx[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) rowpx[j] = ty[(size_t)i * P.stride_y + j];
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int x = ((int)rowpx[j] >> coeff_shift) - 128;
-            if (grp == 0) {
-              partial[0][i + j] += x;            // direction 0
-              partial[1][i + j / 2] += x;        // 1
-              partial[2][i] += x;                // 2
-              partial[3][3 + i - j / 2] += x;    // 3
-            } else {
-              partial[0][7 + i - j] += x;        // 4
-              partial[1][3 - i / 2 + j] += x;    // 5
-              partial[2][j] += x;                // 6
-              partial[3][i / 2 + j] += x;        // 7
-            }
-          }
+          for (int j = 0; j < 8; j++) px[i][j] = ((int)ty[(size_t)i * P.stride_y + j] >> coeff_shift) - 128;
         }
-        // group 0 holds directions 0..3 in partial[0..3], group 1 directions 4..7
-        const int d0 = grp * 4;
-        {  // directions 2 and 6: 8 sums
-          int c = 0;
-#pragma unroll
-          for (int i = 0; i < 8; i++) c += partial[2][i] * partial[2][i];
-          cost[d0 + 2] = c * 105;
-        }
-        {  // directions 0 and 4: 15 diagonals
-          int c = 0;
-#pragma unroll
-          for (int i = 0; i < 7; i++) c += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * c_div_table[i + 1];
-          cost[d0] = c + partial[0][7] * partial[0][7] * 105;
-        }
-#pragma unroll
-        for (int q = 1; q < 4; q += 2) {  // odd directions: 11 sums
-          int c = 0;
-#pragma unroll
-          for (int j = 0; j < 5; j++) c += partial[q][3 + j] * partial[q][3 + j];
-          c *= 105;
-#pragma unroll
-          for (int j = 0; j < 3; j++) c += (partial[q][j] * partial[q][j] + partial[q][10 - j] * partial[q][10 - j]) * c_div_table[2 * j + 2];
-          cost[d0 + q] = c;
-        }
+        cdef_direction_8x8(px, ydir, var);
       }
-      int best = 0;
-#pragma unroll
-      for (int d = 0; d < 8; d++)
-        if (cost[d] > best) { best = cost[d]; ydir = d; }
-      int opp = 0;
-#pragma unroll
-      for (int d = 0; d < 8; d++)
-        if (d == ((ydir + 4) & 7)) opp = cost[d];
-      var = (best - opp) >> 10;
+      pri = cdef_adjusted_pri(P.cdef_y_pri, var, coeff_shift);
     }
-    int pri = P.cdef_y_pri << coeff_shift;
-    const int v6 = var >> 6;
-    const int var_str = v6 ? ((31 - __builtin_clz((unsigned)v6)) < 12 ? (31 - __builtin_clz((unsigned)v6)) : 12) : 0;
-    pri = var ? (pri * (4 + var_str) + 8) >> 4 : 0;
     g_cdef.dir[lane] = (uint8_t)ydir;
     g_cdef.on[lane] = (uint8_t)do_filter;
     g_cdef.pri_y[lane] = (uint16_t)pri;
@@ -264,8 +385,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
   // taps reach 2 samples beyond the superblock (1 in chroma): interior superblocks need no tests
   const bool edge = x0 < 2 || y0 < 2 || x0 + 66 > P.width || y0 + 66 > P.height;
   const int row0 = NS == 1 ? 0 : strip * 16, row1 = NS == 1 ? 64 : strip * 16 + 16;
-  if (edge) cdef_filter_sb<PIX, true>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
-  else cdef_filter_sb<PIX, false>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
+  if (edge) cdef_filter_sb<PIX, true, SEC>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
+  else cdef_filter_sb<PIX, false, SEC>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
 }
 
 // ------------------------------------------------------------------------------ SSE (PSNR)
@@ -420,16 +541,32 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
 
 }  // namespace
 
-extern "C" hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, hipStream_t stream) {
+// dirtab == nullptr: one kernel (direction search + filter); else the filter reads cdef_dir_kernel's table (av1mi_launch_cdef_dir before)
+extern "C" hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, const uint16_t *dirtab,
+                                        hipStream_t stream) {
   const int grid = P->n_frames * P->sb_rows * P->sb_cols;
   const bool strips = P->n_frames == 1;  // a one-frame launch sits on an inter chunk's serial chain
-  if (P->bit_depth == 8) {
-    if (strips) hipLaunchKernelGGL((cdef_sb_kernel<uint8_t, 4>), dim3(grid * 4), dim3(64), 0, stream, *P, (const uint8_t *)rec, (uint8_t *)fin, blk);
-    else hipLaunchKernelGGL((cdef_sb_kernel<uint8_t, 1>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)rec, (uint8_t *)fin, blk);
-  } else {
-    if (strips) hipLaunchKernelGGL((cdef_sb_kernel<uint16_t, 4>), dim3(grid * 4), dim3(64), 0, stream, *P, (const uint16_t *)rec, (uint16_t *)fin, blk);
-    else hipLaunchKernelGGL((cdef_sb_kernel<uint16_t, 1>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)rec, (uint16_t *)fin, blk);
-  }
+  static const bool exp_strips = getenv("AV1MI_CDEF_STRIPS") != nullptr;   // experiment: 16-row strips for chunk-wide launches too
+  const bool sec = P->cdef_y_sec != 0 || P->cdef_uv_sec != 0;
+#define CDEF_LAUNCH2(PIXT, SECV)                                                                                                           \
+  do {                                                                                                                                     \
+    if (exp_strips && dirtab) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 4, true, SECV>), dim3(grid * 4), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
+    else if (strips || exp_strips) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 4, false, SECV>), dim3(grid * 4), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
+    else if (dirtab) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, true, SECV>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
+    else hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, false, SECV>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
+  } while (0)
+#define CDEF_LAUNCH(PIXT) do { if (sec) CDEF_LAUNCH2(PIXT, true); else CDEF_LAUNCH2(PIXT, false); } while (0)
+  if (P->bit_depth == 8) CDEF_LAUNCH(uint8_t); else CDEF_LAUNCH(uint16_t);
+#undef CDEF_LAUNCH2
+#undef CDEF_LAUNCH
+  return hipGetLastError();
+}
+
+// the direction search of a chunk-wide CDEF as a kernel of its own (see cdef_dir_kernel); dirtab: n_frames x superblocks x 64 entries
+extern "C" hipError_t av1mi_launch_cdef_dir(const Av1miDevParams *P, const void *rec, const Av1miBlkInfo *blk, uint16_t *dirtab, hipStream_t stream) {
+  const int grid = P->n_frames * P->sb_rows * P->sb_cols;
+  if (P->bit_depth == 8) hipLaunchKernelGGL((cdef_dir_kernel<uint8_t>), dim3(grid), dim3(64), 0, stream, *P, (const uint8_t *)rec, blk, dirtab);
+  else hipLaunchKernelGGL((cdef_dir_kernel<uint16_t>), dim3(grid), dim3(64), 0, stream, *P, (const uint16_t *)rec, blk, dirtab);
   return hipGetLastError();
 }
 

@@ -316,6 +316,28 @@ def test_entropy_coding_in_groups_beside_the_chain(av1mi, oracle, monkeypatch, w
     assert outs[0][0] == b"".join(tus) and outs[0][2] == b"".join(raw_of(r, bd) for r in recs)
 
 
+def test_alternative_schedules_give_the_same_bytes(av1mi, oracle, monkeypatch):
+    """Scheduling knobs of the all-key-frame path - the chunk pipelined over groups of frames on auxiliary streams, CDEF's direction
+    search as a kernel of its own - change when kernels run, never what they compute: same stream, same reconstruction."""
+    w, h, bd, n = 328, 248, 10, 7
+    frames = [oracle.synthclip_frame(w, h, bd, seed=610, t=t) for t in range(n)]
+    raw = b"".join(raw_of(f, bd) for f in frames)
+    p = av1mi.default_params(w, h, bd, deblock=1, cdef_y_sec=1, cdef_uv_sec=2)
+    outs = []
+    for env in ({}, {"AV1MI_INTRA_GROUPS": "3"}, {"AV1MI_CDEF_SPLIT": "1"}, {"AV1MI_INTRA_GROUPS": "4", "AV1MI_CDEF_SPLIT": "1"}):
+        for k in ("AV1MI_INTRA_GROUPS", "AV1MI_CDEF_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with av1mi.Context(0) as c:
+            data, sizes, rep, recon = c.encode_chunk(p, raw, n, want_recon=True)
+        outs.append((data, list(sizes), recon.tobytes()))
+    assert all(o == outs[0] for o in outs)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5, deblock=1, cdef_y_sec=1, cdef_uv_sec=2)
+    tus, recs = oracle_chunk(oracle, cfg, frames, 1)
+    assert outs[0][0] == b"".join(tus) and outs[0][2] == b"".join(raw_of(r, bd) for r in recs)
+
+
 def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_sequences):
     """The dav1d-pinned inter sequences the GPU path can express (decision-driven, one-superblock tiles)."""
     n = 0
