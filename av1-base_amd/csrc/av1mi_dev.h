@@ -38,6 +38,7 @@ struct Av1miDevParams {
   int using_qm, qm_y, qm_uv;
   int min_bs_log2, max_bs_log2;
   uint32_t mode_mask;
+  int angle_delta;          // 1: directional winners of the luma mode decision are refined over the angle deltas -3 .. +3
   int enable_cdef, cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping;
   int disable_cdf_update;
   // plane geometry in samples
@@ -79,8 +80,8 @@ struct Av1miBlkInfo {
   uint8_t bsl;      // log2 block size in pixels (3..6)
   uint8_t is_inter; // inter frames: 1 = predicted from LAST_FRAME with `mv`
   uint16_t eob[3];
-  int16_t mv_row, mv_col;  // 1/8 luma samples (always multiples of 8: integer-pel search)
-  uint16_t pad;
+  int16_t mv_row, mv_col;  // 1/8 luma samples
+  uint16_t angle;   // angle delta + 3 of a directional intra mode (3 = none), luma and chroma alike
 };
 static_assert(sizeof(Av1miBlkInfo) == 16, "block info is one 16-byte record");
 

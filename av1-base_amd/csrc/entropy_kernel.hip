@@ -712,11 +712,12 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
             const int lm = uni(c_intra_mode_ctx[avail_l ? INFO(b8x - 1, b8y).ymode : 0]);
             sym_wide(y, lane, adapt, ymode, CL::KF_Y_MODE + (am * 5 + lm) * 14, 13);
           }
-          if (ymode >= 1 && ymode <= 8) sym_wide(y, lane, adapt, 3, CL::ANGLE_DELTA + (ymode - 1) * 8, 7);
+          const int adelta = uni(INFO(b8x, b8y).angle);   // angle delta + 3 = the symbol; chroma uses luma's
+          if (ymode >= 1 && ymode <= 8) sym_wide(y, lane, adapt, adelta, CL::ANGLE_DELTA + (ymode - 1) * 8, 7);
           const int uvmode = ymode;
           const int cfl_allowed = n <= 32;
           sym_wide(y, lane, adapt, uvmode, CL::UV_MODE + (cfl_allowed * 13 + ymode) * 15, cfl_allowed ? 14 : 13);
-          if (uvmode >= 1 && uvmode <= 8) sym_wide(y, lane, adapt, 3, CL::ANGLE_DELTA + (uvmode - 1) * 8, 7);
+          if (uvmode >= 1 && uvmode <= 8) sym_wide(y, lane, adapt, adelta, CL::ANGLE_DELTA + (uvmode - 1) * 8, 7);
         }
         const int w4 = n >> 2, w4c = imax(w4 >> 1, 1);
         const int log2c = bsl - 1;

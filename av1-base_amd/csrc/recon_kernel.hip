@@ -197,8 +197,6 @@ __device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int
   const uint16_t *A = S->edge_a + 1 + eo, *L = S->edge_l + 1 + eo;
   switch (mode) {
     case DC_PRED: return dcval;
-    case V_PRED: return A[c];
-    case H_PRED: return L[r];
     case PAETH_PRED: {
       int tl = A[-1], t = A[c], l = L[r];
       int base = t + l - tl;
@@ -217,7 +215,9 @@ __device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int
       int wc = S->smw[c];
       return (wc * L[r] + (256 - wc) * A[N - 1] + 128) >> 8;
     }
-    default: {
+    default: {   // V_PRED .. D67_PRED at the angle `ang` = the mode's base angle + 3 * angle delta
+      if (ang == 90) return A[c];
+      if (ang == 180) return L[r];
       if (ang < 90) {
         int idx = (r + 1) * dx;
         int base = (idx >> 6) + c, sh = (idx >> 1) & 31;
@@ -405,7 +405,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
   };
   if constexpr (PH == 2) {
-    if (plane0 > 0 && ii.is_inter) { inter_done(); return (ii.is_inter << 8) | mode_io; }
+    if (plane0 > 0 && ii.is_inter) { inter_done(); return (ii.is_inter << 8) | (mode_io & 0x7F); }
   }
   STAMP(-1);
   // ---- source block -> LDS (coalesced rows)
@@ -470,7 +470,18 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     __syncthreads();
   }
   // ---- mode decision (luma) + final prediction: one loop, the last trip writes the prediction
-  int best_mode = mode_io, best_sad = 0x7FFFFFFF, sad_dc = -1;
+  // mode_io: bits 0-3 the mode, bits 4-6 the angle delta + 3 (chroma passes follow the luma decision; luma passes decide)
+  int best_mode = mode_io & 15, best_delta = ((mode_io >> 4) & 7) - 3, best_sad = 0x7FFFFFFF, sad_dc = -1;
+  // direction parameters of a directional mode at an angle delta (§7.11.2.4)
+  auto dir_params = [&](int mode, int delta, int &ang, int &dx, int &dy) {
+    ang = 0; dx = 0; dy = 0;
+    if (mode >= V_PRED && mode <= D67_PRED) {
+      ang = c_mode_angle[mode] + 3 * delta;
+      if (ang < 90) dx = c_dr_deriv[ang];
+      else if (ang > 90 && ang < 180) { dx = c_dr_deriv[180 - ang]; dy = c_dr_deriv[ang - 90]; }
+      else if (ang > 180) dy = c_dr_deriv[270 - ang];
+    }
+  };
   int first = (PH != 1 && NPL == 1 && plane0 == 0) ? 0 : 13;
   if (PH != 1 && NPL == 1 && plane0 == 0 && P->mode_mask == 0x7u) {
     // default candidate set {DC, V, H}: the three SADs in one pass over the block instead of three
@@ -497,10 +508,26 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     if (PH != 1 && final_trip && NPL == 1 && plane0 == 0) {
       // DC is kept unless the best other candidate at least halves its SAD
       if (sad_dc >= 0 && (best_sad == 0x7FFFFFFF || 2 * (long)best_sad >= (long)sad_dc)) { best_mode = DC_PRED; best_sad = sad_dc; }
+      // angle delta: a directional winner is refined over the deltas -1, +1, -2, +2, -3, +3; strictly smaller SAD wins
+      best_delta = 0;
+      if (P->angle_delta && best_mode >= V_PRED && best_mode <= D67_PRED) {
+#pragma nounroll
+        for (int k = 0; k < 6; k++) {
+          const int delta = (k & 1) ? (k >> 1) + 1 : -((k >> 1) + 1);
+          int ang, dx, dy;
+          dir_params(best_mode, delta, ang, dx, dy);
+          int sad = 0;
+#pragma unroll 4
+          for (int p = sl; p < N * N; p += G)
+            sad += iabs((int)S->srcblk[po + p] - pred_pixel<LOG2N>(best_mode, p >> LOG2N, p & (N - 1), dcv, ang, dx, dy, eo));
+          sad = wave_sum(sad);
+          if (sad < best_sad) { best_sad = sad; best_delta = delta; }
+        }
+      }
       // inter frames: motion compensation wins when its luma SAD is not larger
       if (INTER) ii.is_inter = ii.sad_inter <= best_sad;
       if constexpr (PH == 2) {
-        if (ii.is_inter) { inter_done(); return (1 << 8) | best_mode; }
+        if (ii.is_inter) { inter_done(); return (1 << 8) | (3 << 4) | best_mode; }
       }
     }
     const int mode = final_trip ? best_mode : m;
@@ -517,13 +544,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         }
       }
     }
-    int ang = 0, dx = 0, dy = 0;
-    if (mode >= V_PRED && mode <= D67_PRED) {
-      ang = c_mode_angle[mode];
-      if (ang < 90) dx = c_dr_deriv[ang];
-      else if (ang > 90 && ang < 180) { dx = c_dr_deriv[180 - ang]; dy = c_dr_deriv[ang - 90]; }
-      else if (ang > 180) dy = c_dr_deriv[270 - ang];
-    }
+    int ang, dx, dy;
+    dir_params(mode, final_trip ? best_delta : 0, ang, dx, dy);
     int sad = 0;
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) {
@@ -677,7 +699,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   if (sl == 0) eob_out[grp] = eob;
   __syncthreads();
   STAMP(6);   // reconstruction -> HBM, line buffers, decoded-block map
-  return ((INTER ? ii.is_inter : 0) << 8) | best_mode;
+  return ((INTER ? ii.is_inter : 0) << 8) | ((best_delta + 3) << 4) | best_mode;
 }
 
 // Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
@@ -713,7 +735,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
     if (bsl == 0) continue;
     const int n = 1 << bsl;
-    int mode = 0;
+    int mode = 3 << 4;   // (mode | (angle delta + 3) << 4)
     InterInfo ii;
     ii.ref = ref_frame; ii.is_inter = 0; ii.mv_row = ii.mv_col = 0; ii.sad_inter = 0;
     if (INTER) {
@@ -745,7 +767,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
       default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
     }
     dec = uniform_i(dec);
-    mode = dec & 0xFF; ii.is_inter = dec >> 8;   // the luma pass decides; the chroma pass follows it
+    mode = dec & 0x7F; ii.is_inter = dec >> 8;   // the luma pass decides (mode and angle delta); the chroma pass follows it
     switch (bsl) {
 #if AV1MI_RECON_BIG
       case 6: tx_item<PIX, 5, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
@@ -761,9 +783,10 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         const int i = cx.lane / n8, j = cx.lane - i * n8;
         Av1miBlkInfo bi;
         const bool unit_inside = cx.sb_y + by + 8 * i < P.height && cx.sb_x + bx + 8 * j < P.width;   // an overhanging block's units beyond the frame have no entry
-        bi.ymode = (uint8_t)mode; bi.skip = (uint8_t)((e0 | e1 | e2) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
+        bi.ymode = (uint8_t)(mode & 15); bi.skip = (uint8_t)((e0 | e1 | e2) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
         bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2;
-        bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0); bi.pad = 0;
+        bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0);
+        bi.angle = (uint16_t)((mode >> 4) & 7);   // angle delta + 3 of the (luma and chroma) directional mode
         if (unit_inside) info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
       }
     }
@@ -873,7 +896,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
       int16_t *sb_levels = levels + (size_t)sb * AV1MI_SB_LEVELS;
       int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
       int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
-      int mode = 0;
+      int mode = 3 << 4;
       __syncthreads();
       // blockIdx.z = 0: the luma block, 1: the two chroma blocks - separate waves, half the latency; each leaves its eobs
       // in the provisional block-info entry (the only fields recon_sb_kernel reads back)

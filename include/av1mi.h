@@ -77,7 +77,8 @@ typedef struct {
   uint32_t color_range;     /* color_config.color_range of the sequence header: 0 (default) = studio / limited range - what Y4M input and the
                                reference's pipeline (ffmpeg -> SVT-AV1, `--pix-format yuv420p10le`, av1an.rs:90) carry; 1 = full range.
                                av1mi_encode_file takes it from the Y4M header's XCOLORRANGE tag when there is one */
-  uint32_t reserved[1];
+  uint32_t intra_angle_delta; /* 1: a directional winner of the luma mode decision (V, H, D45 .. D67) is refined over the angle deltas
+                               -3 .. +3 (3 degrees each) by closed-loop SAD, chroma follows luma; 0 (default): delta 0 */
 } av1mi_params;
 
 typedef struct {

@@ -71,6 +71,8 @@ typedef struct {
    * --qm-min 1 --qm-max 15`, av1an.rs:14): level 0 (steepest) .. 14, 15 = flat (no matrix for that plane) */
   int enable_qm;          /* 1: using_qmatrix */
   int qm_y, qm_uv;        /* qm_y; qm_u = qm_v (separate_uv_delta_q is 0) */
+  int angle_delta;        /* 1: a directional winner of the luma mode decision (V, H, D45 .. D67) is refined over the angle deltas
+                             -3 .. +3 (3 degrees each, §7.11.2.4) by closed-loop SAD; chroma follows luma (same mode, same delta) */
   int color_range;        /* color_config.color_range: 0 = studio / limited (default: what Y4M and the reference's ffmpeg -> SVT-AV1
                              pipeline carry), 1 = full */
   /* test hooks (fuzzing the normative paths against dav1d) */

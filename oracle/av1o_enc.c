@@ -1232,7 +1232,20 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
         if (best < 0 || sad < best) { best = sad; md.ymode = m; }
       }
       if (sad_dc >= 0 && (best < 0 || 2 * (long)best >= (long)sad_dc)) { md.ymode = DC_PRED; best = sad_dc; }
+      /* angle delta: a directional winner is refined over the deltas -1, +1, -2, +2, -3, +3 (3 degrees each);
+       * a delta replaces the current one only when its SAD is strictly smaller */
+      if (cfg->angle_delta && md.ymode >= V_PRED && md.ymode <= D67_PRED) {
+        static const int order[6] = { -1, 1, -2, 2, -3, 3 };
+        int k;
+        for (k = 0; k < 6; k++) {
+          int sad;
+          av1o_predict_intra(pred, n, bsl, md.ymode, order[k], edge_a, edge_l, avail_u, avail_l, bd);
+          sad = block_sad(src, e->src->stride[0], pred, n, n);
+          if (sad < best) { best = sad; md.yangle = order[k]; }
+        }
+      }
       md.uvmode = md.ymode;
+      md.uvangle = md.yangle;
       sad_intra = best;
     }
     /* ---- inter frames: motion-compensated prediction wins when its luma SAD is not larger */

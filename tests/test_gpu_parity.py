@@ -54,6 +54,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_cdef=cfgk.get("enable_cdef", 1))
         assert av1mi.cq_to_qindex(qidx // 4) == qidx
         p.intra_mode_mask = cfgk.get("mode_mask", 0)
+        p.intra_angle_delta = cfgk.get("angle_delta", 0)
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         p.enable_lr = cfgk.get("enable_lr", 0)
         if cfgk.get("deblock", 0) == 2:
@@ -350,7 +351,7 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
             continue   # (covered by test_sizes_that_are_not_multiples_of_8: fixtures here are generated full-size)
         p = av1mi.default_params(m["width"], m["height"], m["bit_depth"], block_log2=bs, keyint=240, me_range=cfgk.get("me_range", 8),
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0), deblock=cfgk.get("deblock", 0),
-                                 subpel=cfgk.get("subpel", 0))
+                                 subpel=cfgk.get("subpel", 0), intra_mode_mask=cfgk.get("mode_mask", 0), intra_angle_delta=cfgk.get("angle_delta", 0))
         if cfgk.get("enable_qm"):
             p.enable_qm, p.qm_min, p.qm_max = 1, cfgk["qm_y"], cfgk["qm_y"]
         frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
@@ -778,14 +779,16 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
             lr = 2   # RESTORE_SWITCHABLE
         if rng2.integers(0, 2) and bs == 5:
             bs = 6   # 64x64 leaves
+        ad = int(rng2.integers(0, 2))   # angle deltas
         big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=3000 + it, t=t) for t in range(n)]
         frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
         p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
-                                 enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb, deblock=db, subpel=sp, enable_qm=qm, qm_min=qmin, qm_max=qmax)
+                                 enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb, deblock=db, subpel=sp, enable_qm=qm, qm_min=qmin, qm_max=qmax,
+                                 intra_angle_delta=ad)
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
         qml = oracle.qm_level(av1mi.cq_to_qindex(cq), qmin, qmax)
         cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq), mode_mask=mask, deblock=db,
-                                    subpel=sp, enable_qm=qm, qm_y=qml, qm_uv=qml,
+                                    subpel=sp, enable_qm=qm, qm_y=qml, qm_uv=qml, angle_delta=ad,
                                     disable_cdf_update=0 if cdf else 1, me_range=me, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb,
                                     film_grain=1 if fg else 0, fg_y_scaling=2 * fg, fg_c_scaling=fg)
         tus, recs, ref, prev = [], [], None, None
@@ -796,7 +799,7 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
             tus.append(tu)
             recs.append(rec)
             ref, prev = rec, f
-        desc = dict(it=it, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db, sp=sp, qm=qm, qmin=qmin, qmax=qmax)
+        desc = dict(it=it, ad=ad, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db, sp=sp, qm=qm, qmin=qmin, qmax=qmax)
         assert list(sizes) == [len(t) for t in tus], desc
         assert data == b"".join(tus), desc
         fb = w * h * 3 // 2 * (2 if bd > 8 else 1)

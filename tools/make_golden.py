@@ -82,6 +82,11 @@ CASES = [
     ("k88x120_overhang_lr_deblock", 88, 120, 8, 73, 0, dict(min_bs_log2=5, max_bs_log2=5, deblock=1, enable_lr=1, cdef_y_sec=2, cdef_uv_sec=1)),
     ("fuzz_overhang_bs5", 216, 248, 10, 74, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_modes=74, fuzz_coeffs=74, fuzz_density=6, fuzz_maxlevel=30)),
     ("fuzz_overhang_bs6_onetile", 248, 184, 8, 75, 0, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=75, tile_w_sb=64, tile_h_sb=64, enable_lr=2)),
+    # angle deltas chosen by the mode decision (directional winners refined over -3 .. +3), all 13 candidates and the default three
+    ("k200x120_angle_all13", 200, 120, 8, 1080, 5, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, angle_delta=1)),
+    ("k248x184_angle_bs5_10b", 248, 184, 10, 81, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, angle_delta=1, deblock=1)),
+    ("k136_angle_dcvh_bs3", 136, 136, 8, 82, 1, dict(min_bs_log2=3, max_bs_log2=3, angle_delta=1)),
+    ("k184x176_angle_bs6", 184, 176, 8, 83, 2, dict(min_bs_log2=6, max_bs_log2=6, mode_mask=0x1FFF, angle_delta=1)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -126,6 +131,7 @@ SEQ_CASES = [
     ("p216x120_overhang_subpel_deblock_lr2_10b", 216, 120, 10, 77, 3, dict(min_bs_log2=5, max_bs_log2=5, subpel=1, deblock=1, enable_lr=2, me_range=16)),
     ("pfuzz_overhang_bs6_subpel", 184, 248, 8, 78, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=11, subpel=1)),
     ("pfuzz_overhang_bs5_onetile", 248, 184, 10, 79, 3, dict(min_bs_log2=5, max_bs_log2=5, fuzz_modes=13, tile_w_sb=64, tile_h_sb=64, deblock=1)),
+    ("p200x120_angle_all13", 200, 120, 8, 84, 3, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, angle_delta=1)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
