@@ -13,7 +13,8 @@ pub struct Av1miParams {            // include/av1mi.h: av1mi_params
     pub cdef_y_pri: u32, pub cdef_y_sec: u32, pub cdef_uv_pri: u32, pub cdef_uv_sec: u32, pub cdef_damping: u32,
     pub intra_mode_mask: u32, pub film_grain: u32, pub first_frame: u32, pub me_range: u32, pub enable_lr: u32, pub tile_sb: u32, pub deblock: u32,
     pub enable_qm: u32, pub qm_min: u32, pub qm_max: u32, pub subpel: u32,
-    pub reserved: [u32; 2],
+    pub color_range: u32,           // 0 = studio (default; a Y4M XCOLORRANGE tag wins), 1 = full
+    pub intra_angle_delta: u32,     // 1 = directional intra winners refined over the angle deltas -3..+3
 }
 #[repr(C)]
 pub struct Av1miJob {               // include/av1mi.h: av1mi_job  <->  Av1anEncodeParams (av1an.rs:36-45)
