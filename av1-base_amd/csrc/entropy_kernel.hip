@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles, const uin
 // the instructions per link of that chain matters more than anything else here.
 #define RC_BATCH 16
 struct RcLds {
-  uint64_t row[MAX_COMBOS * SLOTS_PER_COMBO][64];
+  uint64_t row[MAX_COMBOS * SLOTS_PER_COMBO + 1][64];   // + one dummy row: entries that need no resolving go through it, branch-free
   uint32_t ring[2][RC_BATCH][64];
 };
 __shared__ RcLds g_rc;
@@ -823,7 +823,6 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
   // ---- coder state
   uint32_t low = 0, rng = 0x8000;
   int cnt = -9, out_pos = 0;
-  uint32_t acc = 0;  // one buffered 16-bit entry
   // Output: "pre-carry" entries, one 16-bit value per output byte holding the byte and, in bit 8, a carry that still
   // has to be added to the bytes before it (od_ec's precarry buffer).  Nothing already written is ever touched here;
   // pack_tiles_kernel resolves the carries of a whole tile with a wave-parallel carry-lookahead when it copies the
@@ -832,13 +831,8 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
   const int out_cap = P.tile_slot_bytes;  // entries
 #define EMIT(v_)                                                                               \
   do {                                                                                         \
-    const unsigned ev = (v_) & 0x1FFu;                                                         \
-    acc |= ev << (16 * (out_pos & 1));                                                         \
+    if (out_pos < out_cap) out[out_pos] = (uint16_t)((v_) & 0x1FFu);                           \
     out_pos++;                                                                                 \
-    if ((out_pos & 1) == 0) {                                                                  \
-      if (out_pos <= out_cap) *reinterpret_cast<uint32_t *>(out + out_pos - 2) = acc;          \
-      acc = 0;                                                                                 \
-    }                                                                                          \
   } while (0)
 
   __syncthreads();
@@ -871,24 +865,25 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
 #pragma unroll
           for (int jj = 0; jj < 4; jj++) {
             uint32_t ent = jj == 0 ? q.x : (jj == 1 ? q.y : (jj == 2 ? q.z : q.w));
-            if (i0 + jj < count && !(ent & 0x80000000u)) {
-              const int slot = (ent >> 2) & 0x1FF, s = ent & 3;
-              const uint64_t rw = g_rc.row[slot][lane];
-              const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
-              // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): 16-bit fields of the row
-              const uint64_t cdf48 = rw & 0x0000FFFFFFFFFFFFull;
-              const uint32_t fh = s == 3 ? 0u : (uint32_t)(cdf48 >> (16 * s)) & 0xFFFFu;
-              const uint32_t fl = s == 0 ? 32768u : (uint32_t)(cdf48 >> (16 * (s - 1))) & 0xFFFFu;
-              ent = ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s);
-              if (adapt) {
-                const uint32_t cn = c2n >> 16;
-                const int rate = 5 + (cn > 15) + (cn > 31);
-                const uint32_t c0 = c01 & 0xFFFF, c1 = c01 >> 16, c2 = c2n & 0xFFFF;
-                const uint32_t n0 = 0 < s ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
-                const uint32_t n1 = 1 < s ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
-                const uint32_t n2 = 2 < s ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
-                g_rc.row[slot][lane] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | ((cn + (cn < 32)) << 16)) << 32);
-              }
+            // No branch: an entry that is already resolved (or lies beyond this tile's count) runs the same instructions against the
+            // dummy row and keeps its value - with 64 tiles per wave both kinds are present in almost every step anyway, and the
+            // exec-mask bookkeeping of a divergent `if` was a sixth of the resolver's instructions.
+            const bool nar = i0 + jj < count && !(ent & 0x80000000u);
+            const int slot = nar ? (int)((ent >> 2) & 0x1FF) : MAX_COMBOS * SLOTS_PER_COMBO, s = ent & 3;
+            const uint64_t rw = g_rc.row[slot][lane];
+            const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
+            const uint32_t c0 = c01 & 0xFFFF, c1 = c01 >> 16, c2 = c2n & 0xFFFF;
+            // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3)
+            const uint32_t fh = s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : 0u));
+            const uint32_t fl = s == 0 ? 32768u : (s == 1 ? c0 : (s == 2 ? c1 : c2));
+            ent = nar ? ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s) : ent;
+            if (adapt) {
+              const uint32_t cn = c2n >> 16;
+              const int rate = 5 + (cn > 15) + (cn > 31);
+              const uint32_t n0 = 0 < s ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
+              const uint32_t n1 = 1 < s ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
+              const uint32_t n2 = 2 < s ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
+              g_rc.row[slot][lane] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | ((cn + (cn < 32)) << 16)) << 32);
             }
             g_rc.ring[k & 1][j + jj][lane] = ent;
           }
@@ -904,8 +899,9 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
           // range update (od_ec_encode_q15, the mirror of spec §8.2.6), branch-free: fl6 == 512 <=> s == 0
           uint32_t l = low, r = rng;
           const uint32_t r8 = r >> 8;
-          const uint32_t v = ((r8 * fh6) >> 1) + 4u * ns;
-          const uint32_t u = fl6 >= 512 ? r : ((r8 * fl6) >> 1) + 4u * ns + 4u;
+          // (r8 < 2^8, fl6 / fh6 <= 512: 24-bit multiplies, full rate)
+          const uint32_t v = (__umul24(r8, fh6) >> 1) + 4u * ns;
+          const uint32_t u = fl6 >= 512 ? r : (__umul24(r8, fl6) >> 1) + 4u * ns + 4u;
           l += r - u;
           r = u - v;
           const int d = __builtin_clz(r) - 16;
@@ -947,7 +943,6 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
           n >>= 8;
         } while (s > 0);
       }
-      if ((out_pos & 1) && out_pos + 1 <= out_cap) *reinterpret_cast<uint32_t *>(out + out_pos - 1) = acc;
     }
     if (live) tile_bytes[tile] = overflow ? 0xFFFFFFFFu : (uint32_t)out_pos;
   }
