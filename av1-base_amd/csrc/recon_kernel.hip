@@ -91,7 +91,35 @@ struct SbLds {
   int eobs[4];                  // eob of the current block's Y, U, V transform blocks
 };
 __shared__ SbLds g_sb;
-#define S (&g_sb)
+__shared__ SbLds g_sb_c;   // the chroma wave's block state in a split tile walk (referenced - and allocated - only there)
+// WV: 0 = the wave does luma and chroma of a block in turn; a SPLIT tile walk is a workgroup of two waves - 1 = its luma wave
+// (takes the decisions and posts them), 2 = its chroma wave (follows one decision behind, on LDS of its own)
+template <int WV> struct SbSel { static __device__ __forceinline__ SbLds *get() { return &g_sb; } };
+template <> struct SbSel<2> { static __device__ __forceinline__ SbLds *get() { return &g_sb_c; } };
+#define S (SbSel<WV>::get())
+// luma wave -> chroma wave, per leaf block (index = superblock-in-tile * 64 + Z index of the block's first 8x8 unit):
+// dec = Q_VALID | the decision as tx_item returns it, posted the moment it is taken; e0 = Q_VALID | the luma eob, when the luma
+// block is finished (the chroma wave writes the block-info entry, which holds both)
+struct SplitQueue { int dec[4 * 64]; int e0[4 * 64]; };
+__shared__ SplitQueue g_q;
+#define Q_VALID 0x40000000
+__device__ __forceinline__ int q_wait(const int *slot) {
+  int v;
+  while (!((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & Q_VALID)) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return __builtin_amdgcn_readfirstlane(v) & (Q_VALID - 1);
+}
+__device__ __forceinline__ void q_post(int *slot, int v) {
+  __hip_atomic_store(slot, v | Q_VALID, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Ordering between the lanes of ONE wave that exchange data through LDS: the wave's LDS operations complete in order, so
+// waiting for them is all a "barrier" has to do.  (__syncthreads() would be a barrier of the whole workgroup, and the two waves
+// of a split tile walk do not run the same number of them.)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // ---- diagnostic build only (-DAV1MI_STAMPS, tools/stamp_recon.py): where a transform item spends its cycles.  Lane 0 adds the
 // s_memtime difference of every phase to LDS sums per item class; the wave adds them to g_stamp_sum when it ends.  The
@@ -122,6 +150,9 @@ struct McLds {
   int16_t mid[(MAXN + 7) * MAXN];
 };
 __shared__ McLds g_mc;
+__shared__ McLds g_mc_c;   // chroma wave of a split tile walk
+template <int WV> struct McSel { static __device__ __forceinline__ McLds &get() { return g_mc; } };
+template <> struct McSel<2> { static __device__ __forceinline__ McLds &get() { return g_mc_c; } };
 __constant__ int16_t c_subpel[2][16][8] = AV1_SUBPEL_FILTERS_INIT;  // EIGHTTAP, and its 4-tap form for 4-sample blocks
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -191,7 +222,7 @@ __device__ __forceinline__ int scan_index(int row, int col, int n) {
 
 // ---- intra prediction of one pixel (spec §7.11.2, no edge filter / upsampling) -------------------
 // A = edge_a + 1 (+ group offset), L likewise (index -1 valid); dx/dy = Dr_Intra_Derivative values.
-template <int LOG2N>
+template <int LOG2N, int WV>
 __device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int ang, int dx, int dy, int eo) {
   constexpr int N = 1 << LOG2N;
   const uint16_t *A = S->edge_a + 1 + eo, *L = S->edge_l + 1 + eo;
@@ -280,12 +311,12 @@ __device__ __forceinline__ int mc_sample(const PIX *plane, int stride, int last_
 // reference, not compound): the (N + 7)^2 reference window (coordinates clamped to the signalled frame) is staged in
 // LDS once, horizontal pass -> Round2 by 3 -> 16-bit intermediate, vertical pass -> Round2 by 11 -> clamp.  Writes the
 // prediction of lane group `grp` into dst[0 .. N*N).  px0 / py0: position of the block's first sample in 1/16 samples.
-template <typename PIX, int LOG2N, int NPL>
+template <typename PIX, int LOG2N, int NPL, int WV>
 __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int last_x, int last_y, int px0, int py0, int maxv,
                                               int grp, int sl, uint16_t *dst) {
   constexpr int N = 1 << LOG2N, WN = N + 7, G = 64 / NPL;
-  uint16_t *win = g_mc.win + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 39 + 3 : 23 * 23 + 3));
-  int16_t *mid = g_mc.mid + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 32 : 23 * 16));
+  uint16_t *win = McSel<WV>::get().win + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 39 + 3 : 23 * 23 + 3));
+  int16_t *mid = McSel<WV>::get().mid + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 32 : 23 * 16));
   const int ix0 = (px0 >> 4) - 3, iy0 = (py0 >> 4) - 3;
   const int16_t *fh = c_subpel[N <= 4][px0 & 15], *fv = c_subpel[N <= 4][py0 & 15];
   {  // all loads of the window in flight together (a loop of dependent load -> LDS store pairs paid the latency 24 times)
@@ -302,7 +333,7 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
 #pragma unroll
     for (int k = 0; k < K; k++) { const int p = sl + k * G; if (p < WN * WN) win[p] = (uint16_t)v[k]; }
   }
-  __syncthreads();
+  wave_sync();
   for (int p = sl; p < WN * N; p += G) {
     const int r = p >> LOG2N, c = p & (N - 1);
     const uint16_t *wp = win + r * WN + c;
@@ -311,7 +342,7 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
     for (int t = 0; t < 8; t++) sum += fh[t] * (int)wp[t];
     mid[p] = (int16_t)((sum + 4) >> 3);
   }
-  __syncthreads();
+  wave_sync();
   for (int p = sl; p < N * N; p += G) {
     const int r = p >> LOG2N, c = p & (N - 1);
     int sum = 0;
@@ -320,7 +351,7 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
     const int v = (sum + 1024) >> 11;
     dst[p] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // One transform block per lane GROUP.  NPL = 1: the whole wave works on one block of `plane0` (luma,
@@ -344,9 +375,10 @@ __device__ __forceinline__ T *uniform_p(T *p) {
   const unsigned long long a = (unsigned long long)p;
   return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
-template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM, int PH>
+template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM, int PH, int WV>
 __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
-                                                 int mode_io, InterInfo ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out) {
+                                                 int mode_io, InterInfo ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out, int post_idx) {
+  post_idx = uniform_i(post_idx);
   cx.P = uniform_p(cx.P); cx.sb_x = uniform_i(cx.sb_x); cx.sb_y = uniform_i(cx.sb_y); cx.tox = uniform_i(cx.tox); cx.toy = uniform_i(cx.toy);
   frame = uniform_p(frame); rec_frame = uniform_p(rec_frame); plane0 = uniform_i(plane0); x0 = uniform_i(x0); y0 = uniform_i(y0);
   mode_io = uniform_i(mode_io); lv_out0 = uniform_p(lv_out0); lv_out1 = uniform_p(lv_out1); eob_out = uniform_p(eob_out);
@@ -401,7 +433,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       }
       for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
       if (sl == 0) eob_out[grp] = plane == 0 ? ii.pre_eob[0] : (plane == 1 ? ii.pre_eob[1] : ii.pre_eob[2]);   // (no dynamic index: the array stays in registers)
-      __syncthreads();
+      wave_sync();
     }
   };
   if constexpr (PH == 2) {
@@ -455,7 +487,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
     if (lane < N) S->smw[lane] = c_sm_weights[WOFF + lane];
   }
-  __syncthreads();
+  wave_sync();
   STAMP(0);   // source -> LDS, edges from the line buffers
   // ---- DC value (sum within the lane group)
   {
@@ -467,7 +499,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     else dcv = 1 << (bd - 1);
   }
   } else {
-    __syncthreads();
+    wave_sync();
   }
   // ---- mode decision (luma) + final prediction: one loop, the last trip writes the prediction
   // mode_io: bits 0-3 the mode, bits 4-6 the angle delta + 3 (chroma passes follow the luma decision; luma passes decide)
@@ -519,13 +551,16 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
           int sad = 0;
 #pragma unroll 4
           for (int p = sl; p < N * N; p += G)
-            sad += iabs((int)S->srcblk[po + p] - pred_pixel<LOG2N>(best_mode, p >> LOG2N, p & (N - 1), dcv, ang, dx, dy, eo));
+            sad += iabs((int)S->srcblk[po + p] - pred_pixel<LOG2N, WV>(best_mode, p >> LOG2N, p & (N - 1), dcv, ang, dx, dy, eo));
           sad = wave_sum(sad);
           if (sad < best_sad) { best_sad = sad; best_delta = delta; }
         }
       }
       // inter frames: motion compensation wins when its luma SAD is not larger
       if (INTER) ii.is_inter = ii.sad_inter <= best_sad;
+      if constexpr (WV == 1) {   // split walk: the chroma wave starts on this block now
+        if (lane == 0) q_post(&g_q.dec[post_idx], ((INTER ? ii.is_inter : 0) << 8) | ((best_delta + 3) << 4) | best_mode);
+      }
       if constexpr (PH == 2) {
         if (ii.is_inter) { inter_done(); return (1 << 8) | (3 << 4) | best_mode; }
       }
@@ -538,7 +573,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         const int ss = plane0 > 0;
         const int px0 = (gx << 4) + ((2 * ii.mv_col) >> ss), py0 = (gy << 4) + ((2 * ii.mv_row) >> ss);
         if ((px0 | py0) & 15) {
-          mc_block_8tap<PIX, LOG2N, NPL>(static_cast<const PIX *>(ii.ref) + poff, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
+          mc_block_8tap<PIX, LOG2N, NPL, WV>(static_cast<const PIX *>(ii.ref) + poff, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
                                          px0, py0, (1 << bd) - 1, grp, sl, S->blkpix + po);
           mc_in_lds = true;
         }
@@ -560,7 +595,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         pv = mc_sample<PIX>(rp, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
                             ((gx + c) << 4) + ((2 * ii.mv_col) >> ss), ((gy + r) << 4) + ((2 * ii.mv_row) >> ss), (1 << bd) - 1);
       } else {
-        pv = pred_pixel<LOG2N>(mode, r, c, dcv, ang, dx, dy, eo);
+        pv = pred_pixel<LOG2N, WV>(mode, r, c, dcv, ang, dx, dy, eo);
       }
       const int sv = S->srcblk[po + p];
       if (final_trip) {
@@ -576,7 +611,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       else if (sad < best_sad) { best_sad = sad; best_mode = m; }
     }
   }
-  __syncthreads();
+  wave_sync();
   STAMP(2);   // other candidates, decision, prediction + residual
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
   const int txt = (LOG2N <= 4 && !(INTER && ii.is_inter)) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
@@ -596,7 +631,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
 #pragma unroll
     for (int i = 0; i < CW; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
   }
-  __syncthreads();
+  wave_sync();
   STAMP(3);   // forward columns
   int my_key = -1;  // (anti-diagonal << 6 | position inside it) of the last nonzero level in scan order
   int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk) + po;  // source block is dead: reuse for the levels
@@ -655,7 +690,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
 #pragma unroll
     for (int j = 0; j < N; j++) S->scratch[so + sl * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
   }
-  __syncthreads();
+  wave_sync();
   STAMP(4);   // forward rows, quantiser, dequantiser, eob, inverse rows
   if (tx_lane && eob) {
     const int maxv = (1 << bd) - 1;
@@ -673,7 +708,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     uint32_t *d32 = reinterpret_cast<uint32_t *>(grp ? lv_out1 : lv_out0);
     for (int i = sl; i < WORDS; i += G) d32[i] = (uint32_t)(uint16_t)lvl[2 * i] | ((uint32_t)(uint16_t)lvl[2 * i + 1] << 16);
   }
-  __syncthreads();
+  wave_sync();
   STAMP(5);   // inverse columns, levels -> HBM
   // ---- reconstruction -> HBM (coalesced rows) and -> line buffers for the neighbours to come
   {
@@ -697,7 +732,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
   }
   if (sl == 0) eob_out[grp] = eob;
-  __syncthreads();
+  wave_sync();
   STAMP(6);   // reconstruction -> HBM, line buffers, decoded-block map
   return ((INTER ? ii.is_inter : 0) << 8) | ((best_delta + 3) << 4) | best_mode;
 }
@@ -722,11 +757,14 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
   return 0;
 }
 
-template <typename PIX, bool INTER, int TSB, bool QM>
+template <typename PIX, bool INTER, int TSB, bool QM, bool SPLIT>
 __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
                                                   Av1miBlkInfo *info, int b8_stride, const PIX *ref_frame,
-                                                  const unsigned long long *me_best /* this superblock's first unit */) {
+                                                  const unsigned long long *me_best /* this superblock's first unit */, int si) {
   const Av1miDevParams &P = *cx.P;
+  // SPLIT: wave 0 of the workgroup walks the luma blocks (and takes the decisions), wave 1 the chroma blocks
+  constexpr int WL = SPLIT ? 1 : 0, WC = SPLIT ? 2 : 0;
+  const int wv = SPLIT ? uniform_i((int)threadIdx.x >> 6) : 0;
 #pragma nounroll
   for (int z = 0; z < 64; z++) {  // 8x8 units in Z (partition) order
     const int bx = (((z >> 0) & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) << 3;
@@ -735,6 +773,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
     if (bsl == 0) continue;
     const int n = 1 << bsl;
+    const int qi = si * 64 + z;
     int mode = 3 << 4;   // (mode | (angle delta + 3) << 4)
     InterInfo ii;
     ii.ref = ref_frame; ii.is_inter = 0; ii.mv_row = ii.mv_col = 0; ii.sad_inter = 0;
@@ -757,29 +796,40 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
     int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
     // luma (mode decision inside), then U and V together
-    int dec;
-    switch (bsl) {
+    int dec = 0;
+    if (!SPLIT || wv == 0) {
+      int *eo = SbSel<WL>::get()->eobs;
+      switch (bsl) {
 #if AV1MI_RECON_BIG
-      case 6: dec = tx_item<PIX, 6, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+        case 6: dec = tx_item<PIX, 6, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
 #endif
-      case 5: dec = tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      case 4: dec = tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-      default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+        case 5: dec = tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
+        case 4: dec = tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
+        default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
+      }
+      dec = uniform_i(dec);
+      if (SPLIT) {   // the luma block is finished: its eob for the block-info entry, which the chroma wave writes
+        if (cx.lane == 0) q_post(&g_q.e0[qi], eo[0]);
+        continue;
+      }
+    } else {
+      dec = q_wait(&g_q.dec[qi]);
     }
-    dec = uniform_i(dec);
     mode = dec & 0x7F; ii.is_inter = dec >> 8;   // the luma pass decides (mode and angle delta); the chroma pass follows it
+    int *eo = SbSel<WC>::get()->eobs;
     switch (bsl) {
 #if AV1MI_RECON_BIG
-      case 6: tx_item<PIX, 5, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 6: tx_item<PIX, 5, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
 #endif
-      case 5: tx_item<PIX, 4, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      case 4: tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-      default: tx_item<PIX, 2, 2, INTER, TSB, QM, (INTER ? 2 : 0)>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+      case 5: tx_item<PIX, 4, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
+      case 4: tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
+      default: tx_item<PIX, 2, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
     }
     {  // the block's info into every 8x8 unit it covers: one lane per unit
       const int n8 = n >> 3;
+      const int e0 = SPLIT ? q_wait(&g_q.e0[qi]) : eo[0];
       if (cx.lane < n8 * n8) {
-        const int e0 = S->eobs[0], e1 = S->eobs[1], e2 = S->eobs[2];
+        const int e1 = eo[1], e2 = eo[2];
         const int i = cx.lane / n8, j = cx.lane - i * n8;
         Av1miBlkInfo bi;
         const bool unit_inside = cx.sb_y + by + 8 * i < P.height && cx.sb_x + bx + 8 * j < P.width;   // an overhanging block's units beyond the frame have no entry
@@ -793,8 +843,14 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
   }
 }
 
+// The tile walk of an inter frame is SPLIT (two waves per tile, see encode_superblock): its duration is the chain of the tile with
+// most intra-coded blocks, and the chroma blocks were 45 % of that chain.
+#ifndef AV1MI_SPLIT_INTRA
+#define AV1MI_SPLIT_INTRA 0
+#endif
+template <bool INTER> struct WalkSplit { static constexpr bool value = INTER || AV1MI_SPLIT_INTRA; };
 template <typename PIX, bool INTER, int TSB, bool QM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : 4, AV1MI_RECON_BIG ? 2 : 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
+__global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : 4, AV1MI_RECON_BIG ? 2 : 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
                                                      const unsigned long long *__restrict__ me_best) {
@@ -803,6 +859,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
   // structure (0.6 KB) to scratch at the start of the kernel and read its fields back from there.  Loads through a
   // uniform const pointer are scalar loads.
   const Av1miDevParams &P = *Pd;
+  constexpr bool SPLIT = WalkSplit<INTER>::value;
+  if constexpr (SPLIT) {
+    for (int t = threadIdx.x; t < TSB * TSB * 64; t += 128) { g_q.dec[t] = 0; g_q.e0[t] = 0; }
+  }
 #ifdef AV1MI_STAMPS
   if (threadIdx.x < STAMP_CLASSES * STAMP_PHASES) g_stamp.acc[threadIdx.x] = 0;
   const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
@@ -822,8 +882,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
     if (sbr >= P.sb_rows || sbc >= P.sb_cols) continue;
     const int sb = sbr * P.sb_cols + sbc;
     SbCtx cx;
-    cx.P = Pd; cx.lane = threadIdx.x; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
+    cx.P = Pd; cx.lane = threadIdx.x & 63; cx.sb_x = sbc * 64; cx.sb_y = sbr * 64;
     cx.tox = (si % TSB) * 64; cx.toy = (si / TSB) * 64;
+    SbLds *const sbl = (SPLIT && threadIdx.x >= 64) ? SbSel<2>::get() : SbSel<0>::get();   // each wave of a split walk keeps a map of its own
     // decoded-block map (clear_block_decoded_flags, spec §5.11.3): the row above and the column left of the superblock
     // are decoded as far as the TILE reaches (so the above-right superblock of a two-superblock tile counts)
     __syncthreads();
@@ -839,15 +900,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
           else if (x < 0 && y < sh) v = 1;
           if (y == sz && x == -1) v = 0;
         }
-        S->blkdec[pl][y + 1][x + 1] = (uint8_t)v;
+        sbl->blkdec[pl][y + 1][x + 1] = (uint8_t)v;
       }
     }
     __syncthreads();
     int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
     Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
     // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
-    encode_superblock<PIX, INTER, TSB, QM>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
-                                           me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr);
+    encode_superblock<PIX, INTER, TSB, QM, SPLIT>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
+                                                  me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr, si);
   }
 #ifdef AV1MI_STAMPS
   __syncthreads();
@@ -904,28 +965,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
       if (blockIdx.z == 0) {
         switch (bsl) {
 #if AV1MI_RECON_BIG
-          case 6: tx_item<PIX, 6, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+          case 6: tx_item<PIX, 6, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
 #endif
-          case 5: tx_item<PIX, 5, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-          case 4: tx_item<PIX, 4, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
-          default: tx_item<PIX, 3, 1, true, 1, QM, 1>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, S->eobs); break;
+          case 5: tx_item<PIX, 5, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          case 4: tx_item<PIX, 4, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          default: tx_item<PIX, 3, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
         }
-        if (threadIdx.x == 0) bi->eob[0] = (uint16_t)S->eobs[0];
+        if (threadIdx.x == 0) bi->eob[0] = (uint16_t)g_sb.eobs[0];
       } else {
         switch (bsl) {
 #if AV1MI_RECON_BIG
-          case 6: tx_item<PIX, 5, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+          case 6: tx_item<PIX, 5, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
 #endif
-          case 5: tx_item<PIX, 4, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-          case 4: tx_item<PIX, 3, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
-          default: tx_item<PIX, 2, 2, true, 1, QM, 1>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, S->eobs + 1); break;
+          case 5: tx_item<PIX, 4, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          case 4: tx_item<PIX, 3, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          default: tx_item<PIX, 2, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
         }
-        if (threadIdx.x == 0) { bi->eob[1] = (uint16_t)S->eobs[1]; bi->eob[2] = (uint16_t)S->eobs[2]; }
+        if (threadIdx.x == 0) { bi->eob[1] = (uint16_t)g_sb.eobs[1]; bi->eob[2] = (uint16_t)g_sb.eobs[2]; }
       }
     }
 }
-#undef S
-
 }  // namespace
 
 #if defined(AV1MI_STAMPS) && !AV1MI_RECON_BIG
@@ -966,9 +1025,9 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
   // quantiser matrices (P->qm_tab): kernels of their own, so the plain quantiser's registers and scratch are what they were
 #define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \
   do {                                                                                                                                      \
-    if (P->qm_tab) hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, true>), dim3(grid), dim3(64), 0, stream, dP, (const PIXT *)src,  \
+    if (P->qm_tab) hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, true>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,  \
                                       (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                \
-    else hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, false>), dim3(grid), dim3(64), 0, stream, dP, (const PIXT *)src,           \
+    else hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, false>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,           \
                             (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                          \
   } while (0)
   if (P->bit_depth == 8) {
