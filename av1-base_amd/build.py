@@ -13,7 +13,12 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libav1mi.so")
 OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["recon_kernel.hip", "recon64_kernel.hip", "entropy_kernel.hip", "cdef_pack_kernels.hip", "scene_kernels.hip", "me_kernel.hip", "lr_kernel.hip", "deblock_kernel.hip", "av1mi_host.cpp", "av1mi_file.cpp", "av1mi_exec.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-missing-braces", "-Wno-pass-failed"]
+# -fno-optimize-sibling-calls: keeps LLVM from marking the calls of the `noinline` transform items `tail`.  With the marker the
+# backend's interprocedural register allocation treats the items as ordinary ABI functions that save and restore every
+# callee-saved VGPR they touch - 33 stores + 29 loads of 256 B per call, 60 % of the reconstruction kernel's HBM traffic
+# (profiles/r02_a_pmc_intra.txt vs r02_c); without it the items save nothing and their callers keep nothing in those registers.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-optimize-sibling-calls", "-Wall", "-Wno-unused-function", "-Wno-missing-braces",
+         "-Wno-pass-failed"]
 
 
 def _newer(target, deps):

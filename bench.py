@@ -362,7 +362,12 @@ def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, b
     # a job of `world` scene-chunks, one per GPU: this rank's chunk by the product's own placement rule (av1mi_chunk_owner)
     mine = av1mi.chunks_of_rank(world, world, rank)
     assert len(mine) == 1, mine
-    d_frames = make_clip_torch(w, h, bd, n, a["seed"] + mine[0], dev)   # HBM-resident input
+    if os.environ.get("AV1MI_BENCH_CLIP_ON_CPU"):
+        # counter-collection runs (rocprofv3 --pmc): torch's own GPU kernels crash under the profiler's counter service on this
+        # image, so the same generator runs on the CPU device and the clip is copied over - no kernel but the library's is launched
+        d_frames = make_clip_torch(w, h, bd, n, a["seed"] + mine[0], "cpu").to(dev)
+    else:
+        d_frames = make_clip_torch(w, h, bd, n, a["seed"] + mine[0], dev)   # HBM-resident input
     torch.cuda.synchronize(dev)
     params = av1mi.default_params(w, h, bd, block_log2=a["block_log2"], cdf_update=0 if a["static_cdf"] else 1, keyint=a["keyint"],
                                   me_range=a["me_range"], cq_level=a["cq"], film_grain=a["film_grain"],
