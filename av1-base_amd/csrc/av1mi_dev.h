@@ -39,6 +39,7 @@ struct Av1miDevParams {
   int min_bs_log2, max_bs_log2;
   uint32_t mode_mask;
   int angle_delta;          // 1: directional winners of the luma mode decision are refined over the angle deltas -3 .. +3
+  int edge_filter;          // enable_intra_edge_filter
   int enable_cdef, cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping;
   int disable_cdf_update;
   // plane geometry in samples

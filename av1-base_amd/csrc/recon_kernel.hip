@@ -73,6 +73,9 @@ struct LineLds {
   uint16_t above[3][64 * TSB];
   uint16_t left[3][64 * TSB];
   uint16_t corner[3][16 * TSB + 1][16 * TSB + 1];
+  // intra edge filter (get_filter_type, spec 7.11.2.8): [luma | chroma][8x8-luma unit of the tile] = the last block reconstructed over
+  // that column / beside that row was predicted with a smooth mode
+  uint8_t sm_above[2][8 * TSB], sm_left[2][8 * TSB];
 };
 __shared__ LineLds<1> g_lines1;
 __shared__ LineLds<2> g_lines2;
@@ -220,12 +223,47 @@ __device__ __forceinline__ int scan_index(int row, int col, int n) {
   return before + ((d & 1) ? row - lo : col - lo);
 }
 
-// ---- intra prediction of one pixel (spec §7.11.2, no edge filter / upsampling) -------------------
-// A = edge_a + 1 (+ group offset), L likewise (index -1 valid); dx/dy = Dr_Intra_Derivative values.
+// ---- intra edge filter helpers (spec 7.11.2.9 strength selection, 7.11.2.10 upsample selection; w = h = n)
+__device__ __forceinline__ int ef_strength(int wh, int type, int delta) {
+  const int d = delta < 0 ? -delta : delta;
+  int s = 0;
+  if (type == 0) {
+    if (wh <= 8) { if (d >= 56) s = 1; }
+    else if (wh <= 16) { if (d >= 40) s = 1; }
+    else if (wh <= 24) { if (d >= 8) s = 1; if (d >= 16) s = 2; if (d >= 32) s = 3; }
+    else if (wh <= 32) { if (d >= 1) s = 1; if (d >= 4) s = 2; if (d >= 32) s = 3; }
+    else { if (d >= 1) s = 3; }
+  } else {
+    if (wh <= 8) { if (d >= 40) s = 1; if (d >= 64) s = 2; }
+    else if (wh <= 16) { if (d >= 20) s = 1; if (d >= 48) s = 2; }
+    else if (wh <= 24) { if (d >= 4) s = 3; }
+    else { if (d >= 1) s = 3; }
+  }
+  return s;
+}
+__device__ __forceinline__ int ef_use_upsample(int wh, int type, int delta) {
+  const int d = delta < 0 ? -delta : delta;
+  if (d <= 0 || d >= 40) return 0;
+  return type ? wh <= 8 : wh <= 16;
+}
+// one filtered edge element (7.11.2.12): R[k] = raw element k (k >= 0), `corner` = element -1 (after the corner filter); i = the element
+// (-1 .. ), sz = number of elements the filter covers counted from element -1
+__device__ __forceinline__ int ef_element(const uint16_t *R, int corner, int i, int sz, int strength) {
+  const int ii = i + 1;
+  if (i < 0) return corner;
+  if (strength == 0 || ii >= sz) return R[i];
+  const int k0 = strength == 3 ? 2 : 0, k1 = strength == 2 ? 5 : 4, k2 = strength == 1 ? 8 : (strength == 2 ? 6 : 4);
+  auto E = [&](int k) { k = k < 0 ? 0 : (k > sz - 1 ? sz - 1 : k); return k == 0 ? corner : (int)R[k - 1]; };
+  return (k0 * (E(ii - 2) + E(ii + 2)) + k1 * (E(ii - 1) + E(ii + 1)) + k2 * E(ii) + 8) >> 4;
+}
+
+// ---- intra prediction of one pixel (spec §7.11.2) -------------------
+// A / L = the above / left edge with index -1 valid (-2 when upsampled): the block's raw edges, or for a directional mode under
+// enable_intra_edge_filter the filtered (and, up_a / up_l, upsampled) copies; dx/dy = Dr_Intra_Derivative values.
 template <int LOG2N, int WV>
-__device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int ang, int dx, int dy, int eo) {
+__device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int ang, int dx, int dy, const uint16_t *A, const uint16_t *L,
+                                          int up_a, int up_l) {
   constexpr int N = 1 << LOG2N;
-  const uint16_t *A = S->edge_a + 1 + eo, *L = S->edge_l + 1 + eo;
   switch (mode) {
     case DC_PRED: return dcval;
     case PAETH_PRED: {
@@ -251,23 +289,24 @@ __device__ __forceinline__ int pred_pixel(int mode, int r, int c, int dcval, int
       if (ang == 180) return L[r];
       if (ang < 90) {
         int idx = (r + 1) * dx;
-        int base = (idx >> 6) + c, sh = (idx >> 1) & 31;
-        if (base < 2 * N - 1) return (A[base] * (32 - sh) + A[base + 1] * sh + 16) >> 5;
-        return A[2 * N - 1];
+        int base = (idx >> (6 - up_a)) + (c << up_a), sh = ((idx << up_a) >> 1) & 31;
+        const int max_base = (2 * N - 1) << up_a;
+        if (base < max_base) return (A[base] * (32 - sh) + A[base + 1] * sh + 16) >> 5;
+        return A[max_base];
       } else if (ang < 180) {
         int idx = (c << 6) - (r + 1) * dx;
-        int base = idx >> 6;
-        if (base >= -1) {
-          int sh = (idx >> 1) & 31;
+        int base = idx >> (6 - up_a);
+        if (base >= -(1 << up_a)) {
+          int sh = ((idx << up_a) >> 1) & 31;
           return (A[base] * (32 - sh) + A[base + 1] * sh + 16) >> 5;
         }
         idx = (r << 6) - (c + 1) * dy;
-        base = idx >> 6;
-        int sh = (idx >> 1) & 31;
+        base = idx >> (6 - up_l);
+        int sh = ((idx << up_l) >> 1) & 31;
         return (L[base] * (32 - sh) + L[base + 1] * sh + 16) >> 5;
       } else {
         int idx = (c + 1) * dy;
-        int base = (idx >> 6) + r, sh = (idx >> 1) & 31;
+        int base = (idx >> (6 - up_l)) + (r << up_l), sh = ((idx << up_l) >> 1) & 31;
         return (L[base] * (32 - sh) + L[base + 1] * sh + 16) >> 5;
       }
     }
@@ -432,6 +471,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = (uint16_t)pl[(size_t)(gy + (q < ph_lim ? q : ph_lim - 1)) * gs + gx + cb];
       }
       for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
+      if (lane < (plane0 ? N >> 2 : N >> 3)) { LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = 0; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = 0; }
       if (sl == 0) eob_out[grp] = plane == 0 ? ii.pre_eob[0] : (plane == 1 ? ii.pre_eob[1] : ii.pre_eob[2]);   // (no dynamic index: the array stays in registers)
       wave_sync();
     }
@@ -514,6 +554,57 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       else if (ang > 180) dy = c_dr_deriv[270 - ang];
     }
   };
+  // enable_intra_edge_filter (spec 7.11.2.7 - 7.11.2.12): a directional candidate at an angle other than 90 / 180 predicts from a
+  // filtered - and, for blocks up to 8x8, upsampled - copy of the edges.  The copy lives in the transform staging area (free
+  // until the residual is written); element i of the above edge at FA[i], i = -2 .. , left edge at FL[i].
+  int ef_type = 0;   // get_filter_type(): a neighbour predicted with a smooth mode
+  if constexpr (PH != 1) {
+    if (P->edge_filter) {
+      const int ux = lx >> (plane0 ? 2 : 3), uy = ly >> (plane0 ? 2 : 3);
+      ef_type = uniform_i((have_above && LN.sm_above[pc][ux]) || (have_left && LN.sm_left[pc][uy]));
+    }
+  }
+  constexpr int FEL = N >= 64 ? 136 : 72;
+  uint16_t *const FA = reinterpret_cast<uint16_t *>(S->scratch + so) + 2, *const FL = FA + FEL;
+  auto dir_edges = [&](int ang, const uint16_t *&A, const uint16_t *&L, int &up_a, int &up_l) -> bool {
+    A = S->edge_a + 1 + eo; L = S->edge_l + 1 + eo; up_a = 0; up_l = 0;
+    if (PH == 1 || !P->edge_filter || ang == 0 || ang == 90 || ang == 180) return false;
+    const uint16_t *RA = A, *RL = L;
+    const int n_top = N < pw_lim ? N : pw_lim, n_left = N < ph_lim ? N : ph_lim;
+    int corner = RA[-1];
+    if (ang > 90 && ang < 180 && 2 * N >= 24) corner = (RL[0] * 5 + corner * 6 + RA[0] * 5 + 8) >> 4;   // 7.11.2.7
+    const int st_a = have_above ? ef_strength(2 * N, ef_type, ang - 90) : 0, st_l = have_left ? ef_strength(2 * N, ef_type, ang - 180) : 0;
+    const int sz_a = n_top + (ang < 90 ? N : 0) + 1, sz_l = n_left + (ang > 180 ? N : 0) + 1;
+    wave_sync();   // the previous candidate's reads of FA / FL are done
+    for (int i = sl - 1; i < 2 * N; i += G) {
+      FA[i] = (uint16_t)ef_element(RA, corner, i, sz_a, st_a);
+      FL[i] = (uint16_t)ef_element(RL, corner, i, sz_l, st_l);
+    }
+    wave_sync();
+    if constexpr (N <= 8) {   // 7.11.2.11: one lane per source element, at most 16 of them
+      up_a = ef_use_upsample(2 * N, ef_type, ang - 90); up_l = ef_use_upsample(2 * N, ef_type, ang - 180);
+      if (up_a | up_l) {
+        const int maxv = (1 << bd) - 1;
+        const int npa = N + (ang < 90 ? N : 0), npl = N + (ang > 180 ? N : 0);
+        int va = 0, da = 0, vl = 0, dl = 0;
+        auto up_one = [&](const uint16_t *buf, int i, int np, int &v, int &d2) {
+          const int d0 = buf[i == 0 ? -1 : i - 2], d1 = buf[i - 1], d3 = buf[i + 1 >= np ? np - 1 : i + 1];
+          d2 = buf[i];
+          v = (-d0 + 9 * d1 + 9 * d2 - d3 + 8) >> 4;
+          v = v < 0 ? 0 : (v > maxv ? maxv : v);
+        };
+        if (up_a && sl < npa) up_one(FA, sl, npa, va, da);
+        if (up_l && sl < npl) up_one(FL, sl, npl, vl, dl);
+        const int a_m1 = FA[-1], l_m1 = FL[-1];
+        wave_sync();
+        if (up_a && sl < npa) { FA[2 * sl - 1] = (uint16_t)va; FA[2 * sl] = (uint16_t)da; if (sl == 0) FA[-2] = (uint16_t)a_m1; }
+        if (up_l && sl < npl) { FL[2 * sl - 1] = (uint16_t)vl; FL[2 * sl] = (uint16_t)dl; if (sl == 0) FL[-2] = (uint16_t)l_m1; }
+        wave_sync();
+      }
+    }
+    A = FA; L = FL;
+    return true;
+  };
   int first = (PH != 1 && NPL == 1 && plane0 == 0) ? 0 : 13;
   if (PH != 1 && NPL == 1 && plane0 == 0 && P->mode_mask == 0x7u) {
     // default candidate set {DC, V, H}: the three SADs in one pass over the block instead of three
@@ -548,10 +639,13 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
           const int delta = (k & 1) ? (k >> 1) + 1 : -((k >> 1) + 1);
           int ang, dx, dy;
           dir_params(best_mode, delta, ang, dx, dy);
+          const uint16_t *EA, *EL;
+          int up_a, up_l;
+          dir_edges(ang, EA, EL, up_a, up_l);
           int sad = 0;
 #pragma unroll 4
           for (int p = sl; p < N * N; p += G)
-            sad += iabs((int)S->srcblk[po + p] - pred_pixel<LOG2N, WV>(best_mode, p >> LOG2N, p & (N - 1), dcv, ang, dx, dy, eo));
+            sad += iabs((int)S->srcblk[po + p] - pred_pixel<LOG2N, WV>(best_mode, p >> LOG2N, p & (N - 1), dcv, ang, dx, dy, EA, EL, up_a, up_l));
           sad = wave_sum(sad);
           if (sad < best_sad) { best_sad = sad; best_delta = delta; }
         }
@@ -581,6 +675,10 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
     int ang, dx, dy;
     dir_params(mode, final_trip ? best_delta : 0, ang, dx, dy);
+    const uint16_t *EA = nullptr, *EL = nullptr;
+    int up_a = 0, up_l = 0;
+    // (fe: the filtered edges occupy the staging area the residual goes to - it is then written in a pass of its own)
+    const bool fe = (INTER && final_trip && ii.is_inter) ? false : dir_edges(ang, EA, EL, up_a, up_l);
     int sad = 0;
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) {
@@ -595,15 +693,20 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         pv = mc_sample<PIX>(rp, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
                             ((gx + c) << 4) + ((2 * ii.mv_col) >> ss), ((gy + r) << 4) + ((2 * ii.mv_row) >> ss), (1 << bd) - 1);
       } else {
-        pv = pred_pixel<LOG2N, WV>(mode, r, c, dcv, ang, dx, dy, eo);
+        pv = pred_pixel<LOG2N, WV>(mode, r, c, dcv, ang, dx, dy, EA, EL, up_a, up_l);
       }
       const int sv = S->srcblk[po + p];
       if (final_trip) {
         S->blkpix[po + p] = (uint16_t)pv;
-        S->scratch[so + r * ST + c] = (int16_t)(sv - pv);
+        if (!fe) S->scratch[so + r * ST + c] = (int16_t)(sv - pv);
       } else {
         sad += iabs(sv - pv);
       }
+    }
+    if (final_trip && fe) {
+      wave_sync();
+#pragma unroll 4
+      for (int p = sl; p < N * N; p += G) S->scratch[so + (p >> LOG2N) * ST + (p & (N - 1))] = (int16_t)((int)S->srcblk[po + p] - (int)S->blkpix[po + p]);
     }
     if (!final_trip) {
       sad = wave_sum(sad);
@@ -729,6 +832,10 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
       }
       for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
+      if (lane < (plane0 ? N >> 2 : N >> 3)) {
+        const uint8_t smf = (uint8_t)(!(INTER && ii.is_inter) && best_mode >= SMOOTH_PRED && best_mode <= SMOOTH_H_PRED);
+        LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = smf; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = smf;
+      }
     }
   }
   if (sl == 0) eob_out[grp] = eob;

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AV1MI_ABI_VERSION 4
+#define AV1MI_ABI_VERSION 5
 
 /* positive failure codes (-> Av1anFailed(code)) */
 enum {
@@ -79,6 +79,8 @@ typedef struct {
                                av1mi_encode_file takes it from the Y4M header's XCOLORRANGE tag when there is one */
   uint32_t intra_angle_delta; /* 1: a directional winner of the luma mode decision (V, H, D45 .. D67) is refined over the angle deltas
                                -3 .. +3 (3 degrees each) by closed-loop SAD, chroma follows luma; 0 (default): delta 0 */
+  uint32_t intra_edge_filter; /* sequence header enable_intra_edge_filter (SVT-AV1 and libaom run with it on): 1 = directional intra
+                               predictions read the filtered / upsampled edges of AV1 spec 7.11.2.7 - 7.11.2.12; 0 (default) */
 } av1mi_params;
 
 typedef struct {

@@ -75,6 +75,8 @@ typedef struct {
                              -3 .. +3 (3 degrees each, §7.11.2.4) by closed-loop SAD; chroma follows luma (same mode, same delta) */
   int color_range;        /* color_config.color_range: 0 = studio / limited (default: what Y4M and the reference's ffmpeg -> SVT-AV1
                              pipeline carry), 1 = full */
+  int intra_edge_filter;  /* sequence header enable_intra_edge_filter: directional predictions use the filtered / upsampled
+                           * edges of spec 7.11.2.9 - 7.11.2.12 (SVT-AV1 and libaom run with it on); 0 = the round-1 streams */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */
@@ -132,6 +134,12 @@ void av1o_fdct1d(int32_t *x, int log2n);
 const int16_t *av1o_default_scan(int log2n); /* n*n entries (n<=32) */
 
 /* edge arrays: above[-1..2n-1], left[-1..2n-1] (index 0 of the passed pointer = element -1) */
+/* intra edge filter control of one prediction (spec 7.11.2): enable = enable_intra_edge_filter, filter_type = get_filter_type()
+ * (a neighbour predicted with a smooth mode), n_top / n_left = Min(w, maxX - x + 1) / Min(h, maxY - y + 1) */
+typedef struct { int enable, filter_type, n_top, n_left; } Av1oEdgeCtl;
+void av1o_predict_intra_ef(uint16_t *dst, int stride, int log2n, int mode, int angle_delta,
+                           const uint16_t *above_m1, const uint16_t *left_m1, int have_above, int have_left, int bd,
+                           const Av1oEdgeCtl *ef);
 void av1o_predict_intra(uint16_t *dst, int stride, int log2n, int mode, int angle_delta,
                         const uint16_t *above, const uint16_t *left, int have_above, int have_left, int bd);
 

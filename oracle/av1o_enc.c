@@ -162,7 +162,7 @@ static size_t seq_header_payload(const Av1oConfig *cfg, uint8_t *buf, size_t cap
   if (!cfg->still_picture) bw_put(&b, 0, 1); /* frame_id_numbers_present_flag */
   bw_put(&b, 0, 1); /* use_128x128_superblock */
   bw_put(&b, 0, 1); /* enable_filter_intra */
-  bw_put(&b, 0, 1); /* enable_intra_edge_filter */
+  bw_put(&b, cfg->intra_edge_filter ? 1 : 0, 1); /* enable_intra_edge_filter */
   if (!cfg->still_picture) {
     bw_put(&b, 0, 1); /* enable_interintra_compound */
     bw_put(&b, 0, 1); /* enable_masked_compound */
@@ -471,6 +471,7 @@ typedef struct Enc_ {
   uint8_t *mi_bsl;     /* log2 of block size in pixels of the block covering the mi, 0 = not coded */
   uint8_t *mi_skip;
   uint8_t *mi_ymode;
+  uint8_t *mi_uvmode;  /* get_filter_type() of chroma blocks (spec 7.11.2.8) */
   /* inter frames */
   const Av1oFrame *ref; /* LAST_FRAME: the previous frame's final reconstruction; NULL on key frames */
   const Av1oFrame *prev_src; /* the previous SOURCE frame: what the motion search looks at */
@@ -1186,6 +1187,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
   ModeDec md = { DC_PRED, 0, DC_PRED, 0 };
   int plane, i, j, skip;
   int have_ar[2], have_bl[2];
+  Av1oEdgeCtl ef[2];
   const int log2n_y = bsl, log2n_uv = bsl - 1 > 5 ? 5 : bsl - 1;
   int tx_y, tx_uv;
   /* inter frames: the block is either intra (as on key frames) or predicted from LAST_FRAME with `mv` */
@@ -1207,6 +1209,21 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
     have_bl[plane] = e->block_decoded[plane][r4 + step + 1][c4 - 1 + 1];
   }
 
+  /* intra edge filter (spec 7.11.2.8 get_filter_type): is the block above / left predicted with a smooth mode?  (blocks are
+   * at least 8x8, so the chroma neighbour is the block over / beside the same mi position) */
+  for (plane = 0; plane < 2; plane++) {
+    const uint8_t *modes = plane ? e->mi_uvmode : e->mi_ymode;
+    int sm = 0;
+    if (avail_u && !e->mi_is_inter[(mi_r - 1) * g->mi_cols + mi_c]) { int m = modes[(mi_r - 1) * g->mi_cols + mi_c]; sm |= m == SMOOTH_PRED || m == SMOOTH_V_PRED || m == SMOOTH_H_PRED; }
+    if (avail_l && !e->mi_is_inter[mi_r * g->mi_cols + mi_c - 1]) { int m = modes[mi_r * g->mi_cols + mi_c - 1]; sm |= m == SMOOTH_PRED || m == SMOOTH_V_PRED || m == SMOOTH_H_PRED; }
+    {
+      const int np = plane ? 1 << log2n_uv : n, px = plane ? mi_c * 2 : mi_c * 4, py = plane ? mi_r * 2 : mi_r * 4;
+      const int pw = plane ? cfg->width / 2 : cfg->width, ph = plane ? cfg->height / 2 : cfg->height;
+      ef[plane].enable = cfg->intra_edge_filter; ef[plane].filter_type = sm;
+      ef[plane].n_top = np < pw - px ? np : pw - px; ef[plane].n_left = np < ph - py ? np : ph - py;
+    }
+  }
+
   /* ---- luma mode decision: closed-loop prediction SAD */
   {
     int x = mi_c * 4, y = mi_r * 4, best = -1, m;
@@ -1226,7 +1243,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
       for (m = 0; m < 13; m++) {
         int sad;
         if (!((cfg->mode_mask >> m) & 1)) continue;
-        av1o_predict_intra(pred, n, bsl, m, 0, edge_a, edge_l, avail_u, avail_l, bd);
+        av1o_predict_intra_ef(pred, n, bsl, m, 0, edge_a, edge_l, avail_u, avail_l, bd, &ef[0]);
         sad = block_sad(src, e->src->stride[0], pred, n, n);
         if (m == DC_PRED) { sad_dc = sad; continue; }
         if (best < 0 || sad < best) { best = sad; md.ymode = m; }
@@ -1239,7 +1256,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
         int k;
         for (k = 0; k < 6; k++) {
           int sad;
-          av1o_predict_intra(pred, n, bsl, md.ymode, order[k], edge_a, edge_l, avail_u, avail_l, bd);
+          av1o_predict_intra_ef(pred, n, bsl, md.ymode, order[k], edge_a, edge_l, avail_u, avail_l, bd, &ef[0]);
           sad = block_sad(src, e->src->stride[0], pred, n, n);
           if (sad < best) { best = sad; md.yangle = order[k]; }
         }
@@ -1268,8 +1285,8 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
       }
     }
     if (is_inter) predict_inter(e, 0, x, y, n, mv, e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0]);
-    else av1o_predict_intra(e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0], bsl, md.ymode, md.yangle,
-                            edge_a, edge_l, avail_u, avail_l, bd);
+    else av1o_predict_intra_ef(e->rec->p[0] + (size_t)y * e->rec->stride[0] + x, e->rec->stride[0], bsl, md.ymode, md.yangle,
+                               edge_a, edge_l, avail_u, avail_l, bd, &ef[0]);
   }
   tx_y = (log2n_y <= 4 && !is_inter) ? mode_to_txfm[md.ymode] : DCT_DCT;
   tx_uv = (log2n_uv <= 4 && !is_inter) ? mode_to_txfm[md.uvmode] : DCT_DCT;
@@ -1281,8 +1298,8 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
       predict_inter(e, plane, x, y, nc, mv, e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane]);
     } else {
       prepare_edges(e, plane, x, y, nc, avail_l, avail_u, have_ar[1], have_bl[1], edge_a, edge_l);
-      av1o_predict_intra(e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane], log2n_uv,
-                         md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd);
+      av1o_predict_intra_ef(e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane], log2n_uv,
+                            md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd, &ef[1]);
     }
     code_tx_block(e, plane, x, y, log2n_uv, tx_uv, plane == 1 ? tu : tv);
   }
@@ -1384,6 +1401,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
         e->mi_bsl[idx] = (uint8_t)bsl;
         e->mi_skip[idx] = (uint8_t)skip;
         e->mi_ymode[idx] = (uint8_t)md.ymode;
+        e->mi_uvmode[idx] = (uint8_t)md.uvmode;
         e->mi_is_inter[idx] = (uint8_t)is_inter;
         e->mi_newmv[idx] = (uint8_t)(is_inter && inter_mode == 3);
         e->mi_mv[2 * idx] = (int16_t)(is_inter ? mv.row : 0);
@@ -1672,6 +1690,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   e->mi_bsl = (uint8_t *)calloc(n_mi, 1);
   e->mi_skip = (uint8_t *)calloc(n_mi, 1);
   e->mi_ymode = (uint8_t *)calloc(n_mi, 1);
+  e->mi_uvmode = (uint8_t *)calloc(n_mi, 1);
   e->ref = ref;
   e->prev_src = prev_src;
   e->mi_is_inter = (uint8_t *)calloc(n_mi, 1);
@@ -1716,7 +1735,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
     av1o_lr_frame(cfg, e->rec, cd, src, lr_out, lr_units, cfg->fuzz_modes ? (unsigned)cfg->fuzz_modes + 77u : 0u);
     av1o_frame_free(cd);
     e->lr_units = lr_units;
-    memset(e->mi_bsl, 0, n_mi); memset(e->mi_skip, 0, n_mi); memset(e->mi_ymode, 0, n_mi);
+    memset(e->mi_bsl, 0, n_mi); memset(e->mi_skip, 0, n_mi); memset(e->mi_ymode, 0, n_mi); memset(e->mi_uvmode, 0, n_mi);
     memset(e->mi_is_inter, 0, n_mi); memset(e->mi_newmv, 0, n_mi); memset(e->mi_mv, 0, n_mi * 2 * sizeof(int16_t));
     memset(e->cdef_idx_sb, -1, (size_t)g.sb_rows * g.sb_cols);
     e->rng_state = (uint32_t)(cfg->fuzz_coeffs ? cfg->fuzz_coeffs : (cfg->fuzz_modes ? cfg->fuzz_modes : 1)) * 2654435761u + 1u;
@@ -1786,7 +1805,7 @@ done:
   free(payload);
   free(tilebuf);
   for (p = 0; p < 3; p++) { free(e->above_lvl[p]); free(e->above_dc[p]); }
-  free(e->mi_bsl); free(e->mi_skip); free(e->mi_ymode); free(e->cdef_idx_sb);
+  free(e->mi_bsl); free(e->mi_skip); free(e->mi_ymode); free(e->mi_uvmode); free(e->cdef_idx_sb);
   free(e->mi_is_inter); free(e->mi_newmv); free(e->mi_mv);
   free(lr_units); av1o_frame_free(lr_out);
   av1o_frame_free(src_ext);

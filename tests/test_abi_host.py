@@ -31,7 +31,7 @@ def test_exports_every_declared_symbol(av1mi):
     lib = C.CDLL(os.path.abspath(av1mi.LIB_PATH))
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert av1mi._lib.av1mi_abi_version() == 4
+    assert av1mi._lib.av1mi_abi_version() == 5
 
 
 def test_cq_mapping_matches_aom_table(av1mi):

@@ -87,6 +87,18 @@ CASES = [
     ("k248x184_angle_bs5_10b", 248, 184, 10, 81, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, angle_delta=1, deblock=1)),
     ("k136_angle_dcvh_bs3", 136, 136, 8, 82, 1, dict(min_bs_log2=3, max_bs_log2=3, angle_delta=1)),
     ("k184x176_angle_bs6", 184, 176, 8, 83, 2, dict(min_bs_log2=6, max_bs_log2=6, mode_mask=0x1FFF, angle_delta=1)),
+    # enable_intra_edge_filter: filtered / upsampled edges for the directional modes (decision-driven with all 13 candidates and
+    # angle deltas; fuzzed modes / angles so that smooth neighbours, every strength and both upsampling cases occur)
+    ("k200x120_ef_all13_bs5", 200, 120, 8, 1080, 6, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1)),
+    ("k200x120_ef_all13_bs4_10b", 200, 120, 10, 1080, 7, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1)),
+    ("k202x122_ef_all13_bs3", 202, 122, 8, 85, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1)),
+    ("k184x176_ef_bs6_10b", 184, 176, 10, 86, 1, dict(min_bs_log2=6, max_bs_log2=6, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1)),
+    ("k136_ef_dirs_bs3", 136, 136, 8, 87, 2, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x01FE, intra_edge_filter=1)),
+    ("fuzz_ef_bs3", 200, 120, 8, 88, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=3, intra_edge_filter=1)),
+    ("fuzz_ef_bs4_10b", 264, 200, 10, 89, 0, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, fuzz_modes=5, intra_edge_filter=1)),
+    ("fuzz_ef_bs5", 264, 200, 8, 90, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, fuzz_modes=7, intra_edge_filter=1)),
+    ("fuzz_ef_bs6", 264, 200, 8, 91, 0, dict(min_bs_log2=6, max_bs_log2=6, mode_mask=0x1FFF, fuzz_modes=9, intra_edge_filter=1)),
+    ("fuzz_ef_tiles2x1_10b", 328, 248, 10, 92, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=17, tile_w_sb=2, tile_h_sb=1, intra_edge_filter=1)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -132,6 +144,8 @@ SEQ_CASES = [
     ("pfuzz_overhang_bs6_subpel", 184, 248, 8, 78, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=11, subpel=1)),
     ("pfuzz_overhang_bs5_onetile", 248, 184, 10, 79, 3, dict(min_bs_log2=5, max_bs_log2=5, fuzz_modes=13, tile_w_sb=64, tile_h_sb=64, deblock=1)),
     ("p200x120_angle_all13", 200, 120, 8, 84, 3, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, angle_delta=1)),
+    ("p200x120_ef_all13", 200, 120, 8, 93, 3, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1)),
+    ("pfuzz_ef_bs3_10b", 136, 120, 10, 94, 3, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=21, intra_edge_filter=1)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
