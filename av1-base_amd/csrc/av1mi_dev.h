@@ -40,6 +40,7 @@ struct Av1miDevParams {
   uint32_t mode_mask;
   int angle_delta;          // 1: directional winners of the luma mode decision are refined over the angle deltas -3 .. +3
   int edge_filter;          // enable_intra_edge_filter
+  int cfl;                  // chroma from luma is a candidate (key frames, blocks up to 32x32)
   int enable_cdef, cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping;
   int disable_cdf_update;
   // plane geometry in samples
@@ -103,8 +104,8 @@ AV1MI_HD inline int av1mi_levels_off(int plane, int bx, int by) {
 // for one q context; offsets in uint16 units.  Mirrors the per-tile adaptive state.
 struct Av1miCdfLayout {
   enum {
-    PARTITION = 0,                         // [20][11]
-    KF_Y_MODE = PARTITION + 20 * 11,       // [5][5][14]
+    PARTITION = 0,                         // [16][11]  (8x8 .. 64x64: no 128x128 superblocks)
+    KF_Y_MODE = PARTITION + 16 * 11,       // [5][5][14]
     UV_MODE = KF_Y_MODE + 25 * 14,         // [2][13][15]
     ANGLE_DELTA = UV_MODE + 26 * 15,       // [8][8]
     SKIP = ANGLE_DELTA + 64,               // [3][3]
@@ -123,7 +124,9 @@ struct Av1miCdfLayout {
     COEFF_BASE_EOB = DC_SIGN + 6 * 3,      // [5][2][4][4]
     USE_WIENER = COEFF_BASE_EOB + 40 * 4,  // [3]
     RESTORE_SW = USE_WIENER + 3,           // [4] restoration_type of RESTORE_SWITCHABLE frames: NONE, WIENER, SGRPROJ
-    COEFF_BASE = RESTORE_SW + 4,           // [5][2][42][5]
+    CFL_SIGN = RESTORE_SW + 4,             // [9]
+    CFL_ALPHA = CFL_SIGN + 9,              // [6][17]
+    COEFF_BASE = CFL_ALPHA + 6 * 17,       // [5][2][42][5]
     COEFF_BR = COEFF_BASE + 420 * 5,       // [5][2][21][5]
     INTRA_TOTAL = COEFF_BR + 210 * 5,      // everything a key frame needs
     // inter frames

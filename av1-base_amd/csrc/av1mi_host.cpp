@@ -108,7 +108,7 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping == 0) { p.cdef_y_pri = 2; p.cdef_y_sec = 0; p.cdef_uv_pri = 1; p.cdef_uv_sec = 0; p.cdef_damping = 5; }
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
-  if (p.subpel > 1 || p.enable_lr > 2 || p.color_range > 1 || p.intra_angle_delta > 1 || p.intra_edge_filter > 1) return AV1MI_E_INVALID_ARG;
+  if (p.subpel > 1 || p.enable_lr > 2 || p.color_range > 1 || p.intra_angle_delta > 1 || p.intra_edge_filter > 1 || p.cfl > 1) return AV1MI_E_INVALID_ARG;
   if (p.enable_qm > 1 || p.qm_min > 15 || p.qm_max > 15 || (p.enable_qm && p.qm_min > p.qm_max)) return AV1MI_E_INVALID_ARG;
   // level from the quantiser index, as SVT-AV1 / libaom derive it ("--qm-min", "--qm-max")
   r->qm_level = p.enable_qm ? (int)(p.qm_min + (uint32_t)r->qidx * (p.qm_max + 1 - p.qm_min) / 256) : 15;
@@ -347,7 +347,7 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
   std::vector<uint16_t> v(CL::TOTAL, 0);
   int pn[20];
   for (int i = 0; i < 20; i++) pn[i] = i < 4 ? 4 : (i < 16 ? 10 : 8);
-  emit_rows(v, CL::PARTITION, av1_default_partition_cdf, 20, 11, pn, 0);
+  emit_rows(v, CL::PARTITION, av1_default_partition_cdf, 16, 11, pn, 0);
   emit_rows(v, CL::KF_Y_MODE, &av1_default_kf_y_mode_cdf[0][0], 25, 14, nullptr, 13);
   emit_rows(v, CL::UV_MODE, av1_default_uv_mode_nocfl_cdf, 13, 15, nullptr, 13);
   emit_rows(v, CL::UV_MODE + 13 * 15, av1_default_uv_mode_cfl_cdf, 13, 15, nullptr, 14);
@@ -368,6 +368,8 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
   emit_rows(v, CL::COEFF_BASE_EOB, &av1_default_coeff_base_eob_cdf[q][0][0][0], 40, 4, nullptr, 3);
   emit_rows(v, CL::USE_WIENER, av1_default_use_wiener_cdf, 1, 3, nullptr, 2);
   emit_rows(v, CL::RESTORE_SW, av1_default_switchable_restore_cdf, 1, 4, nullptr, 3);
+  emit_rows(v, CL::CFL_SIGN, av1_default_cfl_sign_cdf, 1, 9, nullptr, 8);
+  emit_rows(v, CL::CFL_ALPHA, av1_default_cfl_alpha_cdf, 6, 17, nullptr, 16);
   // inter frames
   emit_rows(v, CL::IF_Y_MODE, av1_default_if_y_mode_cdf, 4, 14, nullptr, 13);
   emit_rows(v, CL::IS_INTER, av1_default_is_inter_cdf, 4, 3, nullptr, 2);
@@ -585,6 +587,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.mode_mask = p.intra_mode_mask ? (p.intra_mode_mask & 0x1FFF) : 0x0007;  // default candidates: DC, V, H
   P.angle_delta = p.intra_angle_delta ? 1 : 0;
   P.edge_filter = p.intra_edge_filter ? 1 : 0;
+  P.cfl = p.cfl ? 1 : 0;
   P.enable_cdef = p.enable_cdef ? 1 : 0;
   P.cdef_y_pri = p.cdef_y_pri; P.cdef_y_sec = p.cdef_y_sec; P.cdef_uv_pri = p.cdef_uv_pri; P.cdef_uv_sec = p.cdef_uv_sec;
   P.cdef_damping = p.cdef_damping;

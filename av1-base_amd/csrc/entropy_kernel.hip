@@ -47,7 +47,7 @@ struct InterLds {
 };
 __shared__ InterLds g_inter;
 struct SymLds {
-  uint16_t cdf[CL::COEFF_BASE + 64];   // wide rows; +64: whole-row reads by 17 lanes may run past the last row
+  uint16_t cdf[CL::COEFF_BASE + 18];   // wide rows; + 18: whole-row reads by 17 lanes may run past the last row
   int16_t lv[32 * 32];
   uint8_t left_lvl[3][16], left_dc[3][16];   // per superblock row of the tile
 };
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     if (regular == FULL) return;
   }
   for (int i = lane; i < CL::COEFF_BASE; i += 64) S->cdf[i] = cdf_init[i];
-  S->cdf[CL::COEFF_BASE + lane] = 0;
+  if (lane < 18) S->cdf[CL::COEFF_BASE + lane] = 0;
   if (FULL) {
     for (int i = lane; i < CL::INTRA_TOTAL - CL::COEFF_BASE; i += 64) g_cdf_narrow[i] = cdf_init[CL::COEFF_BASE + i];
     g_cdf_narrow[CL::INTRA_TOTAL - CL::COEFF_BASE + lane] = 0;
@@ -712,11 +712,19 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
             const int lm = uni(c_intra_mode_ctx[avail_l ? INFO(b8x - 1, b8y).ymode : 0]);
             sym_wide(y, lane, adapt, ymode, CL::KF_Y_MODE + (am * 5 + lm) * 14, 13);
           }
-          const int adelta = uni(INFO(b8x, b8y).angle);   // angle delta + 3 = the symbol; chroma uses luma's
+          // chroma: the luma mode at luma's angle delta, or chroma from luma (bit 3 of `angle`; alphas + 16 in bits 4-9 / 10-15)
+          const int ainfo = uni(INFO(b8x, b8y).angle), adelta = ainfo & 7, cfl = (ainfo >> 3) & 1;
           if (ymode >= 1 && ymode <= 8) sym_wide(y, lane, adapt, adelta, CL::ANGLE_DELTA + (ymode - 1) * 8, 7);
-          const int uvmode = ymode;
+          const int uvmode = cfl ? 13 : ymode;
           const int cfl_allowed = n <= 32;
           sym_wide(y, lane, adapt, uvmode, CL::UV_MODE + (cfl_allowed * 13 + ymode) * 15, cfl_allowed ? 14 : 13);
+          if (cfl) {   // read_cfl_alphas (spec 5.11.45)
+            const int au = ((ainfo >> 4) & 63) - 16, av = ((ainfo >> 10) & 63) - 16;
+            const int su = au == 0 ? 0 : (au < 0 ? 1 : 2), sv = av == 0 ? 0 : (av < 0 ? 1 : 2);
+            sym_wide(y, lane, adapt, su * 3 + sv - 1, CL::CFL_SIGN, 8);
+            if (su) sym_wide(y, lane, adapt, iabs(au) - 1, CL::CFL_ALPHA + ((su - 1) * 3 + sv) * 17, 16);
+            if (sv) sym_wide(y, lane, adapt, iabs(av) - 1, CL::CFL_ALPHA + ((sv - 1) * 3 + su) * 17, 16);
+          }
           if (uvmode >= 1 && uvmode <= 8) sym_wide(y, lane, adapt, adelta, CL::ANGLE_DELTA + (uvmode - 1) * 8, 7);
         }
         const int w4 = n >> 2, w4c = imax(w4 >> 1, 1);

@@ -59,7 +59,7 @@ __constant__ int16_t c_dr_deriv[91] = {
   31, 0, 0, 27, 0, 0, 23, 0, 0, 19, 0, 0, 15, 0, 0, 0, 0, 11, 0, 0, 7, 0, 0, 3, 0, 0, 0 };
 __constant__ int16_t c_mode_angle[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
 // Mode_To_Txfm (spec §6.10.x): 0 DCT_DCT 1 ADST_DCT 2 DCT_ADST 3 ADST_ADST
-__constant__ uint8_t c_mode_txfm[13] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3 };
+__constant__ uint8_t c_mode_txfm[14] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3, 0 };   // [13] = UV_CFL_PRED
 
 // LDS per superblock-wave (~9 KB, so ~4 waves fit a SIMD): decoder-style line buffers instead of the
 // whole reconstructed superblock.  above[p][x] = bottom row of the last block reconstructed over column
@@ -414,7 +414,9 @@ __device__ __forceinline__ T *uniform_p(T *p) {
   const unsigned long long a = (unsigned long long)p;
   return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
-template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM, int PH, int WV>
+// EXT: the instantiation contains the optional intra tools (edge filter / upsampling, chroma from luma); the default operating
+// point runs the instantiations without them - their code alone cost 5 % (the items are larger than the instruction cache).
+template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM, int PH, int WV, bool EXT>
 __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
                                                  int mode_io, InterInfo ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out, int post_idx) {
   post_idx = uniform_i(post_idx);
@@ -471,7 +473,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = (uint16_t)pl[(size_t)(gy + (q < ph_lim ? q : ph_lim - 1)) * gs + gx + cb];
       }
       for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
-      if (lane < (plane0 ? N >> 2 : N >> 3)) { LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = 0; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = 0; }
+      if (EXT && lane < (plane0 ? N >> 2 : N >> 3)) { LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = 0; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = 0; }
       if (sl == 0) eob_out[grp] = plane == 0 ? ii.pre_eob[0] : (plane == 1 ? ii.pre_eob[1] : ii.pre_eob[2]);   // (no dynamic index: the array stays in registers)
       wave_sync();
     }
@@ -558,7 +560,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // filtered - and, for blocks up to 8x8, upsampled - copy of the edges.  The copy lives in the transform staging area (free
   // until the residual is written); element i of the above edge at FA[i], i = -2 .. , left edge at FL[i].
   int ef_type = 0;   // get_filter_type(): a neighbour predicted with a smooth mode
-  if constexpr (PH != 1) {
+  if constexpr (PH != 1 && EXT) {
     if (P->edge_filter) {
       const int ux = lx >> (plane0 ? 2 : 3), uy = ly >> (plane0 ? 2 : 3);
       ef_type = uniform_i((have_above && LN.sm_above[pc][ux]) || (have_left && LN.sm_left[pc][uy]));
@@ -568,7 +570,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   uint16_t *const FA = reinterpret_cast<uint16_t *>(S->scratch + so) + 2, *const FL = FA + FEL;
   auto dir_edges = [&](int ang, const uint16_t *&A, const uint16_t *&L, int &up_a, int &up_l) -> bool {
     A = S->edge_a + 1 + eo; L = S->edge_l + 1 + eo; up_a = 0; up_l = 0;
-    if (PH == 1 || !P->edge_filter || ang == 0 || ang == 90 || ang == 180) return false;
+    if (PH == 1 || !EXT || !P->edge_filter || ang == 0 || ang == 90 || ang == 180) return false;
     const uint16_t *RA = A, *RL = L;
     const int n_top = N < pw_lim ? N : pw_lim, n_left = N < ph_lim ? N : ph_lim;
     int corner = RA[-1];
@@ -625,6 +627,57 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     first = 13;
   }
   STAMP(1);   // DC value + the default candidates' SADs
+  // ---- chroma from luma (spec 7.11.5): key-frame blocks up to 32x32 luma.  The luma item left the block's
+  // subsampled reconstruction minus its average (Q3) behind the two groups' staging areas; lanes 0-31 decide U's alpha and lanes
+  // 32-63 V's at the same time: least-squares estimate, then the SAD of the estimate and its two neighbours.
+  constexpr int CFL_ACO = 2 * 16 * 17;   // offset of that buffer in S->scratch (chroma blocks up to 16x16, NPL == 2)
+  int use_cfl = 0, cfl_alpha = 0;
+  auto cfl_px = [&](int alpha, int ac) {
+    const int sa = alpha * ac, rr = sa >= 0 ? (sa + 32) >> 6 : -((-sa + 32) >> 6);   // Round2Signed(alpha * ac, 6)
+    const int v = dcv + rr, maxv = (1 << bd) - 1;
+    return v < 0 ? 0 : (v > maxv ? maxv : v);
+  };
+  if constexpr (EXT && NPL == 2 && !INTER && PH == 0 && N <= 16) {
+    if (P->cfl) {
+      const int16_t *AC = S->scratch + CFL_ACO;
+      auto group_sum = [&](int v) { for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+      int ang, dx, dy;
+      dir_params(best_mode, best_delta, ang, dx, dy);
+      const uint16_t *EA = nullptr, *EL = nullptr;
+      int up_a = 0, up_l = 0;
+      dir_edges(ang, EA, EL, up_a, up_l);
+      int sad_reg = 0, num = 0, den = 0;
+#pragma unroll 4
+      for (int p = sl; p < N * N; p += G) {
+        const int sv = S->srcblk[po + p];
+        sad_reg += iabs(sv - pred_pixel<LOG2N, WV>(best_mode, p >> LOG2N, p & (N - 1), dcv, ang, dx, dy, EA, EL, up_a, up_l));
+        const int a = (int)AC[p] >> 3, d = sv - dcv;
+        num += a * d; den += a * a;
+      }
+      sad_reg = group_sum(sad_reg); num = group_sum(num); den = group_sum(den);
+      int est = 0;
+      if (den) {
+        const long long t = 16ll * num + den, d2 = 2ll * den;   // round-half-up of 8 num / den
+        est = (int)(t >= 0 ? t / d2 : -((-t + d2 - 1) / d2));
+      }
+      est = est < -16 ? -16 : (est > 16 ? 16 : est);
+      int sad_cfl = 0x7FFFFFFF;
+#pragma nounroll
+      for (int k = 0; k < 3; k++) {
+        int a = est + (k == 0 ? 0 : (k == 1 ? -1 : 1));
+        a = a < -16 ? -16 : (a > 16 ? 16 : a);
+        int sad = 0;
+#pragma unroll 4
+        for (int p = sl; p < N * N; p += G) sad += iabs((int)S->srcblk[po + p] - cfl_px(a, AC[p]));
+        sad = group_sum(sad);
+        if (sad < sad_cfl) { sad_cfl = sad; cfl_alpha = a; }
+      }
+      const int a_other = __shfl_xor(cfl_alpha, 32, 64);
+      const int tot_cfl = sad_cfl + __shfl_xor(sad_cfl, 32, 64), tot_reg = sad_reg + __shfl_xor(sad_reg, 32, 64);
+      use_cfl = uniform_i(((cfl_alpha | a_other) != 0) && tot_cfl + N < tot_reg);
+      if (use_cfl) { best_mode = 13; best_delta = 0; }
+    }
+  }
 #pragma nounroll
   for (int m = first; m <= 13; m++) {
     const bool final_trip = m == 13;
@@ -678,7 +731,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     const uint16_t *EA = nullptr, *EL = nullptr;
     int up_a = 0, up_l = 0;
     // (fe: the filtered edges occupy the staging area the residual goes to - it is then written in a pass of its own)
-    const bool fe = (INTER && final_trip && ii.is_inter) ? false : dir_edges(ang, EA, EL, up_a, up_l);
+    const bool fe = ((INTER && final_trip && ii.is_inter) || use_cfl) ? false : dir_edges(ang, EA, EL, up_a, up_l);
     int sad = 0;
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) {
@@ -692,6 +745,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         // lastX / lastY of §7.11.3.3: the reference is clamped to the SIGNALLED frame size
         pv = mc_sample<PIX>(rp, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
                             ((gx + c) << 4) + ((2 * ii.mv_col) >> ss), ((gy + r) << 4) + ((2 * ii.mv_row) >> ss), (1 << bd) - 1);
+      } else if (use_cfl) {
+        pv = cfl_px(cfl_alpha, S->scratch[CFL_ACO + p]);
       } else {
         pv = pred_pixel<LOG2N, WV>(mode, r, c, dcv, ang, dx, dy, EA, EL, up_a, up_l);
       }
@@ -832,7 +887,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
       }
       for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
-      if (lane < (plane0 ? N >> 2 : N >> 3)) {
+      if (EXT && lane < (plane0 ? N >> 2 : N >> 3)) {
         const uint8_t smf = (uint8_t)(!(INTER && ii.is_inter) && best_mode >= SMOOTH_PRED && best_mode <= SMOOTH_H_PRED);
         LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = smf; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = smf;
       }
@@ -841,6 +896,32 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   if (sl == 0) eob_out[grp] = eob;
   wave_sync();
   STAMP(6);   // reconstruction -> HBM, line buffers, decoded-block map
+  if constexpr (EXT && NPL == 1 && !INTER && PH == 0 && N >= 8 && N <= 32) {
+    // chroma from luma: the block's reconstructed luma, subsampled 2x2 (sum of four << 1 = Q3) and centred on its rounded
+    // average, for the chroma item that follows (it may predict from it - spec 7.11.5)
+    if (plane0 == 0 && P->cfl) {
+      constexpr int NC = N / 2, L2C = LOG2N - 1;
+      int16_t *AC = S->scratch + 2 * 16 * 17;
+      int sum = 0;
+      for (int p = lane; p < NC * NC; p += 64) {
+        const int i = p >> L2C, j = p & (NC - 1);
+        const uint16_t *q = S->blkpix + (2 * i) * N + 2 * j;
+        const int v = ((int)q[0] + q[1] + q[N] + q[N + 1]) << 1;
+        AC[p] = (int16_t)v;
+        sum += v;
+      }
+      sum = wave_sum(sum);
+      const int avg = (sum + (1 << (2 * L2C - 1))) >> (2 * L2C);
+      for (int p = lane; p < NC * NC; p += 64) AC[p] = (int16_t)(AC[p] - avg);
+      wave_sync();
+    }
+  }
+  if constexpr (NPL == 2) {   // chroma item: the chroma-from-luma decision goes back in bits 16 .. 28 (flag, alpha U + 16, alpha V + 16: 6 bits each)
+    if (use_cfl) {
+      const int au = __builtin_amdgcn_readlane(cfl_alpha, 0), av = __builtin_amdgcn_readlane(cfl_alpha, 32);
+      return (1 << 16) | ((au + 16) << 17) | ((av + 16) << 23) | (3 << 4) | 13;
+    }
+  }
   return ((INTER ? ii.is_inter : 0) << 8) | ((best_delta + 3) << 4) | best_mode;
 }
 
@@ -864,7 +945,7 @@ __device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, in
   return 0;
 }
 
-template <typename PIX, bool INTER, int TSB, bool QM, bool SPLIT>
+template <typename PIX, bool INTER, int TSB, bool QM, bool SPLIT, bool EXT>
 __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
                                                   Av1miBlkInfo *info, int b8_stride, const PIX *ref_frame,
                                                   const unsigned long long *me_best /* this superblock's first unit */, int si) {
@@ -908,11 +989,11 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
       int *eo = SbSel<WL>::get()->eobs;
       switch (bsl) {
 #if AV1MI_RECON_BIG
-        case 6: dec = tx_item<PIX, 6, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
+        case 6: dec = tx_item<PIX, 6, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL, EXT>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
 #endif
-        case 5: dec = tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
-        case 4: dec = tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
-        default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
+        case 5: dec = tx_item<PIX, 5, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL, EXT>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
+        case 4: dec = tx_item<PIX, 4, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL, EXT>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
+        default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL, EXT>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
       }
       dec = uniform_i(dec);
       if (SPLIT) {   // the luma block is finished: its eob for the block-info entry, which the chroma wave writes
@@ -924,13 +1005,14 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     }
     mode = dec & 0x7F; ii.is_inter = dec >> 8;   // the luma pass decides (mode and angle delta); the chroma pass follows it
     int *eo = SbSel<WC>::get()->eobs;
+    int cdec = 0;   // chroma item's return: chroma from luma in bits 16 .. 28
     switch (bsl) {
 #if AV1MI_RECON_BIG
-      case 6: tx_item<PIX, 5, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
+      case 6: tx_item<PIX, 5, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC, EXT>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
 #endif
-      case 5: tx_item<PIX, 4, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
-      case 4: tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
-      default: tx_item<PIX, 2, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
+      case 5: cdec = tx_item<PIX, 4, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC, EXT>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
+      case 4: cdec = tx_item<PIX, 3, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC, EXT>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
+      default: cdec = tx_item<PIX, 2, 2, INTER, TSB, QM, (INTER ? 2 : 0), WC, EXT>(cx, frame, rec_frame, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, eo + 1, -1); break;
     }
     {  // the block's info into every 8x8 unit it covers: one lane per unit
       const int n8 = n >> 3;
@@ -943,7 +1025,9 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         bi.ymode = (uint8_t)(mode & 15); bi.skip = (uint8_t)((e0 | e1 | e2) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
         bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2;
         bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0);
-        bi.angle = (uint16_t)((mode >> 4) & 7);   // angle delta + 3 of the (luma and chroma) directional mode
+        // angle delta + 3 of the (luma and chroma) directional mode | chroma from luma << 3 | (alpha U + 16) << 4 | (alpha V + 16) << 10
+        cdec = uniform_i(cdec);
+        bi.angle = (uint16_t)(((mode >> 4) & 7) | (((cdec >> 16) & 1) << 3) | (((cdec >> 17) & 63) << 4) | (((cdec >> 23) & 63) << 10));
         if (unit_inside) info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
       }
     }
@@ -959,7 +1043,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
 #define AV1MI_SPLIT_INTRA 0
 #endif
 template <bool INTER> struct WalkSplit { static constexpr bool value = INTER || AV1MI_SPLIT_INTRA; };
-template <typename PIX, bool INTER, int TSB, bool QM>
+template <typename PIX, bool INTER, int TSB, bool QM, bool EXT>
 __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
@@ -1017,7 +1101,7 @@ __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribut
     int16_t *sb_levels = levels + ((size_t)f * sbs_per_frame + sb) * AV1MI_SB_LEVELS;
     Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
     // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
-    encode_superblock<PIX, INTER, TSB, QM, SPLIT>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
+    encode_superblock<PIX, INTER, TSB, QM, SPLIT, EXT>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
                                                   me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr, si);
   }
 #ifdef AV1MI_STAMPS
@@ -1075,21 +1159,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
       if (blockIdx.z == 0) {
         switch (bsl) {
 #if AV1MI_RECON_BIG
-          case 6: tx_item<PIX, 6, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          case 6: tx_item<PIX, 6, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
 #endif
-          case 5: tx_item<PIX, 5, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
-          case 4: tx_item<PIX, 4, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
-          default: tx_item<PIX, 3, 1, true, 1, QM, 1, 0>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          case 5: tx_item<PIX, 5, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          case 4: tx_item<PIX, 4, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          default: tx_item<PIX, 3, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
         }
         if (threadIdx.x == 0) bi->eob[0] = (uint16_t)g_sb.eobs[0];
       } else {
         switch (bsl) {
 #if AV1MI_RECON_BIG
-          case 6: tx_item<PIX, 5, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          case 6: tx_item<PIX, 5, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
 #endif
-          case 5: tx_item<PIX, 4, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
-          case 4: tx_item<PIX, 3, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
-          default: tx_item<PIX, 2, 2, true, 1, QM, 1, 0>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          case 5: tx_item<PIX, 4, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          case 4: tx_item<PIX, 3, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          default: tx_item<PIX, 2, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
         }
         if (threadIdx.x == 0) { bi->eob[1] = (uint16_t)g_sb.eobs[1]; bi->eob[2] = (uint16_t)g_sb.eobs[2]; }
       }
@@ -1133,13 +1217,16 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
 #undef PRE_LAUNCH
   }
   // quantiser matrices (P->qm_tab): kernels of their own, so the plain quantiser's registers and scratch are what they were
-#define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \
+#define RECON_LAUNCH2(PIXT, INTERV, TSBV, EXTV)                                                                                             \
   do {                                                                                                                                      \
-    if (P->qm_tab) hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, true>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,  \
+    if (P->qm_tab) hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, true, EXTV>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,  \
                                       (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                \
-    else hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, false>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,           \
+    else hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, false, EXTV>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,           \
                             (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                          \
   } while (0)
+  // the optional intra tools (edge filter, chroma from luma) live in instantiations of their own (EXT)
+#define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \
+  do { if (P->edge_filter || P->cfl) RECON_LAUNCH2(PIXT, INTERV, TSBV, true); else RECON_LAUNCH2(PIXT, INTERV, TSBV, false); } while (0)
   if (P->bit_depth == 8) {
     if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(uint8_t, true, 1); else RECON_LAUNCH(uint8_t, false, 1); }
     else { if (inter) RECON_LAUNCH(uint8_t, true, 2); else RECON_LAUNCH(uint8_t, false, 2); }
@@ -1148,5 +1235,6 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
     else { if (inter) RECON_LAUNCH(uint16_t, true, 2); else RECON_LAUNCH(uint16_t, false, 2); }
   }
 #undef RECON_LAUNCH
+#undef RECON_LAUNCH2
   return hipGetLastError();
 }

@@ -81,6 +81,8 @@ typedef struct {
                                -3 .. +3 (3 degrees each) by closed-loop SAD, chroma follows luma; 0 (default): delta 0 */
   uint32_t intra_edge_filter; /* sequence header enable_intra_edge_filter (SVT-AV1 and libaom run with it on): 1 = directional intra
                                predictions read the filtered / upsampled edges of AV1 spec 7.11.2.7 - 7.11.2.12; 0 (default) */
+  uint32_t cfl;             /* 1: chroma-from-luma prediction (UV_CFL_PRED, AV1 spec 7.11.5) is a candidate for the chroma planes of key-frame
+                               blocks up to 32x32 (alpha per plane by least squares over the reconstructed luma); 0 (default) */
 } av1mi_params;
 
 typedef struct {

@@ -362,6 +362,7 @@ typedef struct {
   uint16_t partition[20][11];
   uint16_t kf_y_mode[5][5][14];
   uint16_t uv_mode[2][13][15];
+  uint16_t cfl_sign[9], cfl_alpha[6][17];
   uint16_t angle_delta[8][8];
   uint16_t skip[3][3];
   uint16_t intra_tx_set1[2][13][8];
@@ -405,6 +406,8 @@ static void init_cdfs(TileCdfs *c, int qidx) {
     load_cdf(c->uv_mode[0][i], av1_default_uv_mode_nocfl_cdf[i], 13);
     load_cdf(c->uv_mode[1][i], av1_default_uv_mode_cfl_cdf[i], 14);
   }
+  load_cdf(c->cfl_sign, av1_default_cfl_sign_cdf[0], 8);
+  for (i = 0; i < 6; i++) load_cdf(c->cfl_alpha[i], av1_default_cfl_alpha_cdf[i], 16);
   for (i = 0; i < 8; i++) load_cdf(c->angle_delta[i], av1_default_angle_delta_cdf[i], 7);
   for (i = 0; i < 3; i++) load_cdf(c->skip[i], av1_default_skip_cdf[i], 2);
   for (i = 0; i < 2; i++)
@@ -1164,13 +1167,66 @@ static void write_mv_component(struct Enc_ *e, int comp, int v) {
 }
 
 /* ------------------------------------------------------------------ block coding §5.11.5 */
-typedef struct { int ymode, yangle, uvmode, uvangle; } ModeDec;
+typedef struct { int ymode, yangle, uvmode, uvangle, cfl_au, cfl_av; } ModeDec;   /* cfl_a*: CflAlphaU / V, -16 .. 16 (uvmode == UV_CFL_PRED) */
 
 static int block_sad(const uint16_t *a, int as, const uint16_t *b, int bs, int n) {
   int i, j, s = 0;
   for (i = 0; i < n; i++)
     for (j = 0; j < n; j++) s += abs((int)a[i * as + j] - (int)b[i * bs + j]);
   return s;
+}
+
+/* ---- chroma from luma (spec 7.11.5).  ac[i * nc + j] = subsampled reconstructed luma in Q3 minus its block average; the block's
+ * own luma reconstruction is complete (one transform block per block, so MaxLumaW / MaxLumaH never clamp). */
+static void cfl_luma_ac(const Enc *e, int x_l, int y_l, int log2nc, int16_t *ac) {
+  const int nc = 1 << log2nc, st = e->rec->stride[0];
+  const uint16_t *l = e->rec->p[0] + (size_t)y_l * st + x_l;
+  int i, j, sum = 0, avg;
+  for (i = 0; i < nc; i++)
+    for (j = 0; j < nc; j++) {
+      int t = l[(2 * i) * st + 2 * j] + l[(2 * i) * st + 2 * j + 1] + l[(2 * i + 1) * st + 2 * j] + l[(2 * i + 1) * st + 2 * j + 1];
+      ac[i * nc + j] = (int16_t)(t << 1);
+      sum += t << 1;
+    }
+  avg = (sum + (1 << (2 * log2nc - 1))) >> (2 * log2nc);
+  for (i = 0; i < nc * nc; i++) ac[i] = (int16_t)(ac[i] - avg);
+}
+static int cfl_px(int dc, int alpha, int ac, int maxv) {
+  const int s = alpha * ac, r = s >= 0 ? (s + 32) >> 6 : -((-s + 32) >> 6);   /* Round2Signed(alpha * ac, 6) */
+  const int v = dc + r;
+  return v < 0 ? 0 : (v > maxv ? maxv : v);
+}
+static int cfl_sad(const uint16_t *src, int sstride, const int16_t *ac, int nc, int dc, int alpha, int maxv) {
+  int i, j, s = 0;
+  for (i = 0; i < nc; i++)
+    for (j = 0; j < nc; j++) s += abs((int)src[i * sstride + j] - cfl_px(dc, alpha, ac[i * nc + j], maxv));
+  return s;
+}
+/* the encoder's alpha for one plane: least-squares estimate 8 * sum(a * d) / sum(a * a) with a = ac >> 3 and
+ * d = source - dc, rounded to nearest and clamped to -16 .. 16; then the SAD of the estimate and its two neighbours, first minimum
+ * in the order estimate, -1, +1 */
+static int cfl_choose_alpha(const uint16_t *src, int sstride, const int16_t *ac, int nc, int dc, int maxv, int *sad_out) {
+  long long num = 0, den = 0, t;
+  int i, j, est, k, best = 0, best_sad = -1;
+  for (i = 0; i < nc; i++)
+    for (j = 0; j < nc; j++) {
+      const int a = ac[i * nc + j] >> 3, d = (int)src[i * sstride + j] - dc;
+      num += a * d; den += a * a;
+    }
+  if (den == 0) est = 0;
+  else {
+    t = 16 * num + den;   /* floor((16 num + den) / (2 den)) = round-half-up of 8 num / den */
+    est = (int)(t >= 0 ? t / (2 * den) : -((-t + 2 * den - 1) / (2 * den)));
+  }
+  est = est < -16 ? -16 : (est > 16 ? 16 : est);
+  for (k = 0; k < 3; k++) {
+    int a = est + (k == 0 ? 0 : (k == 1 ? -1 : 1)), sad;
+    a = a < -16 ? -16 : (a > 16 ? 16 : a);
+    sad = cfl_sad(src, sstride, ac, nc, dc, a, maxv);
+    if (best_sad < 0 || sad < best_sad) { best_sad = sad; best = a; }
+  }
+  *sad_out = best_sad;
+  return best;
 }
 
 static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size in px */) {
@@ -1184,7 +1240,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
   uint16_t *pred = (uint16_t *)malloc(sizeof(uint16_t) * n * n);
   TxbCoefs *ty = (TxbCoefs *)malloc(sizeof(TxbCoefs) * 3);
   TxbCoefs *tu = ty + 1, *tv = ty + 2;
-  ModeDec md = { DC_PRED, 0, DC_PRED, 0 };
+  ModeDec md = { DC_PRED, 0, DC_PRED, 0, 0, 0 };
   int plane, i, j, skip;
   int have_ar[2], have_bl[2];
   Av1oEdgeCtl ef[2];
@@ -1289,19 +1345,61 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
                                edge_a, edge_l, avail_u, avail_l, bd, &ef[0]);
   }
   tx_y = (log2n_y <= 4 && !is_inter) ? mode_to_txfm[md.ymode] : DCT_DCT;
-  tx_uv = (log2n_uv <= 4 && !is_inter) ? mode_to_txfm[md.uvmode] : DCT_DCT;
   code_tx_block(e, 0, mi_c * 4, mi_r * 4, log2n_y, tx_y, ty);
-  /* ---- chroma */
-  for (plane = 1; plane < 3; plane++) {
-    int nc = 1 << log2n_uv, x = mi_c * 2, y = mi_r * 2;
-    if (is_inter) {
-      predict_inter(e, plane, x, y, nc, mv, e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane]);
-    } else {
-      prepare_edges(e, plane, x, y, nc, avail_l, avail_u, have_ar[1], have_bl[1], edge_a, edge_l);
-      av1o_predict_intra_ef(e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x, e->rec->stride[plane], log2n_uv,
-                            md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd, &ef[1]);
+  /* ---- chroma from luma (cfg->cfl; blocks up to 32x32): decision-driven on key frames - CfL replaces the luma-derived chroma mode
+   * when the sum of its two planes' prediction SADs (each plane at its chosen alpha) plus the chroma block width is smaller than
+   * the regular mode's, and the alphas are not both zero (not codable); fuzzed streams take it at random on any frame */
+  {
+    const int nc = 1 << log2n_uv, x = mi_c * 2, y = mi_r * 2, maxv = (1 << bd) - 1;
+    int16_t *ac = NULL;
+    if (cfg->cfl && !is_inter && n <= 32) {
+      if (cfg->fuzz_modes) {
+        unsigned r = fuzz_rand(e);
+        if (r % 3 == 0) {
+          md.cfl_au = (int)((r >> 4) % 33) - 16; md.cfl_av = (int)((r >> 12) % 33) - 16;
+          if (md.cfl_au == 0 && md.cfl_av == 0) md.cfl_av = 5;
+          md.uvmode = UV_CFL_PRED; md.uvangle = 0;
+        }
+      } else if (!inter_frame) {
+        int sad_cfl = 0, sad_reg = 0, au = 0, av = 0;
+        ac = (int16_t *)malloc(sizeof(int16_t) * nc * nc);
+        cfl_luma_ac(e, mi_c * 4, mi_r * 4, log2n_uv, ac);
+        for (plane = 1; plane < 3; plane++) {
+          const uint16_t *src = e->src->p[plane] + (size_t)y * e->src->stride[plane] + x;
+          int sc, dc;
+          prepare_edges(e, plane, x, y, nc, avail_l, avail_u, have_ar[1], have_bl[1], edge_a, edge_l);
+          av1o_predict_intra_ef(pred, nc, log2n_uv, md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd, &ef[1]);
+          sad_reg += block_sad(src, e->src->stride[plane], pred, nc, nc);
+          av1o_predict_intra(pred, nc, log2n_uv, DC_PRED, 0, edge_a, edge_l, avail_u, avail_l, bd);
+          dc = pred[0];
+          if (plane == 1) au = cfl_choose_alpha(src, e->src->stride[plane], ac, nc, dc, maxv, &sc);
+          else av = cfl_choose_alpha(src, e->src->stride[plane], ac, nc, dc, maxv, &sc);
+          sad_cfl += sc;
+        }
+        if ((au || av) && sad_cfl + nc < sad_reg) { md.uvmode = UV_CFL_PRED; md.uvangle = 0; md.cfl_au = au; md.cfl_av = av; }
+      }
     }
-    code_tx_block(e, plane, x, y, log2n_uv, tx_uv, plane == 1 ? tu : tv);
+    if (md.uvmode == UV_CFL_PRED && !ac) { ac = (int16_t *)malloc(sizeof(int16_t) * nc * nc); cfl_luma_ac(e, mi_c * 4, mi_r * 4, log2n_uv, ac); }
+    tx_uv = (log2n_uv <= 4 && !is_inter) ? mode_to_txfm[md.uvmode] : DCT_DCT;
+    for (plane = 1; plane < 3; plane++) {
+      uint16_t *dst = e->rec->p[plane] + (size_t)y * e->rec->stride[plane] + x;
+      if (is_inter) {
+        predict_inter(e, plane, x, y, nc, mv, dst, e->rec->stride[plane]);
+      } else {
+        prepare_edges(e, plane, x, y, nc, avail_l, avail_u, have_ar[1], have_bl[1], edge_a, edge_l);
+        if (md.uvmode == UV_CFL_PRED) {
+          int dc;
+          av1o_predict_intra(pred, nc, log2n_uv, DC_PRED, 0, edge_a, edge_l, avail_u, avail_l, bd);
+          dc = pred[0];
+          for (i = 0; i < nc; i++)
+            for (j = 0; j < nc; j++) dst[i * e->rec->stride[plane] + j] = (uint16_t)cfl_px(dc, plane == 1 ? md.cfl_au : md.cfl_av, ac[i * nc + j], maxv);
+        } else {
+          av1o_predict_intra_ef(dst, e->rec->stride[plane], log2n_uv, md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd, &ef[1]);
+        }
+      }
+      code_tx_block(e, plane, x, y, log2n_uv, tx_uv, plane == 1 ? tu : tv);
+    }
+    free(ac);
   }
   skip = ty->eob == 0 && tu->eob == 0 && tv->eob == 0;
 
@@ -1374,6 +1472,12 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
       WRITE_SYM(e, md.uvmode, e->cdf.uv_mode[cfl_allowed][md.ymode], cfl_allowed ? 14 : 13);
     }
     if (md.uvmode >= V_PRED && md.uvmode <= D67_PRED) WRITE_SYM(e, md.uvangle + 3, e->cdf.angle_delta[md.uvmode - V_PRED], 7);
+    if (md.uvmode == UV_CFL_PRED) {   /* read_cfl_alphas, spec 5.11.45: joint sign (zero / negative / positive per plane), then |alpha| - 1 */
+      const int su = md.cfl_au == 0 ? 0 : (md.cfl_au < 0 ? 1 : 2), sv = md.cfl_av == 0 ? 0 : (md.cfl_av < 0 ? 1 : 2);
+      WRITE_SYM(e, su * 3 + sv - 1, e->cdf.cfl_sign, 8);
+      if (su) WRITE_SYM(e, abs(md.cfl_au) - 1, e->cdf.cfl_alpha[(su - 1) * 3 + sv], 16);
+      if (sv) WRITE_SYM(e, abs(md.cfl_av) - 1, e->cdf.cfl_alpha[(sv - 1) * 3 + su], 16);
+    }
   }
   /* (palette: allow_screen_content_tools = 0; filter intra: disabled; tx_size: TX_MODE_LARGEST) */
 

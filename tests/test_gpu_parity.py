@@ -56,6 +56,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         p.intra_mode_mask = cfgk.get("mode_mask", 0)
         p.intra_angle_delta = cfgk.get("angle_delta", 0)
         p.intra_edge_filter = cfgk.get("intra_edge_filter", 0)
+        p.cfl = cfgk.get("cfl", 0)
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         p.enable_lr = cfgk.get("enable_lr", 0)
         if cfgk.get("deblock", 0) == 2:
@@ -354,6 +355,7 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
                                  cdf_update=0 if cfgk.get("disable_cdf_update") else 1, enable_lr=cfgk.get("enable_lr", 0), deblock=cfgk.get("deblock", 0),
                                  subpel=cfgk.get("subpel", 0), intra_mode_mask=cfgk.get("mode_mask", 0), intra_angle_delta=cfgk.get("angle_delta", 0))
         p.intra_edge_filter = cfgk.get("intra_edge_filter", 0)
+        p.cfl = cfgk.get("cfl", 0)
         if cfgk.get("enable_qm"):
             p.enable_qm, p.qm_min, p.qm_max = 1, cfgk["qm_y"], cfgk["qm_y"]
         frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
@@ -783,15 +785,16 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
             bs = 6   # 64x64 leaves
         ad = int(rng2.integers(0, 2))   # angle deltas
         ef = int(rng2.integers(0, 2))   # enable_intra_edge_filter
+        cf = int(rng2.integers(0, 2))   # chroma from luma
         big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=3000 + it, t=t) for t in range(n)]
         frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
         p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
                                  enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb, deblock=db, subpel=sp, enable_qm=qm, qm_min=qmin, qm_max=qmax,
-                                 intra_angle_delta=ad, intra_edge_filter=ef)
+                                 intra_angle_delta=ad, intra_edge_filter=ef, cfl=cf)
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
         qml = oracle.qm_level(av1mi.cq_to_qindex(cq), qmin, qmax)
         cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq), mode_mask=mask, deblock=db,
-                                    subpel=sp, enable_qm=qm, qm_y=qml, qm_uv=qml, angle_delta=ad, intra_edge_filter=ef,
+                                    subpel=sp, enable_qm=qm, qm_y=qml, qm_uv=qml, angle_delta=ad, intra_edge_filter=ef, cfl=cf,
                                     disable_cdf_update=0 if cdf else 1, me_range=me, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb,
                                     film_grain=1 if fg else 0, fg_y_scaling=2 * fg, fg_c_scaling=fg)
         tus, recs, ref, prev = [], [], None, None
@@ -802,7 +805,7 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
             tus.append(tu)
             recs.append(rec)
             ref, prev = rec, f
-        desc = dict(it=it, ad=ad, ef=ef, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db, sp=sp, qm=qm, qmin=qmin, qmax=qmax)
+        desc = dict(it=it, ad=ad, ef=ef, cf=cf, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db, sp=sp, qm=qm, qmin=qmin, qmax=qmax)
         assert list(sizes) == [len(t) for t in tus], desc
         assert data == b"".join(tus), desc
         fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
@@ -830,6 +833,29 @@ def test_intra_edge_filter_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, ke
     p.intra_edge_filter = 0
     data0, _, _, _ = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n)
     assert data0 != data   # the switch does something on this input
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint,mask,ef,tsb", [(200, 120, 8, 1, 5, 1, 0x7, 0, 1), (202, 122, 10, 2, 3, 1, 0x1FFF, 1, 1), (264, 200, 8, 3, 4, 2, 0x1FFF, 0, 2),
+                                                          (248, 216, 10, 1, 5, 1, 0x7, 1, 1), (184, 176, 8, 2, 6, 240, 0x7, 0, 1), (648, 360, 8, 2, 5, 1, 0x7, 0, 1)])
+def test_chroma_from_luma_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, mask, ef, tsb):
+    """UV_CFL_PRED (spec 7.11.5): subsampled reconstructed luma incl. the overhanging part of edge blocks, the per-plane alpha
+    (least squares + neighbours), the joint decision against the luma-derived chroma mode, cfl_alpha_signs / cfl_alpha_u / _v
+    syntax - on key frames; inter frames of the same chunk code without it.  The oracle's side is pinned by dav1d
+    (tests/golden/*cfl*)."""
+    big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=4300 + w + bs, t=t) for t in range(n)]
+    frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, intra_mode_mask=mask, intra_edge_filter=ef, tile_sb=tsb, cfl=1)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, mode_mask=mask, intra_edge_filter=ef, cfl=1, tile_w_sb=tsb, tile_h_sb=tsb)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert data == b"".join(tus)
+    fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+    for i, rec in enumerate(recs):
+        assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
+    if bs < 6:
+        p.cfl = 0
+        data0, _, _, _ = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n)
+        assert data0 != data   # chroma from luma was chosen somewhere
 
 
 @pytest.mark.parametrize("w,h,bd,n,bs,keyint,lr,tsb", [(70, 58, 8, 1, 5, 1, 0, 1), (202, 122, 10, 3, 5, 240, 0, 1), (130, 66, 8, 3, 4, 2, 1, 1),

@@ -99,6 +99,18 @@ CASES = [
     ("fuzz_ef_bs5", 264, 200, 8, 90, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, fuzz_modes=7, intra_edge_filter=1)),
     ("fuzz_ef_bs6", 264, 200, 8, 91, 0, dict(min_bs_log2=6, max_bs_log2=6, mode_mask=0x1FFF, fuzz_modes=9, intra_edge_filter=1)),
     ("fuzz_ef_tiles2x1_10b", 328, 248, 10, 92, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=17, tile_w_sb=2, tile_h_sb=1, intra_edge_filter=1)),
+    # chroma from luma (UV_CFL_PRED, spec 7.11.5): decision-driven on key frames (alpha by least squares + neighbours),
+    # fuzzed alphas / signs with every block size that allows it, an overhanging block row, levels fuzzed as well
+    ("k200x120_cfl_bs5", 200, 120, 8, 1080, 8, dict(min_bs_log2=5, max_bs_log2=5, cfl=1)),
+    ("k200x120_cfl_all13_ef_bs4_10b", 200, 120, 10, 1080, 9, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1, cfl=1)),
+    ("k202x122_cfl_bs3", 202, 122, 8, 95, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, cfl=1)),
+    ("k248x216_cfl_overhang_bs5_10b", 248, 216, 10, 96, 1, dict(min_bs_log2=5, max_bs_log2=5, cfl=1, deblock=1)),
+    ("k184x176_cfl_bs6", 184, 176, 8, 97, 1, dict(min_bs_log2=6, max_bs_log2=6, cfl=1)),
+    ("fuzz_cfl_bs3", 200, 120, 8, 98, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=3, cfl=1)),
+    ("fuzz_cfl_bs4_10b_ef", 264, 200, 10, 99, 0, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, fuzz_modes=5, intra_edge_filter=1, cfl=1)),
+    ("fuzz_cfl_bs5", 264, 200, 8, 100, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, fuzz_modes=7, cfl=1)),
+    ("fuzz_cfl_tiles2x1_10b", 328, 248, 10, 101, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=17, tile_w_sb=2, tile_h_sb=1, cfl=1)),
+    ("fuzz_cfl_levels_10b", 136, 136, 10, 102, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=14, fuzz_coeffs=19, fuzz_density=6, fuzz_maxlevel=30, cfl=1)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -146,6 +158,8 @@ SEQ_CASES = [
     ("p200x120_angle_all13", 200, 120, 8, 84, 3, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, angle_delta=1)),
     ("p200x120_ef_all13", 200, 120, 8, 93, 3, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1)),
     ("pfuzz_ef_bs3_10b", 136, 120, 10, 94, 3, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=21, intra_edge_filter=1)),
+    ("p200x120_cfl", 200, 120, 8, 103, 3, dict(min_bs_log2=5, max_bs_log2=5, cfl=1)),
+    ("pfuzz_cfl_bs4_10b", 136, 120, 10, 104, 3, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, fuzz_modes=23, cfl=1)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
