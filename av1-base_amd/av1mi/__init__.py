@@ -17,7 +17,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "libav1mi.so")
+LIB_PATH = os.environ.get("AV1MI_LIB") or os.path.join(_HERE, "..", "libav1mi.so")   # AV1MI_LIB: another build of the same library (A/B runs on one box)
 
 # PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in
 # one process do not coexist, so when torch is installed it is imported FIRST: libav1mi.so's

@@ -801,20 +801,48 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     for (int j = 0; j < N; j++) x[j] = S->scratch[so + sl * ST + j];
     Tx1d<LOG2N>::fwd(x, ht);
     const int row = sl;
+    if constexpr (!QM) {
+      // One step for every AC coefficient, another for DC: the dead-zone class of a coefficient is two compares against per-lane
+      // thresholds (no divergent three-way branch), signs go through the sign mask, the dequantiser's product fits a 24-bit
+      // multiply (level < 2^15, step < 2^15), and of the scan key only the last nonzero column is tracked (the key grows with the
+      // column inside a row).  The dequantiser stays behind `if (lv)`: a column with no level in any row costs the wave nothing.
+      const uint32_t acq = (uint32_t)P->ac_q, acr = P->ac_recip;
+      const uint32_t r0 = (3 * acq) >> 3, r1 = acq >> 2, r2 = acq >> 3;
+      const int ta = (CW >> 2) - row, tb = (CW >> 1) - row;   // column j is in dead-zone class 0 below ta, 1 below tb, else 2
+      const int lim = 1 << (7 + bd);
+      int lastj = -1;
+#pragma unroll
+      for (int j = 0; j < CW; j++) {
+        const int v = rshift_round(x[j], SH2);
+        uint32_t q = acq, recip = acr, rnd = j < ta ? r0 : (j < tb ? r1 : r2);
+        if (j == 0) {
+          const bool dc = row == 0;
+          q = dc ? (uint32_t)P->dc_q : acq; recip = dc ? P->dc_recip : acr;
+          rnd = 0 < ta ? (3 * q) >> 3 : (0 < tb ? (q >> 2) : (q >> 3));
+        }
+        const int sgn = v >> 31;
+        const uint32_t a = ((uint32_t)((v ^ sgn) - sgn) << TSH) + rnd;
+        uint32_t lv = __umulhi(a, recip);
+        lv = lv > 0x7FFF ? 0x7FFF : lv;
+        lvl[row * CW + j] = (int16_t)(((int)lv ^ sgn) - sgn);
+        int d = 0;
+        if (lv) {   // (most columns beyond the first few hold no level in any row: the wave skips the block)
+          lastj = j;
+          d = (int)((__umul24(lv, q) & 0xFFFFFF) >> TSH);
+          d = (d ^ sgn) - sgn;
+          d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
+        }
+        x[j] = d;
+      }
+      if (lastj >= 0) { const int d0 = row + lastj; my_key = (d0 << 6) | ((d0 & 1) ? row : lastj); }
+    } else {
     constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
-    const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row : nullptr;
+    const Av1miQmEntry *tab = P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row;
 #pragma unroll
     for (int j = 0; j < CW; j++) {
       const int v = rshift_round(x[j], SH2);
-      uint32_t q, recip;
-      if constexpr (QM) {
-        const Av1miQmEntry e = tab[j * CW];
-        q = e.q; recip = e.recip;
-      } else {
-        const bool dc = (row | j) == 0;
-        q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
-        recip = dc ? P->dc_recip : P->ac_recip;
-      }
+      const Av1miQmEntry e = tab[j * CW];
+      const uint32_t q = e.q, recip = e.recip;
       // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above (n = the coded width)
       const int d0 = row + j;
       const uint32_t rnd = d0 < (CW >> 2) ? (3 * q) >> 3 : (d0 < (CW >> 1) ? (q >> 2) : (q >> 3));
@@ -833,6 +861,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
       }
       x[j] = d;
+    }
     }
 #pragma unroll
     for (int j = CW; j < N; j++) x[j] = 0;
