@@ -39,6 +39,7 @@ static __device__ __forceinline__ int32_t av1_half_btf(int32_t w0, int32_t a, in
   return (__mul24(w0, a) + __mul24(w1, b) + 2048) >> 12;
 }
 #include "txfm_gen.h"
+#include "fdct32_matrix.h"
 
 namespace {
 
@@ -59,6 +60,9 @@ __constant__ int16_t c_dr_deriv[91] = {
   31, 0, 0, 27, 0, 0, 23, 0, 0, 19, 0, 0, 15, 0, 0, 0, 0, 11, 0, 0, 7, 0, 0, 3, 0, 0, 0 };
 __constant__ int16_t c_mode_angle[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
 // Mode_To_Txfm (spec §6.10.x): 0 DCT_DCT 1 ADST_DCT 2 DCT_ADST 3 ADST_ADST
+// luma 32x32 forward transform on the matrix cores: per lane the operand fragments of fdct32_matrix.h (stage-1 B low / high bytes,
+// stage-2 A low / high bytes)
+__device__ const uint32_t c_fdct32_frag[64][16] = AV1_FDCT32_FRAG_INIT;
 __constant__ uint8_t c_mode_txfm[14] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3, 0 };   // [13] = UV_CFL_PRED
 
 // LDS per superblock-wave (~9 KB, so ~4 waves fit a SIMD): decoder-style line buffers instead of the
@@ -429,6 +433,10 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   }
   constexpr int N = 1 << LOG2N;
   constexpr int ST = N + 1;
+  // MM: luma 32x32 blocks run the forward transform as a matrix product on the matrix cores: the residual rows are
+  // then read with 128-bit loads, so they lie 32 apart (16-byte aligned) instead of 33
+  constexpr bool MM = LOG2N == 5 && NPL == 1;
+  constexpr int STR = MM ? 32 : ST;
   constexpr int G = 64 / NPL;              // lanes per group
   constexpr int PIXO = NPL == 1 ? 0 : (N > 16 ? 1024 : 512); // per-group offset inside srcblk / blkpix (NPL == 2: N <= 16, or 32 in the 64x64 build)
   constexpr int SCRO = NPL == 1 ? 0 : (N > 16 ? 32 * 33 : 16 * 17);
@@ -753,7 +761,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       const int sv = S->srcblk[po + p];
       if (final_trip) {
         S->blkpix[po + p] = (uint16_t)pv;
-        if (!fe) S->scratch[so + r * ST + c] = (int16_t)(sv - pv);
+        if (!fe) S->scratch[so + r * STR + c] = (int16_t)(sv - pv);
       } else {
         sad += iabs(sv - pv);
       }
@@ -761,7 +769,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     if (final_trip && fe) {
       wave_sync();
 #pragma unroll 4
-      for (int p = sl; p < N * N; p += G) S->scratch[so + (p >> LOG2N) * ST + (p & (N - 1))] = (int16_t)((int)S->srcblk[po + p] - (int)S->blkpix[po + p]);
+      for (int p = sl; p < N * N; p += G) S->scratch[so + (p >> LOG2N) * STR + (p & (N - 1))] = (int16_t)((int)S->srcblk[po + p] - (int)S->blkpix[po + p]);
     }
     if (!final_trip) {
       sad = wave_sum(sad);
@@ -782,95 +790,190 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   constexpr int TSH = LOG2N == 6 ? 2 : (LOG2N == 5 ? 1 : 0);  // dequant shift of the size class (§7.12.3)
   int32_t x[N];
   const bool tx_lane = sl < N, row_lane = sl < CW;
-  if (tx_lane) {
-#pragma unroll
-    for (int i = 0; i < N; i++) x[i] = (int)S->scratch[so + i * ST + sl] << SH0;
-    Tx1d<LOG2N>::fwd(x, vt);
-#pragma unroll
-    for (int i = 0; i < CW; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
-  }
-  wave_sync();
-  STAMP(3);   // forward columns
   int my_key = -1;  // (anti-diagonal << 6 | position inside it) of the last nonzero level in scan order
   int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk) + po;  // source block is dead: reuse for the levels
-  // dead-zone quantiser + normative dequantiser (§7.12.3) of this lane's coefficient row.  QM: the step of every position
-  // comes from the context's quantiser-matrix table {Round2(q * Quantizer_Matrix, 5), ceil(2^32 / that)}; the matrices are
-  // symmetric, so lanes read entry [j][row] (consecutive addresses across the wave).
-  if (row_lane) {
+  if constexpr (MM) {
+    // ---- forward 32x32 DCT as Y = Cm * X * Cm^T on the matrix cores (v_mfma_i32_32x32x32_i8; tools/mfma_fwd32_ab.hip is the
+    // measured A/B against the butterflies).  Values are split into signed bytes, v = 256 * hi + lo: four products per stage, the two
+    // mixed ones into one accumulator.  Stage 1: A = X (lane = row r, its half h holds columns 16h .. 16h + 15), B = Cm^T; the result
+    // U has its column on the lane and 16 of its rows in the accumulator registers, which is exactly the B operand of stage 2
+    // (A = Cm with its k index in that register order) - no lane movement, no LDS between the stages.  The result again has the
+    // column m (horizontal frequency) on the lane and the rows k = (reg & 3) + 8 * (reg >> 2) + 4 * h in 16 registers: the
+    // quantiser runs on all 64 lanes, 16 coefficients each (the butterfly form: 32 lanes x 32).
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef int v16i_t __attribute__((ext_vector_type(16)));
+    const int mr = lane & 31, mh = lane >> 5;
+    const v4i_t *fr = reinterpret_cast<const v4i_t *>(c_fdct32_frag[lane]);
+    const v4i_t s1_lo = fr[0], s1_hi = fr[1], s2_lo = fr[2], s2_hi = fr[3];
+    const v4i_t q0 = *reinterpret_cast<const v4i_t *>(&S->scratch[so + mr * 32 + 16 * mh]);
+    const v4i_t q1 = *reinterpret_cast<const v4i_t *>(&S->scratch[so + mr * 32 + 16 * mh + 8]);
+    v4i_t a_lo, a_hi;
 #pragma unroll
-    for (int j = 0; j < N; j++) x[j] = S->scratch[so + sl * ST + j];
-    Tx1d<LOG2N>::fwd(x, ht);
-    const int row = sl;
-    if constexpr (!QM) {
-      // One step for every AC coefficient, another for DC: the dead-zone class of a coefficient is two compares against per-lane
-      // thresholds (no divergent three-way branch), signs go through the sign mask, the dequantiser's product fits a 24-bit
-      // multiply (level < 2^15, step < 2^15), and of the scan key only the last nonzero column is tracked (the key grows with the
-      // column inside a row).  The dequantiser stays behind `if (lv)`: a column with no level in any row costs the wave nothing.
+    for (int i = 0; i < 4; i++) {
+      const unsigned e0 = (unsigned)(i < 2 ? q0[2 * i] : q1[2 * i - 4]), e1 = (unsigned)(i < 2 ? q0[2 * i + 1] : q1[2 * i - 3]);
+      a_lo[i] = (int)__builtin_amdgcn_perm(e1, e0, 0x06040200u);   // the low bytes of four residuals
+      // (v + 128) >> 8 of each halfword: add 128 without carrying into the neighbour, take the high bytes
+      const unsigned g0 = ((e0 & 0x7FFF7FFFu) + 0x00800080u) ^ (e0 & 0x80008000u);
+      const unsigned g1 = ((e1 & 0x7FFF7FFFu) + 0x00800080u) ^ (e1 & 0x80008000u);
+      a_hi[i] = (int)__builtin_amdgcn_perm(g1, g0, 0x07050301u);
+    }
+    v16i_t hh = {0}, mid = {0}, ll = {0};
+    hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, s1_hi, hh, 0, 0, 0);
+    mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, s1_lo, mid, 0, 0, 0);
+    mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, s1_hi, mid, 0, 0, 0);
+    ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, s1_lo, ll, 0, 0, 0);
+    v4i_t b_lo = {0, 0, 0, 0}, b_hi = {0, 0, 0, 0};
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int u = ((hh[reg] << 16) + (mid[reg] << 8) + ll[reg] + 512) >> 10;
+      b_lo[reg >> 2] |= (u & 255) << (8 * (reg & 3));
+      b_hi[reg >> 2] |= (((u + 128) >> 8) & 255) << (8 * (reg & 3));
+    }
+    v16i_t hh2 = {0}, mid2 = {0}, ll2 = {0};
+    hh2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(s2_hi, b_hi, hh2, 0, 0, 0);
+    mid2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(s2_hi, b_lo, mid2, 0, 0, 0);
+    mid2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(s2_lo, b_hi, mid2, 0, 0, 0);
+    ll2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(s2_lo, b_lo, ll2, 0, 0, 0);
+    STAMP(3);   // forward transform
+    // ---- dead-zone quantiser of the lane's 16 coefficients (k, m): levels to LDS, the key of the last nonzero one in scan order
+    {
+      const int col = mr;
       const uint32_t acq = (uint32_t)P->ac_q, acr = P->ac_recip;
-      const uint32_t r0 = (3 * acq) >> 3, r1 = acq >> 2, r2 = acq >> 3;
-      const int ta = (CW >> 2) - row, tb = (CW >> 1) - row;   // column j is in dead-zone class 0 below ta, 1 below tb, else 2
-      const int lim = 1 << (7 + bd);
-      int lastj = -1;
+      const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + AV1MI_QM_32X32 + col : nullptr;
 #pragma unroll
-      for (int j = 0; j < CW; j++) {
-        const int v = rshift_round(x[j], SH2);
-        uint32_t q = acq, recip = acr, rnd = j < ta ? r0 : (j < tb ? r1 : r2);
-        if (j == 0) {
-          const bool dc = row == 0;
-          q = dc ? (uint32_t)P->dc_q : acq; recip = dc ? P->dc_recip : acr;
-          rnd = 0 < ta ? (3 * q) >> 3 : (0 < tb ? (q >> 2) : (q >> 3));
-        }
+      for (int reg = 0; reg < 16; reg++) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * mh;
+        const int v = ((hh2[reg] << 16) + (mid2[reg] << 8) + ll2[reg] + 2048) >> 12;
+        uint32_t q, recip;
+        if constexpr (QM) { const Av1miQmEntry e = tab[row * 32]; q = e.q; recip = e.recip; }
+        else if (reg == 0) { const bool dc = (row | col) == 0; q = dc ? (uint32_t)P->dc_q : acq; recip = dc ? P->dc_recip : acr; }
+        else { q = acq; recip = acr; }
+        const int d0 = row + col;
+        const uint32_t rnd = d0 < 8 ? (3 * q) >> 3 : (d0 < 16 ? (q >> 2) : (q >> 3));
         const int sgn = v >> 31;
         const uint32_t a = ((uint32_t)((v ^ sgn) - sgn) << TSH) + rnd;
         uint32_t lv = __umulhi(a, recip);
         lv = lv > 0x7FFF ? 0x7FFF : lv;
-        lvl[row * CW + j] = (int16_t)(((int)lv ^ sgn) - sgn);
+        lvl[row * 32 + col] = (int16_t)(((int)lv ^ sgn) - sgn);
+        if (lv) {
+          const int key = (d0 << 6) | ((d0 & 1) ? row : col);
+          my_key = key > my_key ? key : my_key;
+        }
+      }
+    }
+    wave_sync();
+  } else {
+    if (tx_lane) {
+  #pragma unroll
+      for (int i = 0; i < N; i++) x[i] = (int)S->scratch[so + i * ST + sl] << SH0;
+      Tx1d<LOG2N>::fwd(x, vt);
+  #pragma unroll
+      for (int i = 0; i < CW; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
+    }
+    wave_sync();
+    STAMP(3);   // forward columns
+    // dead-zone quantiser + normative dequantiser (§7.12.3) of this lane's coefficient row.  QM: the step of every position
+    // comes from the context's quantiser-matrix table {Round2(q * Quantizer_Matrix, 5), ceil(2^32 / that)}; the matrices are
+    // symmetric, so lanes read entry [j][row] (consecutive addresses across the wave).
+    if (row_lane) {
+  #pragma unroll
+      for (int j = 0; j < N; j++) x[j] = S->scratch[so + sl * ST + j];
+      Tx1d<LOG2N>::fwd(x, ht);
+      const int row = sl;
+      if constexpr (!QM) {
+        // One step for every AC coefficient, another for DC: the dead-zone class of a coefficient is two compares against per-lane
+        // thresholds (no divergent three-way branch), signs go through the sign mask, the dequantiser's product fits a 24-bit
+        // multiply (level < 2^15, step < 2^15), and of the scan key only the last nonzero column is tracked (the key grows with the
+        // column inside a row).  The dequantiser stays behind `if (lv)`: a column with no level in any row costs the wave nothing.
+        const uint32_t acq = (uint32_t)P->ac_q, acr = P->ac_recip;
+        const uint32_t r0 = (3 * acq) >> 3, r1 = acq >> 2, r2 = acq >> 3;
+        const int ta = (CW >> 2) - row, tb = (CW >> 1) - row;   // column j is in dead-zone class 0 below ta, 1 below tb, else 2
+        const int lim = 1 << (7 + bd);
+        int lastj = -1;
+  #pragma unroll
+        for (int j = 0; j < CW; j++) {
+          const int v = rshift_round(x[j], SH2);
+          uint32_t q = acq, recip = acr, rnd = j < ta ? r0 : (j < tb ? r1 : r2);
+          if (j == 0) {
+            const bool dc = row == 0;
+            q = dc ? (uint32_t)P->dc_q : acq; recip = dc ? P->dc_recip : acr;
+            rnd = 0 < ta ? (3 * q) >> 3 : (0 < tb ? (q >> 2) : (q >> 3));
+          }
+          const int sgn = v >> 31;
+          const uint32_t a = ((uint32_t)((v ^ sgn) - sgn) << TSH) + rnd;
+          uint32_t lv = __umulhi(a, recip);
+          lv = lv > 0x7FFF ? 0x7FFF : lv;
+          lvl[row * CW + j] = (int16_t)(((int)lv ^ sgn) - sgn);
+          int d = 0;
+          if (lv) {   // (most columns beyond the first few hold no level in any row: the wave skips the block)
+            lastj = j;
+            d = (int)((__umul24(lv, q) & 0xFFFFFF) >> TSH);
+            d = (d ^ sgn) - sgn;
+            d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
+          }
+          x[j] = d;
+        }
+        if (lastj >= 0) { const int d0 = row + lastj; my_key = (d0 << 6) | ((d0 & 1) ? row : lastj); }
+      } else {
+      constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
+      const Av1miQmEntry *tab = P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row;
+  #pragma unroll
+      for (int j = 0; j < CW; j++) {
+        const int v = rshift_round(x[j], SH2);
+        const Av1miQmEntry e = tab[j * CW];
+        const uint32_t q = e.q, recip = e.recip;
+        // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above (n = the coded width)
+        const int d0 = row + j;
+        const uint32_t rnd = d0 < (CW >> 2) ? (3 * q) >> 3 : (d0 < (CW >> 1) ? (q >> 2) : (q >> 3));
+        const uint32_t a = ((uint32_t)iabs(v) << TSH) + rnd;
+        uint32_t lv = __umulhi(a, recip);
+        if (lv > 0x7FFF) lv = 0x7FFF;
+        lvl[row * CW + j] = (int16_t)(v < 0 ? -(int)lv : (int)lv);
         int d = 0;
-        if (lv) {   // (most columns beyond the first few hold no level in any row: the wave skips the block)
-          lastj = j;
-          d = (int)((__umul24(lv, q) & 0xFFFFFF) >> TSH);
-          d = (d ^ sgn) - sgn;
+        if (lv) {
+          // scan order: by anti-diagonal, odd ones by increasing row, even ones by increasing column
+          const int key = (d0 << 6) | ((d0 & 1) ? row : j);
+          my_key = key > my_key ? key : my_key;
+          d = (int)(((uint32_t)lv * q) & 0xFFFFFF) >> TSH;
+          const int lim = 1 << (7 + bd);
+          d = v < 0 ? -d : d;
           d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
         }
         x[j] = d;
       }
-      if (lastj >= 0) { const int d0 = row + lastj; my_key = (d0 << 6) | ((d0 & 1) ? row : lastj); }
-    } else {
-    constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
-    const Av1miQmEntry *tab = P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row;
-#pragma unroll
-    for (int j = 0; j < CW; j++) {
-      const int v = rshift_round(x[j], SH2);
-      const Av1miQmEntry e = tab[j * CW];
-      const uint32_t q = e.q, recip = e.recip;
-      // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above (n = the coded width)
-      const int d0 = row + j;
-      const uint32_t rnd = d0 < (CW >> 2) ? (3 * q) >> 3 : (d0 < (CW >> 1) ? (q >> 2) : (q >> 3));
-      const uint32_t a = ((uint32_t)iabs(v) << TSH) + rnd;
-      uint32_t lv = __umulhi(a, recip);
-      if (lv > 0x7FFF) lv = 0x7FFF;
-      lvl[row * CW + j] = (int16_t)(v < 0 ? -(int)lv : (int)lv);
-      int d = 0;
-      if (lv) {
-        // scan order: by anti-diagonal, odd ones by increasing row, even ones by increasing column
-        const int key = (d0 << 6) | ((d0 & 1) ? row : j);
-        my_key = key > my_key ? key : my_key;
-        d = (int)(((uint32_t)lv * q) & 0xFFFFFF) >> TSH;
-        const int lim = 1 << (7 + bd);
-        d = v < 0 ? -d : d;
-        d = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
       }
-      x[j] = d;
+  #pragma unroll
+      for (int j = CW; j < N; j++) x[j] = 0;
     }
-    }
-#pragma unroll
-    for (int j = CW; j < N; j++) x[j] = 0;
   }
   for (int o = G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(my_key, o, 64); my_key = t > my_key ? t : my_key; }
   int eob = 0;
   if (my_key >= 0) {
     const int d0 = my_key >> 6, w = my_key & 63;
     eob = scan_index((d0 & 1) ? w : d0 - w, (d0 & 1) ? d0 - w : w, CW) + 1;
+  }
+  if constexpr (MM) {
+    if (row_lane && eob) {   // the row's levels back from LDS, through the normative dequantiser (spec 7.12.3)
+      const int row = sl, lim = 1 << (7 + bd);
+      const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + AV1MI_QM_32X32 + row : nullptr;
+      const uint32_t *lw = reinterpret_cast<const uint32_t *>(lvl + row * 32);
+#pragma unroll
+      for (int j2 = 0; j2 < 16; j2++) {
+        const uint32_t w = lw[j2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int j = 2 * j2 + e;
+          const int lvs = e ? (int)w >> 16 : (int)(int16_t)(w & 0xFFFF);
+          uint32_t q;
+          if constexpr (QM) q = tab[j * 32].q;
+          else q = (row | j) == 0 ? (uint32_t)P->dc_q : (uint32_t)P->ac_q;
+          const int sgn = lvs >> 31;
+          int d = (int)((__umul24((uint32_t)((lvs ^ sgn) - sgn), q) & 0xFFFFFF) >> TSH);
+          d = (d ^ sgn) - sgn;
+          x[j] = d < -lim ? -lim : (d > lim - 1 ? lim - 1 : d);
+        }
+      }
+    }
   }
   if (row_lane && eob) {
     Tx1d<LOG2N>::inv(x, ht);

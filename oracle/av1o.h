@@ -128,6 +128,8 @@ long av1o_write_sequence_header(const Av1oConfig *cfg, uint8_t *out, size_t cap)
 
 /* ---- exported building blocks (tested individually / compared with the HIP kernels) ---- */
 void av1o_fwd_txfm2d(const int32_t *resid, int stride, int32_t *coef, int log2n, int tx_type, int bd);
+/* 32x32 DCT_DCT as U = (X * Cm^T + 512) >> 10, Y = (Cm * U + 2048) >> 12 with Cm = round(4096 * orthonormal DCT-II) (fdct32_matrix.h) */
+void av1o_fwd_dct32x32_matrix(const int32_t *resid, int stride, int32_t *coef);
 void av1o_inv_txfm2d_add(const int32_t *dq, uint16_t *dst, int stride, int log2n, int tx_type, int bd, int eob);
 void av1o_inv_txfm2d(const int32_t *dq, int32_t *resid, int log2n, int tx_type, int bd);
 void av1o_idct1d(int32_t *x, int log2n);

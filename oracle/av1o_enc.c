@@ -786,7 +786,10 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
       if ((fuzz_rand(e) & 63) == 0) break; /* vary eob */
     }
   } else {
-    av1o_fwd_txfm2d(resid, n, coef, log2n, tx_type, bd);
+    /* luma 32x32 blocks: the forward transform is the exact-integer matrix product of DESIGN.md 3.4b (what the HIP path's matrix
+     * cores compute); every other size and plane: the butterfly networks */
+    if (plane == 0 && log2n == 5) av1o_fwd_dct32x32_matrix(resid, n, coef);
+    else av1o_fwd_txfm2d(resid, n, coef, log2n, tx_type, bd);
     for (i = 0; i < cw; i++)
       for (j = 0; j < cw; j++) {
         int32_t v = coef[i * n + j];

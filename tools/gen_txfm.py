@@ -378,6 +378,49 @@ def main():
     p2 = os.path.join(HERE, "..", "oracle", "txfm_tables.h")
     open(p2, "w").write("\n".join(tb) + "\n")
     print("wrote", os.path.relpath(p1), "and", os.path.relpath(p2))
+    emit_fdct32_matrix()
+
+
+def fdct32_matrix():
+    """Cm[k][n] = round(4096 * orthonormal 32-point DCT-II): the luma 32x32 forward transform as an exact-integer matrix product
+    (the matrix cores run it: v_mfma_i32_32x32x32_i8 on signed-byte halves of matrix and data)."""
+    return [[int(round(4096.0 * math.sqrt(2.0 / 32) * (math.sqrt(0.5) if k == 0 else 1.0) * math.cos((2 * n + 1) * k * math.pi / 64)))
+             for n in range(32)] for k in range(32)]
+
+
+def emit_fdct32_matrix():
+    cm = fdct32_matrix()
+    assert max(abs(v) for r in cm for v in r) <= 1024
+    lo8 = lambda v: v & 255
+    hi8 = lambda v: ((v + 128) >> 8) & 255
+    pack = lambda b: b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24)
+    out = ["/* GENERATED by tools/gen_txfm.py - do not edit.  The luma 32x32 forward transform as a matrix product:",
+           " *   U[r][m] = (sum_c X[r][c] * Cm[m][c] + 512) >> 10,   Y[k][m] = (sum_r Cm[k][r] * U[r][m] + 2048) >> 12",
+           " * with Cm = round(4096 * orthonormal DCT-II) - 4 x the orthonormal 2-D DCT, the scale of the butterfly form.",
+           " * AV1_FDCT32_FRAG: per lane of a wave the four operand fragments of v_mfma_i32_32x32x32_i8 (16 signed bytes each,",
+           " * value = 256 * hi + lo, lo = (int8)(v & 255), hi = (v + 128) >> 8): stage-1 B = Cm^T low, high (lane = column m, bytes",
+           " * = Cm[m][16h + j]); stage-2 A = Cm low, high with k in the order the accumulator registers hold rows",
+           " * (byte j of lane half h = Cm[k][(j & 3) + 8 * (j >> 2) + 4 * h]). */",
+           "#ifndef AV1MI_FDCT32_MATRIX_H", "#define AV1MI_FDCT32_MATRIX_H", "#include <stdint.h>",
+           "#define AV1_FDCT32_MATRIX_INIT { \\"]
+    for r in cm:
+        out.append("  { " + ", ".join("%d" % v for v in r) + " }, \\")
+    out.append("}")
+    out.append("#define AV1_FDCT32_FRAG_INIT { \\")
+    for lane in range(64):
+        r, h = lane & 31, lane >> 5
+        s1 = [cm[r][16 * h + j] for j in range(16)]
+        s2 = [cm[r][(j & 3) + 8 * (j >> 2) + 4 * h] for j in range(16)]
+        words = []
+        for vals, f in ((s1, lo8), (s1, hi8), (s2, lo8), (s2, hi8)):
+            b = [f(v) for v in vals]
+            words += [pack(b[4 * i:4 * i + 4]) for i in range(4)]
+        out.append("  { " + ", ".join("0x%08xu" % w for w in words) + " }, \\")
+    out.append("}")
+    out.append("#endif")
+    for path in (os.path.join(HERE, "..", "av1-base_amd", "csrc", "fdct32_matrix.h"), os.path.join(HERE, "..", "oracle", "fdct32_matrix.h")):
+        open(path, "w").write("\n".join(out) + "\n")
+        print("wrote", os.path.relpath(path))
 
 
 if __name__ == "__main__":
