@@ -122,10 +122,12 @@ __device__ __forceinline__ void q_post(int *slot, int v) {
 // Ordering between the lanes of ONE wave that exchange data through LDS: the wave's LDS operations complete in order, so
 // waiting for them is all a "barrier" has to do.  (__syncthreads() would be a barrier of the whole workgroup, and the two waves
 // of a split tile walk do not run the same number of them.)
+// The fences name the LDS address space only: a generic workgroup fence also waits for every global store the wave has in flight
+// (the levels and the reconstruction of the block just finished - about a microsecond each), which nothing here depends on.
 __device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // ---- diagnostic build only (-DAV1MI_STAMPS, tools/stamp_recon.py): where a transform item spends its cycles.  Lane 0 adds the
@@ -433,7 +435,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   }
   constexpr int N = 1 << LOG2N;
   constexpr int ST = N + 1;
-  // MM: luma 32x32 blocks run the forward transform as a matrix product on the matrix cores (DESIGN.md 3.4b): the residual rows are
+  // MM: luma 32x32 blocks run the forward transform as a matrix product on the matrix cores (DESIGN.md §3 item 3e): the residual rows are
   // then read with 128-bit loads, so they lie 32 apart (16-byte aligned) instead of 33
   constexpr bool MM = LOG2N == 5 && NPL == 1;
   constexpr int STR = MM ? 32 : ST;
@@ -635,7 +637,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     first = 13;
   }
   STAMP(1);   // DC value + the default candidates' SADs
-  // ---- chroma from luma (spec 7.11.5; DESIGN.md 3.3c): key-frame blocks up to 32x32 luma.  The luma item left the block's
+  // ---- chroma from luma (spec 7.11.5; DESIGN.md §3 item 3d): key-frame blocks up to 32x32 luma.  The luma item left the block's
   // subsampled reconstruction minus its average (Q3) behind the two groups' staging areas; lanes 0-31 decide U's alpha and lanes
   // 32-63 V's at the same time: least-squares estimate, then the SAD of the estimate and its two neighbours.
   constexpr int CFL_ACO = 2 * 16 * 17;   // offset of that buffer in S->scratch (chroma blocks up to 16x16, NPL == 2)

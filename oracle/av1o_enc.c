@@ -786,7 +786,7 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
       if ((fuzz_rand(e) & 63) == 0) break; /* vary eob */
     }
   } else {
-    /* luma 32x32 blocks: the forward transform is the exact-integer matrix product of DESIGN.md 3.4b (what the HIP path's matrix
+    /* luma 32x32 blocks: the forward transform is the exact-integer matrix product of DESIGN.md §3 item 3e (what the HIP path's matrix
      * cores compute); every other size and plane: the butterfly networks */
     if (plane == 0 && log2n == 5) av1o_fwd_dct32x32_matrix(resid, n, coef);
     else av1o_fwd_txfm2d(resid, n, coef, log2n, tx_type, bd);
@@ -1205,7 +1205,7 @@ static int cfl_sad(const uint16_t *src, int sstride, const int16_t *ac, int nc, 
     for (j = 0; j < nc; j++) s += abs((int)src[i * sstride + j] - cfl_px(dc, alpha, ac[i * nc + j], maxv));
   return s;
 }
-/* the encoder's alpha for one plane (DESIGN.md 3.3c): least-squares estimate 8 * sum(a * d) / sum(a * a) with a = ac >> 3 and
+/* the encoder's alpha for one plane (DESIGN.md §3 item 3d): least-squares estimate 8 * sum(a * d) / sum(a * a) with a = ac >> 3 and
  * d = source - dc, rounded to nearest and clamped to -16 .. 16; then the SAD of the estimate and its two neighbours, first minimum
  * in the order estimate, -1, +1 */
 static int cfl_choose_alpha(const uint16_t *src, int sstride, const int16_t *ac, int nc, int dc, int maxv, int *sad_out) {

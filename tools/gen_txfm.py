@@ -383,7 +383,7 @@ def main():
 
 def fdct32_matrix():
     """Cm[k][n] = round(4096 * orthonormal 32-point DCT-II): the luma 32x32 forward transform as an exact-integer matrix product
-    (DESIGN.md 3.4b; the matrix cores run it: v_mfma_i32_32x32x32_i8 on signed-byte halves of matrix and data)."""
+    (DESIGN.md §3 item 3e; the matrix cores run it: v_mfma_i32_32x32x32_i8 on signed-byte halves of matrix and data)."""
     return [[int(round(4096.0 * math.sqrt(2.0 / 32) * (math.sqrt(0.5) if k == 0 else 1.0) * math.cos((2 * n + 1) * k * math.pi / 64)))
              for n in range(32)] for k in range(32)]
 

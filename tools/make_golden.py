@@ -99,7 +99,7 @@ CASES = [
     ("fuzz_ef_bs5", 264, 200, 8, 90, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, fuzz_modes=7, intra_edge_filter=1)),
     ("fuzz_ef_bs6", 264, 200, 8, 91, 0, dict(min_bs_log2=6, max_bs_log2=6, mode_mask=0x1FFF, fuzz_modes=9, intra_edge_filter=1)),
     ("fuzz_ef_tiles2x1_10b", 328, 248, 10, 92, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=17, tile_w_sb=2, tile_h_sb=1, intra_edge_filter=1)),
-    # chroma from luma (UV_CFL_PRED, spec 7.11.5): decision-driven on key frames (alpha by least squares + neighbours, DESIGN.md 3.3c),
+    # chroma from luma (UV_CFL_PRED, spec 7.11.5): decision-driven on key frames (alpha by least squares + neighbours, DESIGN.md §3 item 3d),
     # fuzzed alphas / signs with every block size that allows it, an overhanging block row, levels fuzzed as well
     ("k200x120_cfl_bs5", 200, 120, 8, 1080, 8, dict(min_bs_log2=5, max_bs_log2=5, cfl=1)),
     ("k200x120_cfl_all13_ef_bs4_10b", 200, 120, 10, 1080, 9, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, angle_delta=1, intra_edge_filter=1, cfl=1)),
