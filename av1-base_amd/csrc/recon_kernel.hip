@@ -1,11 +1,13 @@
 // recon_kernel.hip - closed-loop reconstruction: one tile (1 or 2x2 64x64 superblocks) per wavefront, every tile of every
 // key frame of a chunk in one launch (recon_sb_kernel); inter frames one at a time, in two launches - every block as an
-// inter block in parallel (recon_inter_pre_kernel), then the tile walk that decides and codes the intra winners.
+// inter block in parallel (recon_inter_pre_kernel), then the tile walk that decides and codes the intra winners - a workgroup of
+// two waves per tile there: the luma wave takes the decisions and posts them through LDS, the chroma wave follows one behind.
 //
 // Replaces the per-superblock inner loop that the reference runs inside an external SVT-AV1
 // worker (av1an -> SVT-AV1, reached through `run_av1an`,
 // /root/reference/crates/daemon/src/encode/av1an.rs:126-139):
-// directional/smooth/Paeth/DC intra prediction (AV1 spec §7.11.2), forward DCT/ADST, dead-zone
+// directional/smooth/Paeth/DC intra prediction (AV1 spec §7.11.2) with angle deltas and, in the EXT instantiations, the intra
+// edge filter / upsampling (§7.11.2.7-12) and chroma from luma (§7.11.5); forward DCT/ADST, dead-zone
 // quantiser, normative dequantiser (§7.12.3) and inverse DCT/ADST (§7.13.3).
 //
 // MI355X mapping: one 64-lane wave owns one tile; the edges its blocks predict from
@@ -13,7 +15,11 @@
 // HBM; source pixels are read once (coalesced rows); transforms run one row or
 // column per lane on VGPR-resident straight-line butterflies (txfm_gen.h) with the 2-D
 // transposition staged through a padded LDS tile (stride n+1: conflict-free for both row and
-// column access); quantised levels are staged in LDS and leave as 16-byte-per-lane stores.
+// column access) - except the forward transform of luma 32x32 blocks, an exact-integer matrix product on the matrix cores
+// (eight v_mfma_i32_32x32x32_i8 on signed-byte halves, fdct32_matrix.h; measured against the butterflies by
+// tools/mfma_fwd32_ab.hip); quantised levels are staged in LDS and leave as 16-byte-per-lane stores.
+// The transform items are `noinline` functions: the library is built with -fno-optimize-sibling-calls so that they save no
+// callee-saved registers (DESIGN.md §4.2 iv).
 // Algorithmic HBM traffic per superblock: source read once, reconstruction written once, levels
 // written once (SURVEY.md §8d "stage A").
 #include <hip/hip_runtime.h>

@@ -503,6 +503,7 @@ def extra_configs(base):
     return [
         mk("cfg2_1080p_intra_all13", mode_mask=0x1FFF),
         mk("cfg2_1080p_intra_64x64", block_log2=6),
+        mk("cfg2_1080p_intra_x4", chunks_per_gpu=4),   # the product's default: AV1MI_DEFAULT_WORKERS_PER_GPU chunks in flight per GPU
         mk("cfg3_1080p_ippp", keyint=240),
         mk("cfg3_1080p_ippp_x4", keyint=240, chunks_per_gpu=4),
         mk("cfg4_4k_ippp_chunk", width=3840, height=2160, frames=30, keyint=240, seed=2160),
