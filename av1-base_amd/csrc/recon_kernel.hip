@@ -731,7 +731,10 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     const int mode = final_trip ? best_mode : m;
     if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
     bool mc_in_lds = false;  // the motion-compensated prediction already sits in blkpix (sub-sample position, EIGHTTAP)
-    if constexpr (INTER) {
+    // (sub-sample motion compensation is compiled into the PH == 1 items of the sub-sample kernels only - there EXT says so: its
+    // LDS window, 5.6 KB, took the whole-sample inter pass from 16 to 12 waves per CU, and the walk (PH == 2) never predicts an
+    // inter block)
+    if constexpr (INTER && PH == 1 && EXT) {
       if (final_trip && ii.is_inter && P->subpel) {
         const int ss = plane0 > 0;
         const int px0 = (gx << 4) + ((2 * ii.mv_col) >> ss), py0 = (gy << 4) + ((2 * ii.mv_row) >> ss);
@@ -1258,7 +1261,7 @@ __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribut
 // and the levels in place and the eobs in a provisional block-info entry; recon_sb_kernel then walks the tiles in order for the part
 // that does depend on neighbours - the intra SAD of the decision and the blocks intra prediction wins.
 // (As one kernel a P frame was 510 waves of six serial block passes: 290 us of latency on the chunk's serial chain.)
-template <typename PIX, bool QM>
+template <typename PIX, bool QM, bool SP /* sub-sample motion vectors (P->subpel) */>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : 4))) recon_inter_pre_kernel(const Av1miDevParams *__restrict__ Pd,
                                                      const PIX *__restrict__ src, PIX *__restrict__ rec, int16_t *__restrict__ levels,
                                                      Av1miBlkInfo *__restrict__ blk, const PIX *__restrict__ ref,
@@ -1299,21 +1302,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
       if (blockIdx.z == 0) {
         switch (bsl) {
 #if AV1MI_RECON_BIG
-          case 6: tx_item<PIX, 6, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          case 6: tx_item<PIX, 6, 1, true, 1, QM, 1, 0, SP>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
 #endif
-          case 5: tx_item<PIX, 5, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
-          case 4: tx_item<PIX, 4, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
-          default: tx_item<PIX, 3, 1, true, 1, QM, 1, 0, false>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          case 5: tx_item<PIX, 5, 1, true, 1, QM, 1, 0, SP>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          case 4: tx_item<PIX, 4, 1, true, 1, QM, 1, 0, SP>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
+          default: tx_item<PIX, 3, 1, true, 1, QM, 1, 0, SP>(cx, src, rec, 0, bx, by, mode, ii, lv_y, lv_y, g_sb.eobs, -1); break;
         }
         if (threadIdx.x == 0) bi->eob[0] = (uint16_t)g_sb.eobs[0];
       } else {
         switch (bsl) {
 #if AV1MI_RECON_BIG
-          case 6: tx_item<PIX, 5, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          case 6: tx_item<PIX, 5, 2, true, 1, QM, 1, 0, SP>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
 #endif
-          case 5: tx_item<PIX, 4, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
-          case 4: tx_item<PIX, 3, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
-          default: tx_item<PIX, 2, 2, true, 1, QM, 1, 0, false>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          case 5: tx_item<PIX, 4, 2, true, 1, QM, 1, 0, SP>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          case 4: tx_item<PIX, 3, 2, true, 1, QM, 1, 0, SP>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
+          default: tx_item<PIX, 2, 2, true, 1, QM, 1, 0, SP>(cx, src, rec, 1, bx >> 1, by >> 1, mode, ii, lv_u, lv_v, g_sb.eobs + 1, -1); break;
         }
         if (threadIdx.x == 0) { bi->eob[1] = (uint16_t)g_sb.eobs[1]; bi->eob[2] = (uint16_t)g_sb.eobs[2]; }
       }
@@ -1346,15 +1349,17 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
   if (inter) {  // first launch of an inter frame: every block as an inter block, all at once (see recon_inter_pre_kernel)
     const int g = P->max_bs_log2 > (AV1MI_RECON_BIG ? 6 : 5) ? (AV1MI_RECON_BIG ? 6 : 5) : P->max_bs_log2, cell = 1 << g;
     dim3 pgrid((P->width + cell - 1) / cell, (P->height + cell - 1) / cell, 2);   // z: luma | chroma
-#define PRE_LAUNCH(PIXT)                                                                                                                     \
+#define PRE_LAUNCH2(PIXT, SPV)                                                                                                               \
     do {                                                                                                                                     \
-      if (P->qm_tab) hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, true>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec, \
+      if (P->qm_tab) hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, true, SPV>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec, \
                                         levels, blk, (const PIXT *)ref, me_best, g);                                                         \
-      else hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, false>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec,          \
+      else hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, false, SPV>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec,          \
                               levels, blk, (const PIXT *)ref, me_best, g);                                                                   \
     } while (0)
+#define PRE_LAUNCH(PIXT) do { if (P->subpel) PRE_LAUNCH2(PIXT, true); else PRE_LAUNCH2(PIXT, false); } while (0)
     if (P->bit_depth == 8) PRE_LAUNCH(uint8_t); else PRE_LAUNCH(uint16_t);
 #undef PRE_LAUNCH
+#undef PRE_LAUNCH2
   }
   // quantiser matrices (P->qm_tab): kernels of their own, so the plain quantiser's registers and scratch are what they were
 #define RECON_LAUNCH2(PIXT, INTERV, TSBV, EXTV)                                                                                             \
