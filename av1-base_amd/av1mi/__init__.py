@@ -42,7 +42,7 @@ ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", 
 class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "bit_depth", "cq_level", "keyint", "block_log2", "cdf_update",
                                           "enable_cdef", "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec",
-                                          "cdef_damping")] + [("intra_mode_mask", C.c_uint32), ("film_grain", C.c_uint32), ("first_frame", C.c_uint32), ("me_range", C.c_uint32), ("enable_lr", C.c_uint32), ("tile_sb", C.c_uint32), ("deblock", C.c_uint32), ("enable_qm", C.c_uint32), ("qm_min", C.c_uint32), ("qm_max", C.c_uint32), ("subpel", C.c_uint32), ("color_range", C.c_uint32), ("intra_angle_delta", C.c_uint32), ("intra_edge_filter", C.c_uint32), ("cfl", C.c_uint32)]
+                                          "cdef_damping")] + [("intra_mode_mask", C.c_uint32), ("film_grain", C.c_uint32), ("first_frame", C.c_uint32), ("me_range", C.c_uint32), ("enable_lr", C.c_uint32), ("tile_sb", C.c_uint32), ("deblock", C.c_uint32), ("enable_qm", C.c_uint32), ("qm_min", C.c_uint32), ("qm_max", C.c_uint32), ("subpel", C.c_uint32), ("color_range", C.c_uint32), ("intra_angle_delta", C.c_uint32), ("intra_edge_filter", C.c_uint32), ("cfl", C.c_uint32), ("tx_search", C.c_uint32)]
 
 
 class Buf(C.Structure):

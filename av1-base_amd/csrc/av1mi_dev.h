@@ -41,6 +41,7 @@ struct Av1miDevParams {
   int angle_delta;          // 1: directional winners of the luma mode decision are refined over the angle deltas -3 .. +3
   int edge_filter;          // enable_intra_edge_filter
   int cfl;                  // chroma from luma is a candidate (key frames, blocks up to 32x32)
+  int tx_search;            // identity transform for sparse intra luma residuals
   int enable_cdef, cdef_y_pri, cdef_y_sec, cdef_uv_pri, cdef_uv_sec, cdef_damping;
   int disable_cdf_update;
   // plane geometry in samples
@@ -83,7 +84,8 @@ struct Av1miBlkInfo {
   uint8_t is_inter; // inter frames: 1 = predicted from LAST_FRAME with `mv`
   uint16_t eob[3];
   int16_t mv_row, mv_col;  // 1/8 luma samples
-  uint16_t angle;   // angle delta + 3 of a directional intra mode (3 = none), luma and chroma alike
+  uint16_t angle;   // bits 0-2: angle delta + 3 of a directional intra mode (3 = none), luma and chroma alike; bit 3: luma IDTX;
+                    // bits 4-9 / 10-15: chroma-from-luma alpha U / V (6-bit two's complement; both zero = not chroma from luma)
 };
 static_assert(sizeof(Av1miBlkInfo) == 16, "block info is one 16-byte record");
 

@@ -173,6 +173,8 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
 template <bool FULL, int TSB>
 __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int adapt, const TileGeo &tg, int plane, int log2n, int x4,
                                            int y4, int eob, int ymode, int is_inter, const int16_t *lv_global) {
+  const int idtx = ymode >> 8;   // bit 8 of the mode argument: the luma block uses the identity transform
+  ymode &= 255;
   const int ptype = plane > 0;
   const int txs = log2n - 2;
   const int w4 = (1 << log2n) >> 2;
@@ -210,9 +212,10 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       else if (log2n == 5) sym_wide<1>(y, lane, adapt, 1, CL::INTER_TX3 + 3 * 3, 2);
       // (TX_64X64: the transform set is DCT only, nothing is coded)
     } else if (plane == 0 && log2n <= 4) {
+      // intra_tx_type: the mode's default type, or IDTX (symbol 0 of both intra sets) when the reconstruction chose it
       const int tt = c_mode_txfm[ymode];
-      if (log2n <= 3) sym_wide(y, lane, adapt, c_txsym_set1[tt], CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
-      else sym_wide(y, lane, adapt, c_txsym_set2[tt], CL::TX_SET2 + ((log2n - 2) * 13 + ymode) * 6, 5);
+      if (log2n <= 3) sym_wide(y, lane, adapt, idtx ? 0 : c_txsym_set1[tt], CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
+      else sym_wide(y, lane, adapt, idtx ? 0 : c_txsym_set2[tt], CL::TX_SET2 + ((log2n - 2) * 13 + ymode) * 6, 5);
     }
     {
       const int eob_pt = eob <= 2 ? eob : floor_log2((unsigned)(eob - 1)) + 2;
@@ -712,14 +715,14 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
             const int lm = uni(c_intra_mode_ctx[avail_l ? INFO(b8x - 1, b8y).ymode : 0]);
             sym_wide(y, lane, adapt, ymode, CL::KF_Y_MODE + (am * 5 + lm) * 14, 13);
           }
-          // chroma: the luma mode at luma's angle delta, or chroma from luma (bit 3 of `angle`; alphas + 16 in bits 4-9 / 10-15)
-          const int ainfo = uni(INFO(b8x, b8y).angle), adelta = ainfo & 7, cfl = (ainfo >> 3) & 1;
+          // chroma: the luma mode at luma's angle delta, or chroma from luma (`angle` bits 4-9 / 10-15: the alphas, not both zero)
+          const int ainfo = uni(INFO(b8x, b8y).angle), adelta = ainfo & 7, cfl = (ainfo >> 4) != 0;
           if (ymode >= 1 && ymode <= 8) sym_wide(y, lane, adapt, adelta, CL::ANGLE_DELTA + (ymode - 1) * 8, 7);
           const int uvmode = cfl ? 13 : ymode;
           const int cfl_allowed = n <= 32;
           sym_wide(y, lane, adapt, uvmode, CL::UV_MODE + (cfl_allowed * 13 + ymode) * 15, cfl_allowed ? 14 : 13);
           if (cfl) {   // read_cfl_alphas (spec 5.11.45)
-            const int au = ((ainfo >> 4) & 63) - 16, av = ((ainfo >> 10) & 63) - 16;
+            const int au = ((ainfo >> 4) & 63) - 2 * ((ainfo >> 4) & 32), av = ((ainfo >> 10) & 63) - 2 * ((ainfo >> 10) & 32);   // 6-bit two's complement
             const int su = au == 0 ? 0 : (au < 0 ? 1 : 2), sv = av == 0 ? 0 : (av < 0 ? 1 : 2);
             sym_wide(y, lane, adapt, su * 3 + sv - 1, CL::CFL_SIGN, 8);
             if (su) sym_wide(y, lane, adapt, iabs(au) - 1, CL::CFL_ALPHA + ((su - 1) * 3 + sv) * 17, 16);
@@ -740,7 +743,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
           for (int pl = 0; pl < 3; pl++) {
             const int l2 = pl ? log2c : bsl;
             const int16_t *lvp = sb_levels + av1mi_levels_off(pl, bx, by);
-            sym_coeffs<FULL, TSB>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode, is_inter, lvp);
+            sym_coeffs<FULL, TSB>(y, lane, adapt, tg, pl, l2, pl ? bx >> 3 : bx >> 2, pl ? by >> 3 : by >> 2, pl == 0 ? eob0 : (pl == 1 ? eob1 : eob2), ymode | (pl == 0 ? ((uni(INFO(b8x, b8y).angle) >> 3) & 1) << 8 : 0), is_inter, lvp);
           }
         }
       }

@@ -185,7 +185,13 @@ __device__ __forceinline__ int clamp_bits(int v, int bits) {
   return v < lo ? lo : (v > hi ? hi : v);
 }
 
-// ---- 1-D transforms (type: 0 DCT, 1 ADST) ---------------------------------------------------
+// ---- 1-D transforms (type: 0 DCT, 1 ADST, 3 identity) -----------------------------------------
+// identity transform (spec 7.13.2.15; the forward one is the same scaling): x * sqrt(2), * 2, * 2 sqrt(2) for 4, 8, 16 points
+template <int LOG2N>
+__device__ __forceinline__ void ident1d(int32_t *x) {
+#pragma unroll
+  for (int i = 0; i < (1 << LOG2N); i++) x[i] = LOG2N == 2 ? (x[i] * 5793 + 2048) >> 12 : (LOG2N == 3 ? x[i] * 2 : (x[i] * 11586 + 2048) >> 12);
+}
 template <int LOG2N> struct Tx1d;
 template <> struct Tx1d<2> {
   static __device__ __forceinline__ void iadst(int32_t *x) {
@@ -204,16 +210,16 @@ template <> struct Tx1d<2> {
     int y0 = s0 + s2 + s5, y1 = 3344 * s7, y2 = s1 - s3 + s6, y3 = s4;
     x[0] = (y0 + y3 + 2048) >> 12; x[1] = (y1 + 2048) >> 12; x[2] = (y2 - y3 + 2048) >> 12; x[3] = (y2 - y0 + y3 + 2048) >> 12;
   }
-  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t) fadst(x); else av1_fdct4(x); }
-  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t) iadst(x); else av1_idct4(x); }
+  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t == 3) ident1d<2>(x); else if (t) fadst(x); else av1_fdct4(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t == 3) ident1d<2>(x); else if (t) iadst(x); else av1_idct4(x); }
 };
 template <> struct Tx1d<3> {
-  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t) av1_fadst8(x); else av1_fdct8(x); }
-  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t) av1_iadst8(x); else av1_idct8(x); }
+  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t == 3) ident1d<3>(x); else if (t) av1_fadst8(x); else av1_fdct8(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t == 3) ident1d<3>(x); else if (t) av1_iadst8(x); else av1_idct8(x); }
 };
 template <> struct Tx1d<4> {
-  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t) av1_fadst16(x); else av1_fdct16(x); }
-  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t) av1_iadst16(x); else av1_idct16(x); }
+  static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t == 3) ident1d<4>(x); else if (t) av1_fadst16(x); else av1_fdct16(x); }
+  static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t == 3) ident1d<4>(x); else if (t) av1_iadst16(x); else av1_idct16(x); }
 };
 template <> struct Tx1d<5> {
   static __device__ __forceinline__ void fwd(int32_t *x, int) { av1_fdct32(x); }
@@ -792,7 +798,17 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   STAMP(2);   // other candidates, decision, prediction + residual
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
   const int txt = (LOG2N <= 4 && !(INTER && ii.is_inter)) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
-  const int vt = txt & 1, ht = txt >> 1;  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
+  // transform type search (tx_search; EXT instantiations): an intra luma block of up to 16x16 whose residual
+  // is sparse - at most one sample in eight nonzero - takes the identity transform (IDTX) both ways
+  int idtx = 0;
+  if constexpr (EXT && NPL == 1 && LOG2N <= 4 && PH != 1) {
+    if (plane0 == 0 && P->tx_search && !(INTER && ii.is_inter)) {
+      int nz = 0;
+      for (int p = sl; p < N * N; p += G) nz += S->scratch[so + (p >> LOG2N) * STR + (p & (N - 1))] != 0;
+      idtx = uniform_i(wave_sum(nz) * 8 <= N * N);
+    }
+  }
+  const int vt = idtx ? 3 : (txt & 1), ht = idtx ? 3 : ((txt >> 1) & 1);  // ADST_DCT(1): vertical ADST; DCT_ADST(2): horizontal ADST
   // 64-point transforms (64x64 build): only the 32x32 low-frequency corner is coded (CW = 32) - the column pass keeps its first
   // 32 outputs, the row pass runs on 32 lanes and keeps 32, the inverse passes take 32 inputs (zeros beyond) and give 64 outputs
   constexpr int CW = N > 32 ? 32 : N;
@@ -931,7 +947,11 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   #pragma unroll
       for (int j = 0; j < CW; j++) {
         const int v = rshift_round(x[j], SH2);
-        const Av1miQmEntry e = tab[j * CW];
+        Av1miQmEntry e = tab[j * CW];
+        if (idtx) {   // the matrices apply to the 2-D DCT / ADST types only (spec 7.12.3: PlaneTxType < IDTX)
+          const bool dc = (row | j) == 0;
+          e.q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q; e.recip = dc ? P->dc_recip : P->ac_recip;
+        }
         const uint32_t q = e.q, recip = e.recip;
         // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above (n = the coded width)
         const int d0 = row + j;
@@ -1065,7 +1085,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       return (1 << 16) | ((au + 16) << 17) | ((av + 16) << 23) | (3 << 4) | 13;
     }
   }
-  return ((INTER ? ii.is_inter : 0) << 8) | ((best_delta + 3) << 4) | best_mode;
+  return (idtx << 12) | ((INTER ? ii.is_inter : 0) << 8) | ((best_delta + 3) << 4) | best_mode;
 }
 
 // Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
@@ -1139,14 +1159,15 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         default: dec = tx_item<PIX, 3, 1, INTER, TSB, QM, (INTER ? 2 : 0), WL, EXT>(cx, frame, rec_frame, 0, bx, by, mode, ii, lv_y, lv_y, eo, qi); break;
       }
       dec = uniform_i(dec);
-      if (SPLIT) {   // the luma block is finished: its eob for the block-info entry, which the chroma wave writes
-        if (cx.lane == 0) q_post(&g_q.e0[qi], eo[0]);
+      if (SPLIT) {   // the luma block is finished: its eob (and identity-transform flag) for the block-info entry, which the chroma wave writes
+        if (cx.lane == 0) q_post(&g_q.e0[qi], eo[0] | (((dec >> 12) & 1) << 12));
         continue;
       }
     } else {
       dec = q_wait(&g_q.dec[qi]);
     }
-    mode = dec & 0x7F; ii.is_inter = dec >> 8;   // the luma pass decides (mode and angle delta); the chroma pass follows it
+    int idtx = (dec >> 12) & 1;
+    mode = dec & 0x7F; ii.is_inter = (dec >> 8) & 1;   // the luma pass decides (mode and angle delta); the chroma pass follows it
     int *eo = SbSel<WC>::get()->eobs;
     int cdec = 0;   // chroma item's return: chroma from luma in bits 16 .. 28
     switch (bsl) {
@@ -1159,7 +1180,8 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     }
     {  // the block's info into every 8x8 unit it covers: one lane per unit
       const int n8 = n >> 3;
-      const int e0 = SPLIT ? q_wait(&g_q.e0[qi]) : eo[0];
+      int e0 = SPLIT ? q_wait(&g_q.e0[qi]) : eo[0];
+      if (SPLIT) { idtx = (e0 >> 12) & 1; e0 &= 0xFFF; }
       if (cx.lane < n8 * n8) {
         const int e1 = eo[1], e2 = eo[2];
         const int i = cx.lane / n8, j = cx.lane - i * n8;
@@ -1168,9 +1190,11 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         bi.ymode = (uint8_t)(mode & 15); bi.skip = (uint8_t)((e0 | e1 | e2) == 0); bi.bsl = (uint8_t)bsl; bi.is_inter = (uint8_t)ii.is_inter;
         bi.eob[0] = (uint16_t)e0; bi.eob[1] = (uint16_t)e1; bi.eob[2] = (uint16_t)e2;
         bi.mv_row = (int16_t)(ii.is_inter ? ii.mv_row : 0); bi.mv_col = (int16_t)(ii.is_inter ? ii.mv_col : 0);
-        // angle delta + 3 of the (luma and chroma) directional mode | chroma from luma << 3 | (alpha U + 16) << 4 | (alpha V + 16) << 10
+        // angle delta + 3 of the (luma and chroma) directional mode | luma identity transform << 3 | chroma from luma: alpha U, alpha V as
+        // 6-bit two's complement << 4, << 10 (both zero = no chroma from luma: that pair is not codable)
         cdec = uniform_i(cdec);
-        bi.angle = (uint16_t)(((mode >> 4) & 7) | (((cdec >> 16) & 1) << 3) | (((cdec >> 17) & 63) << 4) | (((cdec >> 23) & 63) << 10));
+        const int cflf = (cdec >> 16) & 1, au = cflf ? ((cdec >> 17) & 63) - 16 : 0, av = cflf ? ((cdec >> 23) & 63) - 16 : 0;
+        bi.angle = (uint16_t)(((mode >> 4) & 7) | (idtx << 3) | ((au & 63) << 4) | ((av & 63) << 10));
         if (unit_inside) info[((by >> 3) + i) * b8_stride + (bx >> 3) + j] = bi;
       }
     }
@@ -1371,7 +1395,7 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
   } while (0)
   // the optional intra tools (edge filter, chroma from luma) live in instantiations of their own (EXT)
 #define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \
-  do { if (P->edge_filter || P->cfl) RECON_LAUNCH2(PIXT, INTERV, TSBV, true); else RECON_LAUNCH2(PIXT, INTERV, TSBV, false); } while (0)
+  do { if (P->edge_filter || P->cfl || P->tx_search) RECON_LAUNCH2(PIXT, INTERV, TSBV, true); else RECON_LAUNCH2(PIXT, INTERV, TSBV, false); } while (0)
   if (P->bit_depth == 8) {
     if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(uint8_t, true, 1); else RECON_LAUNCH(uint8_t, false, 1); }
     else { if (inter) RECON_LAUNCH(uint8_t, true, 2); else RECON_LAUNCH(uint8_t, false, 2); }

@@ -83,6 +83,8 @@ typedef struct {
                                predictions read the filtered / upsampled edges of AV1 spec 7.11.2.7 - 7.11.2.12; 0 (default) */
   uint32_t cfl;             /* 1: chroma-from-luma prediction (UV_CFL_PRED, AV1 spec 7.11.5) is a candidate for the chroma planes of key-frame
                                blocks up to 32x32 (alpha per plane by least squares over the reconstructed luma); 0 (default) */
+  uint32_t tx_search;       /* 1: transform type search - intra luma blocks up to 16x16 whose residual is sparse (at most one sample in
+                               eight nonzero) are coded with the identity transform (IDTX); 0 (default): the mode's default type */
 } av1mi_params;
 
 typedef struct {

@@ -17,6 +17,7 @@ pub struct Av1miParams {            // include/av1mi.h: av1mi_params
     pub intra_angle_delta: u32,     // 1 = directional intra winners refined over the angle deltas -3..+3
     pub intra_edge_filter: u32,     // 1 = enable_intra_edge_filter (filtered / upsampled prediction edges)
     pub cfl: u32,                   // 1 = chroma-from-luma prediction is a candidate (key frames, blocks up to 32x32)
+    pub tx_search: u32,             // 1 = identity transform (IDTX) for sparse intra luma residuals
 }
 #[repr(C)]
 pub struct Av1miJob {               // include/av1mi.h: av1mi_job  <->  Av1anEncodeParams (av1an.rs:36-45)

@@ -78,6 +78,7 @@ typedef struct {
   int intra_edge_filter;  /* sequence header enable_intra_edge_filter: directional predictions use the filtered / upsampled
                            * edges of spec 7.11.2.9 - 7.11.2.12 (SVT-AV1 and libaom run with it on); 0 = the round-1 streams */
   int cfl;                /* 1: chroma-from-luma prediction (spec 7.11.5) is a candidate for the chroma planes of key-frame blocks up to 32x32 */
+  int tx_search;          /* 1: transform type search - intra luma blocks up to 16x16 with a sparse residual take the identity transform (IDTX) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */

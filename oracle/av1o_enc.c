@@ -748,20 +748,20 @@ static int tx_scale_shift(int log2n) { return log2n >= 6 ? 2 : (log2n == 5 ? 1 :
 int av1o_qm_level(int base_q_idx, int qm_min, int qm_max) { return qm_min + base_q_idx * (qm_max + 1 - qm_min) / 256; }
 
 /* §7.12.3: the dequantiser step at coefficient (i, j): q, or with a quantiser matrix Round2(q * Quantizer_Matrix[..], 5).
- * All transforms here are 2-D DCT/ADST (PlaneTxType < IDTX), so the matrix applies whenever the plane's level is < 15. */
-static uint32_t qstep_at(const Enc *e, int plane, int log2n, int i, int j) {
+ * The matrix applies to the 2-D DCT/ADST types (PlaneTxType < IDTX) whenever the plane's level is < 15. */
+static uint32_t qstep_at(const Enc *e, int plane, int log2n, int i, int j, int tx_type) {
   static const int off[4] = { AV1_QM_4X4, AV1_QM_8X8, AV1_QM_16X16, AV1_QM_32X32 };
   const uint32_t q = (uint32_t)((i | j) ? e->ac_q : e->dc_q);
   const int lvl = e->cfg->enable_qm ? (plane ? e->cfg->qm_uv : e->cfg->qm_y) : 15;
   const int l2 = log2n > 5 ? 5 : log2n;
-  if (lvl >= 15) return q;
+  if (lvl >= 15 || tx_type >= IDTX) return q;   /* §7.12.3: the matrix applies only when PlaneTxType < IDTX */
   return (q * av1_qm_iwt[lvl][plane > 0][off[l2 - 2] + (i << l2) + j] + 16) >> 5;
 }
 
 /* forward transform + dead-zone quantise -> levels; dequantise + inverse -> recon in place.
  * Returns eob.  DESIGN.md §3.5: level = ((|coef| << s) + rnd) * ceil(2^32/q) >> 32 with the
  * frequency-dependent dead zone rnd = 3q/8 (row+col < n/4), q/4 (< n/2), q/8 (else). */
-static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type, TxbCoefs *t) {
+static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type, TxbCoefs *t, int allow_idtx) {
   const int n = 1 << log2n, bd = e->cfg->bit_depth;
   const int cw = n > 32 ? 32 : n, bwl = log2n > 5 ? 5 : log2n;
   const int sh = tx_scale_shift(log2n);
@@ -776,6 +776,15 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
   memset(t->level, 0, sizeof(int32_t) * cw * cw);
   for (i = 0; i < n; i++)
     for (j = 0; j < n; j++) resid[i * n + j] = (int32_t)src[i * sstride + j] - (int32_t)rec[i * rstride + j];
+  /* transform type search (cfg->tx_search): an intra luma block of up to 16x16 whose residual is sparse - at
+   * most one sample in eight is nonzero - is coded with the identity transform (IDTX): flat areas with isolated edges, text */
+  if (allow_idtx) {
+    int nnz = 0;
+    for (c = 0; c < n * n; c++) nnz += resid[c] != 0;
+    if (e->cfg->fuzz_modes) { if (fuzz_rand(e) % 3 == 0) tx_type = IDTX; }
+    else if (nnz * 8 <= n * n) tx_type = IDTX;
+    t->tx_type = tx_type;
+  }
   if (e->cfg->fuzz_coeffs) {
     for (c = 0; c < cw * cw; c++) {
       if (fuzz_rand(e) % (unsigned)e->cfg->fuzz_density == 0) {
@@ -793,7 +802,7 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
     for (i = 0; i < cw; i++)
       for (j = 0; j < cw; j++) {
         int32_t v = coef[i * n + j];
-        uint32_t q = qstep_at(e, plane, log2n, i, j);
+        uint32_t q = qstep_at(e, plane, log2n, i, j, tx_type);
         uint32_t recip = (uint32_t)((((uint64_t)1 << 32) + q - 1) / q);
         uint32_t rnd = (i + j) < (cw >> 2) ? (3 * q) >> 3 : ((i + j) < (cw >> 1) ? (q >> 2) : (q >> 3));
         uint32_t a = ((uint32_t)abs(v) << sh) + rnd;
@@ -813,7 +822,7 @@ static int code_tx_block(Enc *e, int plane, int x, int y, int log2n, int tx_type
       for (j = 0; j < cw; j++) {
         int32_t lv = t->level[(i << bwl) + j];
         if (lv) {
-          uint32_t q = qstep_at(e, plane, log2n, i, j);
+          uint32_t q = qstep_at(e, plane, log2n, i, j, tx_type);
           int64_t d = ((int64_t)abs(lv) * q) & 0xFFFFFF;
           int64_t lim = (int64_t)1 << (7 + bd);
           d >>= sh;
@@ -1348,7 +1357,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
                                edge_a, edge_l, avail_u, avail_l, bd, &ef[0]);
   }
   tx_y = (log2n_y <= 4 && !is_inter) ? mode_to_txfm[md.ymode] : DCT_DCT;
-  code_tx_block(e, 0, mi_c * 4, mi_r * 4, log2n_y, tx_y, ty);
+  code_tx_block(e, 0, mi_c * 4, mi_r * 4, log2n_y, tx_y, ty, cfg->tx_search && !is_inter && log2n_y <= 4);
   /* ---- chroma from luma (cfg->cfl; blocks up to 32x32): decision-driven on key frames - CfL replaces the luma-derived chroma mode
    * when the sum of its two planes' prediction SADs (each plane at its chosen alpha) plus the chroma block width is smaller than
    * the regular mode's, and the alphas are not both zero (not codable); fuzzed streams take it at random on any frame */
@@ -1400,7 +1409,7 @@ static void encode_block(Enc *e, int mi_r, int mi_c, int bsl /* log2 block size 
           av1o_predict_intra_ef(dst, e->rec->stride[plane], log2n_uv, md.uvmode, md.uvangle, edge_a, edge_l, avail_u, avail_l, bd, &ef[1]);
         }
       }
-      code_tx_block(e, plane, x, y, log2n_uv, tx_uv, plane == 1 ? tu : tv);
+      code_tx_block(e, plane, x, y, log2n_uv, tx_uv, plane == 1 ? tu : tv, 0);
     }
     free(ac);
   }

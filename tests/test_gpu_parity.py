@@ -57,6 +57,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         p.intra_angle_delta = cfgk.get("angle_delta", 0)
         p.intra_edge_filter = cfgk.get("intra_edge_filter", 0)
         p.cfl = cfgk.get("cfl", 0)
+        p.tx_search = cfgk.get("tx_search", 0)
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         p.enable_lr = cfgk.get("enable_lr", 0)
         if cfgk.get("deblock", 0) == 2:
@@ -69,7 +70,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         for k in ("cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping"):
             if k in cfgk:
                 setattr(p, k, cfgk[k])
-        src = oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=m["t"])
+        src = [(pl >> m.get("src_shift", 0)) << m.get("src_shift", 0) for pl in oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=m["t"])]
         data, sizes, rep, recon = ctx.encode_chunk(p, raw_of(src, m["bit_depth"]), 1, want_recon=True)
         assert data == m["obu"], m["name"]
         assert sha(split_planes(recon.tobytes(), m["width"], m["height"], m["bit_depth"])) == m["recon_sha256"], m["name"]
@@ -786,15 +787,17 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
         ad = int(rng2.integers(0, 2))   # angle deltas
         ef = int(rng2.integers(0, 2))   # enable_intra_edge_filter
         cf = int(rng2.integers(0, 2))   # chroma from luma
+        ts = int(rng2.integers(0, 2))   # transform type search (IDTX)
+        post = int(rng2.choice([0, 0, 5]))   # posterised source: sparse residuals
         big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=3000 + it, t=t) for t in range(n)]
-        frames = [[f[0][:h, :w].copy(), f[1][:h // 2, :w // 2].copy(), f[2][:h // 2, :w // 2].copy()] for f in big]
+        frames = [[(f[0][:h, :w] >> post) << post, (f[1][:h // 2, :w // 2] >> post) << post, (f[2][:h // 2, :w // 2] >> post) << post] for f in big]
         p = av1mi.default_params(w, h, bd, block_log2=bs, cq_level=cq, intra_mode_mask=mask, cdf_update=cdf, keyint=keyint, me_range=me,
                                  enable_lr=lr, film_grain=fg, first_frame=5, tile_sb=tsb, deblock=db, subpel=sp, enable_qm=qm, qm_min=qmin, qm_max=qmax,
-                                 intra_angle_delta=ad, intra_edge_filter=ef, cfl=cf)
+                                 intra_angle_delta=ad, intra_edge_filter=ef, cfl=cf, tx_search=ts)
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
         qml = oracle.qm_level(av1mi.cq_to_qindex(cq), qmin, qmax)
         cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, base_q_idx=av1mi.cq_to_qindex(cq), mode_mask=mask, deblock=db,
-                                    subpel=sp, enable_qm=qm, qm_y=qml, qm_uv=qml, angle_delta=ad, intra_edge_filter=ef, cfl=cf,
+                                    subpel=sp, enable_qm=qm, qm_y=qml, qm_uv=qml, angle_delta=ad, intra_edge_filter=ef, cfl=cf, tx_search=ts,
                                     disable_cdf_update=0 if cdf else 1, me_range=me, enable_lr=lr, tile_w_sb=tsb, tile_h_sb=tsb,
                                     film_grain=1 if fg else 0, fg_y_scaling=2 * fg, fg_c_scaling=fg)
         tus, recs, ref, prev = [], [], None, None
@@ -805,7 +808,7 @@ def test_random_configurations_equal_oracle(av1mi, ctx, oracle):
             tus.append(tu)
             recs.append(rec)
             ref, prev = rec, f
-        desc = dict(it=it, ad=ad, ef=ef, cf=cf, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db, sp=sp, qm=qm, qmin=qmin, qmax=qmax)
+        desc = dict(it=it, ad=ad, ef=ef, cf=cf, ts=ts, post=post, w=w, h=h, bd=bd, bs=bs, cq=cq, mask=hex(mask), cdf=cdf, keyint=keyint, me=me, lr=lr, fg=fg, tsb=tsb, n=n, db=db, sp=sp, qm=qm, qmin=qmin, qmax=qmax)
         assert list(sizes) == [len(t) for t in tus], desc
         assert data == b"".join(tus), desc
         fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
@@ -856,6 +859,27 @@ def test_chroma_from_luma_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, key
         p.cfl = 0
         data0, _, _, _ = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n)
         assert data0 != data   # chroma from luma was chosen somewhere
+
+
+@pytest.mark.parametrize("w,h,bd,n,bs,keyint,mask,qm,shift", [(200, 120, 8, 1, 4, 1, 0x7, 0, 5), (202, 122, 10, 2, 3, 1, 0x1FFF, 1, 7), (264, 200, 8, 3, 4, 2, 0x1FFF, 0, 5),
+                                                             (648, 360, 8, 2, 3, 240, 0x7, 1, 5)])
+def test_identity_transform_search_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, keyint, mask, qm, shift):
+    """tx_search: intra luma blocks up to 16x16 with a sparse residual (posterised source: flat areas, sharp edges) are coded with
+    IDTX - identity 1-D transforms both ways, intra_tx_type symbol 0, no quantiser matrix on those blocks (spec 7.12.3) - on key
+    frames and for the intra blocks of inter frames (two-wave tile walk).  The oracle's side is pinned by dav1d (tests/golden/*idtx*)."""
+    big = [oracle.synthclip_frame(((w + 7) & ~7) + 8, ((h + 7) & ~7) + 8, bd, seed=4500 + w + bs, t=t) for t in range(n)]
+    frames = [[(f[0][:h, :w] >> shift) << shift, (f[1][:h // 2, :w // 2] >> shift) << shift, (f[2][:h // 2, :w // 2] >> shift) << shift] for f in big]
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=keyint, intra_mode_mask=mask, tx_search=1, enable_qm=qm, qm_min=5, qm_max=5)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, mode_mask=mask, tx_search=1, enable_qm=qm, qm_y=5, qm_uv=5)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert data == b"".join(tus)
+    fb = w * h * 3 // 2 * (2 if bd > 8 else 1)
+    for i, rec in enumerate(recs):
+        assert recon.tobytes()[i * fb:(i + 1) * fb] == raw_of(rec, bd), "reconstruction of frame %d" % i
+    p.tx_search = 0
+    data0, _, _, _ = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n)
+    assert data0 != data   # IDTX was chosen somewhere
 
 
 @pytest.mark.parametrize("w,h,bd,n,bs,keyint,lr,tsb", [(70, 58, 8, 1, 5, 1, 0, 1), (202, 122, 10, 3, 5, 240, 0, 1), (130, 66, 8, 3, 4, 2, 1, 1),

@@ -111,6 +111,14 @@ CASES = [
     ("fuzz_cfl_bs5", 264, 200, 8, 100, 0, dict(min_bs_log2=5, max_bs_log2=5, mode_mask=0x1FFF, fuzz_modes=7, cfl=1)),
     ("fuzz_cfl_tiles2x1_10b", 328, 248, 10, 101, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=17, tile_w_sb=2, tile_h_sb=1, cfl=1)),
     ("fuzz_cfl_levels_10b", 136, 136, 10, 102, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=14, fuzz_coeffs=19, fuzz_density=6, fuzz_maxlevel=30, cfl=1)),
+    # identity transform (IDTX) for intra luma blocks with sparse residuals (tx_search): decision-driven on posterised sources, fuzzed
+    # on regular ones (with quantiser matrices: they do not apply to IDTX blocks, spec 7.12.3)
+    ("k200x120_idtx_bs4_post", 200, 120, 8, 1080, 10, dict(min_bs_log2=4, max_bs_log2=4, tx_search=1, src_shift=5)),
+    ("k200x120_idtx_bs3_post_10b", 200, 120, 10, 1080, 11, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, tx_search=1, src_shift=7)),
+    ("k248x184_idtx_cfl_bs4_post", 248, 184, 8, 105, 0, dict(min_bs_log2=4, max_bs_log2=4, tx_search=1, cfl=1, intra_edge_filter=1, mode_mask=0x1FFF, src_shift=5)),
+    ("fuzz_idtx_bs3", 200, 120, 8, 106, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=3, tx_search=1)),
+    ("fuzz_idtx_bs4_qm_10b", 264, 200, 10, 107, 0, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, fuzz_modes=5, tx_search=1, enable_qm=1, qm_y=4, qm_uv=6)),
+    ("fuzz_idtx_levels", 136, 136, 8, 108, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=15, fuzz_coeffs=21, fuzz_density=4, fuzz_maxlevel=20, tx_search=1)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -202,7 +210,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     index = []
     for name, w, h, bd, seed, t, kw in CASES:
-        src = av1o.synthclip_frame(w, h, bd, seed=seed, t=t)
+        kw = dict(kw)
+        src_shift = kw.pop("src_shift", 0)   # posterised source (low bits cleared): flat areas with sharp edges, sparse residuals
+        src = [(p >> src_shift) << src_shift for p in av1o.synthclip_frame(w, h, bd, seed=seed, t=t)]
         cfg = av1o.default_config(w, h, bd, **kw)
         tu, rec, st = av1o.encode_frame(cfg, src)
         dec = oracle_avif.decode_obus(tu, w, h, bd)
@@ -215,7 +225,7 @@ def main():
             elif d.max() != 0:
                 raise SystemExit("%s: dav1d output differs from the oracle reconstruction in plane %d" % (name, p))
         open(os.path.join(OUT, name + ".obu"), "wb").write(tu)
-        meta = dict(name=name, width=w, height=h, bit_depth=bd, seed=seed, t=t, config=kw, bytes=len(tu),
+        meta = dict(name=name, width=w, height=h, bit_depth=bd, seed=seed, t=t, config=kw, src_shift=src_shift, bytes=len(tu),
                     dav1d_sha256=sha(dec), recon_sha256=sha(rec), dav1d_applies_grain=grain, src_sha256=sha(src), n_symbols=int(st.n_symbols),
                     psnr=[round(x, 3) for x in av1o.psnr(st, cfg)], decoder="dav1d 1.5.3 via libavif 1.4.1 (Pillow 12.2.0)")
         json.dump(meta, open(os.path.join(OUT, name + ".json"), "w"), indent=1, sort_keys=True)
