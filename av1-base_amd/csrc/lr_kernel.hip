@@ -57,11 +57,14 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 // differ only in the final blend.
 __constant__ int8_t c_sgr_cand[3][3] = { { 9, 31, 31 }, { 9, 0, 31 }, { 9, 31, 95 } };
 // A (<= 256) and B of the box filter at the positions a slice of SGR_ROWS rows of a unit section needs: rows ya - 1 .. yb
-// (<= SGR_ROWS + 2), columns xs - 1 .. xs + 64.  Slices keep the LDS footprint at 24 KB (6 waves per CU; whole 64-row sections
+// (<= SGR_ROWS + 2), columns xs - 1 .. xs + 64.  Slices keep the LDS footprint small (whole 64-row sections
 // needed 62 KB: 2 waves per CU, half the SIMDs idle, 3x slower).
 #define SGR_ROWS 16   /* == the rows of a wave's slice */
-__shared__ uint16_t g_sgrA[2][SGR_ROWS + 2][66];
-__shared__ int32_t g_sgrB[2][SGR_ROWS + 2][66];
+// Pass 0 (r = 2) is only evaluated at odd rows: its grids hold every second row (row index >> 1; a slice starts at an even row, so
+// the odd rows ya - 1, ya + 1 .. have even indices).  That is 3.5 KB less: 17 KB per wave, 9 waves per CU instead of 7, and the
+// 2040 working waves of a 1080p frame are resident at once (the same step the inter pass took).
+__shared__ uint16_t g_sgrA0[(SGR_ROWS + 2) / 2][66], g_sgrA1[SGR_ROWS + 2][66];
+__shared__ int32_t g_sgrB0[(SGR_ROWS + 2) / 2][66], g_sgrB1[SGR_ROWS + 2][66];
 
 // get_source_sample (§7.17.6): the row of the frame that supplies restoration input row y of the stripe [s0, s1]
 template <typename PIX>
@@ -125,8 +128,8 @@ __device__ __forceinline__ void sgr_grid(int bd, int ya, int yb, int lane) {
       for (int t = 0; t < WN; t++) { b += h1[t]; a += h2[t]; }
       uint32_t A; int32_t B;
       sgr_ab<R>(a, b, bd, A, B);
-      g_sgrA[PASS][yc - (ya - 1)][lane + 1] = (uint16_t)A;
-      g_sgrB[PASS][yc - (ya - 1)][lane + 1] = B;
+      if (PASS == 0) { g_sgrA0[(yc - (ya - 1)) >> 1][lane + 1] = (uint16_t)A; g_sgrB0[(yc - (ya - 1)) >> 1][lane + 1] = B; }
+      else { g_sgrA1[yc - (ya - 1)][lane + 1] = (uint16_t)A; g_sgrB1[yc - (ya - 1)][lane + 1] = B; }
     }
   }
   const int rows = yb - ya + 2;
@@ -142,8 +145,8 @@ __device__ __forceinline__ void sgr_grid(int bd, int ya, int yb, int lane) {
     }
     uint32_t A; int32_t B;
     sgr_ab<R>(a, b, bd, A, B);
-    g_sgrA[PASS][ri][side ? 65 : 0] = (uint16_t)A;
-    g_sgrB[PASS][ri][side ? 65 : 0] = B;
+    if (PASS == 0) { g_sgrA0[ri >> 1][side ? 65 : 0] = (uint16_t)A; g_sgrB0[ri >> 1][side ? 65 : 0] = B; }
+    else { g_sgrA1[ri][side ? 65 : 0] = (uint16_t)A; g_sgrB1[ri][side ? 65 : 0] = B; }
   }
 }
 
@@ -157,21 +160,23 @@ __device__ __forceinline__ void sgr_flt(int lane, int y, int ya, int cur, int &f
 #pragma unroll
       for (int dx = -1; dx <= 1; dx++) {
         const int w = (dx == 0 || dy == 0) ? 4 : 3;
-        a += w * (int)g_sgrA[1][ri + dy][c + dx]; b += w * g_sgrB[1][ri + dy][c + dx];
+        a += w * (int)g_sgrA1[ri + dy][c + dx]; b += w * g_sgrB1[ri + dy][c + dx];
       }
     flt1 = (a * cur + b + (1 << 8)) >> 9;
   }
   {
     int a = 0, b = 0;
     if (y & 1) {  // odd row: the row itself, weights 5 6 5, shift 4
-      a = 5 * (int)g_sgrA[0][ri][c - 1] + 6 * (int)g_sgrA[0][ri][c] + 5 * (int)g_sgrA[0][ri][c + 1];
-      b = 5 * g_sgrB[0][ri][c - 1] + 6 * g_sgrB[0][ri][c] + 5 * g_sgrB[0][ri][c + 1];
+      const int r0 = ri >> 1;
+      a = 5 * (int)g_sgrA0[r0][c - 1] + 6 * (int)g_sgrA0[r0][c] + 5 * (int)g_sgrA0[r0][c + 1];
+      b = 5 * g_sgrB0[r0][c - 1] + 6 * g_sgrB0[r0][c] + 5 * g_sgrB0[r0][c + 1];
       flt0 = (a * cur + b + (1 << 7)) >> 8;
     } else {      // even row: the rows above and below, shift 5
 #pragma unroll
       for (int dy = -1; dy <= 1; dy += 2) {
-        a += 5 * (int)g_sgrA[0][ri + dy][c - 1] + 6 * (int)g_sgrA[0][ri + dy][c] + 5 * (int)g_sgrA[0][ri + dy][c + 1];
-        b += 5 * g_sgrB[0][ri + dy][c - 1] + 6 * g_sgrB[0][ri + dy][c] + 5 * g_sgrB[0][ri + dy][c + 1];
+        const int r0 = (ri + dy) >> 1;
+        a += 5 * (int)g_sgrA0[r0][c - 1] + 6 * (int)g_sgrA0[r0][c] + 5 * (int)g_sgrA0[r0][c + 1];
+        b += 5 * g_sgrB0[r0][c - 1] + 6 * g_sgrB0[r0][c] + 5 * g_sgrB0[r0][c + 1];
       }
       flt0 = (a * cur + b + (1 << 8)) >> 9;
     }
