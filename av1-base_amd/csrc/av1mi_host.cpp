@@ -404,6 +404,7 @@ std::vector<uint16_t> make_cdf_blob(int qidx) {
 struct av1mi_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  bool pooled_streams = false;    // the streams go back to the process-wide pool (av1mi_ctx_create)
   hipStream_t stream2 = nullptr;  // CDEF + SSE run here, beside the entropy kernels on `stream`
   hipStream_t stream3 = nullptr;  // inter chunks: entropy coding of finished groups of frames, beside the frame-by-frame chain
   hipStream_t stream4 = nullptr;  // all-key-frame chunks pipelined over groups: the groups' entropy coding alternates between stream3 and this one
@@ -644,6 +645,25 @@ int av1mi_write_headers(const av1mi_params *p, uint8_t *seq_hdr, size_t *seq_len
   return AV1MI_OK;
 }
 
+// The four streams of a context come from a process-wide pool and go back to it when the context is destroyed.  The runtime maps
+// streams onto a few hardware queues in creation order, and after contexts had been created and destroyed a number of times a new
+// context's chain stream could share a queue with its own search stream, whose launches for the whole chunk are queued up front: a
+// single 1080p IPPP chunk then took 20.3 ms instead of 13.7 (bench.py's configs run one after the other in one process; a daemon that
+// lives for days is the same case).  Reused streams keep the mapping of the first contexts.
+namespace {
+struct StreamSet { hipStream_t s[4]; };
+std::mutex g_stream_mu;
+std::vector<std::pair<int, StreamSet>> g_stream_pool;   // (device, set)
+}  // namespace
+extern "C" void av1mi_host_release_streams(void) {
+  std::vector<std::pair<int, StreamSet>> all;
+  { std::lock_guard<std::mutex> lk(g_stream_mu); all.swap(g_stream_pool); }
+  for (auto &e : all) {
+    (void)hipSetDevice(e.first);
+    for (auto st : e.second.s) if (st) (void)hipStreamDestroy(st);
+  }
+}
+
 int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   if (!out) return AV1MI_E_INVALID_ARG;
   *out = nullptr;
@@ -667,6 +687,20 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
     aux_ok = hipSetDevice(device_id) == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream2, 8, mask) == hipSuccess &&
              hipExtStreamCreateWithCUMask(&c->stream3, 8, mask) == hipSuccess;
   }
+  if (aux_ok && !c->stream2) {   // a pooled set, if there is one for this device
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); i++)
+      if (g_stream_pool[i].first == device_id) {
+        const StreamSet ss = g_stream_pool[i].second;
+        g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+        c->stream = ss.s[0]; c->stream2 = ss.s[1]; c->stream3 = ss.s[2]; c->stream4 = ss.s[3];
+        c->pooled_streams = true;
+        break;
+      }
+  }
+  if (c->pooled_streams) {
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; return AV1MI_E_NO_DEVICE; }
+  } else
   if (!aux_ok || hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       (!c->stream2 && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess) ||
       (!c->stream3 && hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo) != hipSuccess) ||
@@ -676,6 +710,7 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
     delete c;
     return AV1MI_E_NO_DEVICE;
   }
+  if (!getenv("AV1MI_AUX_CU_MASK")) c->pooled_streams = true;   // (the masked streams of the experiment knob are not pooled)
   for (auto &e : c->ev) (void)hipEventCreate(&e);
   *out = c;
   return AV1MI_OK;
@@ -689,10 +724,16 @@ void av1mi_ctx_destroy(av1mi_ctx *c) {
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->me_ev) (void)hipEventDestroy(e);
   for (auto &e : c->grp_ev) (void)hipEventDestroy(e);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->stream3) (void)hipStreamDestroy(c->stream3);
-  if (c->stream4) (void)hipStreamDestroy(c->stream4);
+  if (c->pooled_streams && c->stream && c->stream2 && c->stream3 && c->stream4) {
+    (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream3); (void)hipStreamSynchronize(c->stream4);
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_pool.push_back({ c->device, StreamSet{ { c->stream, c->stream2, c->stream3, c->stream4 } } });
+  } else {
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
+  }
   delete c;
 }
 
