@@ -677,6 +677,11 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   // taking its slots
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device_id) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (const char *fp = getenv("AV1MI_STREAM_PRIORITIES")) {   // experiment knob: "flat" = every stream at the default priority, "hi" = all high
+    if (!strcmp(fp, "flat")) prio_lo = prio_hi = 0;
+    else if (!strcmp(fp, "hi")) prio_lo = prio_hi;
+    else if (!strcmp(fp, "mid")) prio_lo = 0;   // chain high, the rest normal
+  }
   // experiment knob: AV1MI_AUX_CU_MASK=<hex word> restricts the two auxiliary streams (bulk work beside the chain) to the CUs whose bit
   // is set in the word, repeated over the chip's 256 CUs (0x55555555: every other CU)
   bool aux_ok = true;
