@@ -159,15 +159,6 @@ __device__ __forceinline__ void stamp_phase(int cls, int phase) {
 #else
 #define STAMP(phase) do { } while (0)
 #endif
-// motion compensation at sub-sample positions (inter instantiations only): reference window and horizontal-pass output
-struct McLds {
-  uint16_t win[(MAXN + 7) * (MAXN + 7) + 7];
-  int16_t mid[(MAXN + 7) * MAXN];
-};
-__shared__ McLds g_mc;
-__shared__ McLds g_mc_c;   // chroma wave of a split tile walk
-template <int WV> struct McSel { static __device__ __forceinline__ McLds &get() { return g_mc; } };
-template <> struct McSel<2> { static __device__ __forceinline__ McLds &get() { return g_mc_c; } };
 __constant__ int16_t c_subpel[2][16][8] = AV1_SUBPEL_FILTERS_INIT;  // EIGHTTAP, and its 4-tap form for 4-sample blocks
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -368,47 +359,55 @@ __device__ __forceinline__ int mc_sample(const PIX *plane, int stride, int last_
 // reference, not compound): the (N + 7)^2 reference window (coordinates clamped to the signalled frame) is staged in
 // LDS once, horizontal pass -> Round2 by 3 -> 16-bit intermediate, vertical pass -> Round2 by 11 -> clamp.  Writes the
 // prediction of lane group `grp` into dst[0 .. N*N).  px0 / py0: position of the block's first sample in 1/16 samples.
-template <typename PIX, int LOG2N, int NPL, int WV>
+template <typename PIX, int LOG2N, int NPL>
 __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int last_x, int last_y, int px0, int py0, int maxv,
-                                              int grp, int sl, uint16_t *dst) {
-  constexpr int N = 1 << LOG2N, WN = N + 7, G = 64 / NPL;
-  uint16_t *win = McSel<WV>::get().win + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 39 + 3 : 23 * 23 + 3));
-  int16_t *mid = McSel<WV>::get().mid + grp * (NPL == 1 ? 0 : (N > 16 ? 39 * 32 : 23 * 16));
+                                              int grp, int sl, uint16_t *buf, uint16_t *dst) {
+  // In strips of 16 rows: the window of a strip ((16 + 7) x (N + 7) samples) and its horizontal-pass output fit the block's source
+  // and staging tiles, which are free while the block is predicted BEFORE its source is loaded - the kernel needs no LDS of its own
+  // for the window (5.6 KB: 12 instead of 16 waves per CU in the inter pass).
+  constexpr int N = 1 << LOG2N, WN = N + 7, G = 64 / NPL, RS = N < 16 ? N : 16, WR = RS + 7;
+  constexpr int WSZ = (WR * WN + 3) & ~3, MSZ = WR * N;
+  static_assert(NPL * (WSZ + MSZ) <= MAXN * MAXN + MAXN * (MAXN + 1), "the strip's window and intermediate must fit srcblk + scratch");
+  uint16_t *win = buf + grp * (WSZ + MSZ);
+  int16_t *mid = reinterpret_cast<int16_t *>(win + WSZ);
   const int ix0 = (px0 >> 4) - 3, iy0 = (py0 >> 4) - 3;
   const int16_t *fh = c_subpel[N <= 4][px0 & 15], *fv = c_subpel[N <= 4][py0 & 15];
-  {  // all loads of the window in flight together (a loop of dependent load -> LDS store pairs paid the latency 24 times)
-    constexpr int K = (WN * WN + G - 1) / G;
-    PIX v[K];
+#pragma nounroll
+  for (int s0 = 0; s0 < N; s0 += RS) {
+    {  // all loads of the window in flight together (a loop of dependent load -> LDS store pairs paid the latency every time)
+      constexpr int K = (WR * WN + G - 1) / G;
+      PIX v[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int p = sl + k * G, i = p / WN, j = p - i * WN;
-      int yy = iy0 + i, xx = ix0 + j;
-      yy = yy < 0 ? 0 : (yy > last_y ? last_y : yy);
-      xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
-      v[k] = rp[(size_t)yy * stride + xx];
+      for (int k = 0; k < K; k++) {
+        const int p = sl + k * G, i = p / WN, j = p - i * WN;
+        int yy = iy0 + s0 + i, xx = ix0 + j;
+        yy = yy < 0 ? 0 : (yy > last_y ? last_y : yy);
+        xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
+        v[k] = rp[(size_t)yy * stride + xx];
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++) { const int p = sl + k * G; if (p < WR * WN) win[p] = (uint16_t)v[k]; }
     }
+    wave_sync();
+    for (int p = sl; p < WR * N; p += G) {
+      const int r = p >> LOG2N, c = p & (N - 1);
+      const uint16_t *wp = win + r * WN + c;
+      int sum = 0;
 #pragma unroll
-    for (int k = 0; k < K; k++) { const int p = sl + k * G; if (p < WN * WN) win[p] = (uint16_t)v[k]; }
-  }
-  wave_sync();
-  for (int p = sl; p < WN * N; p += G) {
-    const int r = p >> LOG2N, c = p & (N - 1);
-    const uint16_t *wp = win + r * WN + c;
-    int sum = 0;
+      for (int t = 0; t < 8; t++) sum += fh[t] * (int)wp[t];
+      mid[p] = (int16_t)((sum + 4) >> 3);
+    }
+    wave_sync();
+    for (int p = sl; p < RS * N; p += G) {
+      const int r = p >> LOG2N, c = p & (N - 1);
+      int sum = 0;
 #pragma unroll
-    for (int t = 0; t < 8; t++) sum += fh[t] * (int)wp[t];
-    mid[p] = (int16_t)((sum + 4) >> 3);
+      for (int t = 0; t < 8; t++) sum += fv[t] * (int)mid[(r + t) * N + c];
+      const int v = (sum + 1024) >> 11;
+      dst[s0 * N + p] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+    }
+    wave_sync();
   }
-  wave_sync();
-  for (int p = sl; p < N * N; p += G) {
-    const int r = p >> LOG2N, c = p & (N - 1);
-    int sum = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) sum += fv[t] * (int)mid[(r + t) * N + c];
-    const int v = (sum + 1024) >> 11;
-    dst[p] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
-  }
-  wave_sync();
 }
 
 // One transform block per lane GROUP.  NPL = 1: the whole wave works on one block of `plane0` (luma,
@@ -504,6 +503,20 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     if (plane0 > 0 && ii.is_inter) { inter_done(); return (ii.is_inter << 8) | (mode_io & 0x7F); }
   }
   STAMP(-1);
+  // ---- sub-sample motion compensation (PH == 1 items of the sub-sample kernels: EXT says so there) - first of all, while the source
+  // and staging tiles are still free for its window
+  bool mc_in_lds = false;  // the motion-compensated prediction already sits in blkpix (sub-sample position, EIGHTTAP)
+  if constexpr (INTER && PH == 1 && EXT) {
+    if (P->subpel) {
+      const int ss = plane0 > 0;
+      const int px0 = (gx << 4) + ((2 * ii.mv_col) >> ss), py0 = (gy << 4) + ((2 * ii.mv_row) >> ss);
+      if ((px0 | py0) & 15) {
+        mc_block_8tap<PIX, LOG2N, NPL>(static_cast<const PIX *>(ii.ref) + poff, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
+                                       px0, py0, (1 << bd) - 1, grp, sl, S->srcblk, S->blkpix + po);
+        mc_in_lds = true;
+      }
+    }
+  }
   // ---- source block -> LDS (coalesced rows)
   {
     const PIX *pl = frame + poff;
@@ -736,21 +749,6 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
     const int mode = final_trip ? best_mode : m;
     if (!final_trip && !((P->mode_mask >> m) & 1)) continue;
-    bool mc_in_lds = false;  // the motion-compensated prediction already sits in blkpix (sub-sample position, EIGHTTAP)
-    // (sub-sample motion compensation is compiled into the PH == 1 items of the sub-sample kernels only - there EXT says so: its
-    // LDS window, 5.6 KB, took the whole-sample inter pass from 16 to 12 waves per CU, and the walk (PH == 2) never predicts an
-    // inter block)
-    if constexpr (INTER && PH == 1 && EXT) {
-      if (final_trip && ii.is_inter && P->subpel) {
-        const int ss = plane0 > 0;
-        const int px0 = (gx << 4) + ((2 * ii.mv_col) >> ss), py0 = (gy << 4) + ((2 * ii.mv_row) >> ss);
-        if ((px0 | py0) & 15) {
-          mc_block_8tap<PIX, LOG2N, NPL, WV>(static_cast<const PIX *>(ii.ref) + poff, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
-                                         px0, py0, (1 << bd) - 1, grp, sl, S->blkpix + po);
-          mc_in_lds = true;
-        }
-      }
-    }
     int ang, dx, dy;
     dir_params(mode, final_trip ? best_delta : 0, ang, dx, dy);
     const uint16_t *EA = nullptr, *EL = nullptr;
