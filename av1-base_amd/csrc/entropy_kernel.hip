@@ -883,18 +883,25 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
             const int slot = nar ? (int)((ent >> 2) & 0x1FF) : MAX_COMBOS * SLOTS_PER_COMBO, s = ent & 3;
             const uint64_t rw = g_rc.row[slot][lane];
             const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
-            const uint32_t c0 = c01 & 0xFFFF, c1 = c01 >> 16, c2 = c2n & 0xFFFF;
-            // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3)
-            const uint32_t fh = s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : 0u));
-            const uint32_t fl = s == 0 ? 32768u : (s == 1 ? c0 : (s == 2 ? c1 : c2));
+            // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): one 64-bit shift each of {32768, c0, c1, c2} / {c0, c1, c2, 0}
+            const uint64_t vals = ((uint64_t)(c2n & 0xFFFFu) << 32) | c01;
+            const uint32_t fh = (uint32_t)(vals >> (16 * s)) & 0xFFFFu;
+            const uint32_t fl = (uint32_t)(((vals << 16) | 0x8000u) >> (16 * s)) & 0xFFFFu;
             ent = nar ? ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s) : ent;
             if (adapt) {
+              // the three values move towards 32768 (index < s) or 0 by their distance >> rate: packed 16-bit arithmetic on {c0, c1}
+              // and on {c2, counter} (the counter half is replaced afterwards)
+              typedef unsigned short us2 __attribute__((ext_vector_type(2)));
               const uint32_t cn = c2n >> 16;
-              const int rate = 5 + (cn > 15) + (cn > 31);
-              const uint32_t n0 = 0 < s ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
-              const uint32_t n1 = 1 < s ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
-              const uint32_t n2 = 2 < s ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
-              g_rc.row[slot][lane] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | ((cn + (cn < 32)) << 16)) << 32);
+              const unsigned short rate = (unsigned short)(5 + (cn > 15) + (cn > 31));
+              const us2 rv = { rate, rate }, top = { 0x8000, 0x8000 };
+              const us2 a = __builtin_bit_cast(us2, c01), b = __builtin_bit_cast(us2, c2n);
+              const uint32_t up01 = __builtin_bit_cast(uint32_t, (us2)(a + ((top - a) >> rv))), dn01 = __builtin_bit_cast(uint32_t, (us2)(a - (a >> rv)));
+              const uint32_t up2 = __builtin_bit_cast(uint32_t, (us2)(b + ((top - b) >> rv))), dn2 = __builtin_bit_cast(uint32_t, (us2)(b - (b >> rv)));
+              const uint32_t m01 = s >= 2 ? 0xFFFFFFFFu : (s ? 0xFFFFu : 0u);   // halves with index < s
+              const uint32_t n01 = (up01 & m01) | (dn01 & ~m01);
+              const uint32_t n2 = ((s > 2 ? up2 : dn2) & 0xFFFFu) | ((cn + (cn < 32)) << 16);
+              g_rc.row[slot][lane] = (uint64_t)n01 | ((uint64_t)n2 << 32);
             }
             g_rc.ring[k & 1][j + jj][lane] = ent;
           }
