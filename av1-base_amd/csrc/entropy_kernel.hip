@@ -868,51 +868,63 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
             qn[j / 4] = i1 < count ? *reinterpret_cast<const uint4 *>(st + i1) : make_uint4(0, 0, 0, 0);
           }
         }
+        // The 16 entries of the batch, one after the other.  An entry that is already resolved (or lies beyond this tile's count) runs
+        // the same instructions against a dummy row and keeps its value: no divergent branch.  The row of entry i + 1 is read BEFORE
+        // entry i's row is written back, and replaced by that new row if both entries name the same slot - otherwise every entry
+        // waited for an LDS round trip behind the previous entry's write (read -> adapt -> write -> read ...).
+        uint32_t ev[RC_BATCH];
 #pragma unroll
-        for (int j = 0; j < RC_BATCH; j += 4) {
-          const int i0 = k * RC_BATCH + j;
-          // 4 entries per 16-byte load; stream_cap is a multiple of 4 so the group is in bounds
-          const uint4 q = qc[j / 4];
+        for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = qc[j / 4].x; ev[j + 1] = qc[j / 4].y; ev[j + 2] = qc[j / 4].z; ev[j + 3] = qc[j / 4].w; }
+        const int i0 = k * RC_BATCH;
+        auto slot_of = [&](int idx, uint32_t e) { return (i0 + idx < count && !(e & 0x80000000u)) ? (int)((e >> 2) & 0x1FF) : MAX_COMBOS * SLOTS_PER_COMBO; };
+        int slot = slot_of(0, ev[0]);
+        uint64_t rw = g_rc.row[slot][lane];
 #pragma unroll
-          for (int jj = 0; jj < 4; jj++) {
-            uint32_t ent = jj == 0 ? q.x : (jj == 1 ? q.y : (jj == 2 ? q.z : q.w));
-            // No branch: an entry that is already resolved (or lies beyond this tile's count) runs the same instructions against the
-            // dummy row and keeps its value - with 64 tiles per wave both kinds are present in almost every step anyway, and the
-            // exec-mask bookkeeping of a divergent `if` was a sixth of the resolver's instructions.
-            const bool nar = i0 + jj < count && !(ent & 0x80000000u);
-            const int slot = nar ? (int)((ent >> 2) & 0x1FF) : MAX_COMBOS * SLOTS_PER_COMBO, s = ent & 3;
-            const uint64_t rw = g_rc.row[slot][lane];
-            const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
-            // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): one 64-bit shift each of {32768, c0, c1, c2} / {c0, c1, c2, 0}
-            const uint64_t vals = ((uint64_t)(c2n & 0xFFFFu) << 32) | c01;
-            const uint32_t fh = (uint32_t)(vals >> (16 * s)) & 0xFFFFu;
-            const uint32_t fl = (uint32_t)(((vals << 16) | 0x8000u) >> (16 * s)) & 0xFFFFu;
-            ent = nar ? ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s) : ent;
-            if (adapt) {
-              // the three values move towards 32768 (index < s) or 0 by their distance >> rate: packed 16-bit arithmetic on {c0, c1}
-              // and on {c2, counter} (the counter half is replaced afterwards)
-              typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-              const uint32_t cn = c2n >> 16;
-              const unsigned short rate = (unsigned short)(5 + (cn > 15) + (cn > 31));
-              const us2 rv = { rate, rate }, top = { 0x8000, 0x8000 };
-              const us2 a = __builtin_bit_cast(us2, c01), b = __builtin_bit_cast(us2, c2n);
-              const uint32_t up01 = __builtin_bit_cast(uint32_t, (us2)(a + ((top - a) >> rv))), dn01 = __builtin_bit_cast(uint32_t, (us2)(a - (a >> rv)));
-              const uint32_t up2 = __builtin_bit_cast(uint32_t, (us2)(b + ((top - b) >> rv))), dn2 = __builtin_bit_cast(uint32_t, (us2)(b - (b >> rv)));
-              const uint32_t m01 = s >= 2 ? 0xFFFFFFFFu : (s ? 0xFFFFu : 0u);   // halves with index < s
-              const uint32_t n01 = (up01 & m01) | (dn01 & ~m01);
-              const uint32_t n2 = ((s > 2 ? up2 : dn2) & 0xFFFFu) | ((cn + (cn < 32)) << 16);
-              g_rc.row[slot][lane] = (uint64_t)n01 | ((uint64_t)n2 << 32);
-            }
-            g_rc.ring[k & 1][j + jj][lane] = ent;
+        for (int jj = 0; jj < RC_BATCH; jj++) {
+          uint32_t ent = ev[jj];
+          const bool nar = i0 + jj < count && !(ent & 0x80000000u);
+          const int s = ent & 3;
+          int slot_nx = 0;
+          uint64_t rw_nx = 0;
+          if (jj + 1 < RC_BATCH) { slot_nx = slot_of(jj + 1, ev[jj + 1]); rw_nx = g_rc.row[slot_nx][lane]; }
+          const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
+          // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): one 64-bit shift each of {32768, c0, c1, c2} / {c0, c1, c2, 0}
+          const uint64_t vals = ((uint64_t)(c2n & 0xFFFFu) << 32) | c01;
+          const uint32_t fh = (uint32_t)(vals >> (16 * s)) & 0xFFFFu;
+          const uint32_t fl = (uint32_t)(((vals << 16) | 0x8000u) >> (16 * s)) & 0xFFFFu;
+          ent = nar ? ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s) : ent;
+          uint64_t nrow = rw;
+          if (adapt) {
+            // the three values move towards 32768 (index < s) or 0 by their distance >> rate: packed 16-bit arithmetic on {c0, c1}
+            // and on {c2, counter} (the counter half is replaced afterwards)
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const uint32_t cn = c2n >> 16;
+            const unsigned short rate = (unsigned short)(5 + (cn > 15) + (cn > 31));
+            const us2 rv = { rate, rate }, top = { 0x8000, 0x8000 };
+            const us2 a = __builtin_bit_cast(us2, c01), b = __builtin_bit_cast(us2, c2n);
+            const uint32_t up01 = __builtin_bit_cast(uint32_t, (us2)(a + ((top - a) >> rv))), dn01 = __builtin_bit_cast(uint32_t, (us2)(a - (a >> rv)));
+            const uint32_t up2 = __builtin_bit_cast(uint32_t, (us2)(b + ((top - b) >> rv))), dn2 = __builtin_bit_cast(uint32_t, (us2)(b - (b >> rv)));
+            const uint32_t m01 = s >= 2 ? 0xFFFFFFFFu : (s ? 0xFFFFu : 0u);   // halves with index < s
+            const uint32_t n01 = (up01 & m01) | (dn01 & ~m01);
+            const uint32_t n2 = ((s > 2 ? up2 : dn2) & 0xFFFFu) | ((cn + (cn < 32)) << 16);
+            nrow = (uint64_t)n01 | ((uint64_t)n2 << 32);
+            g_rc.row[slot][lane] = nrow;
           }
+          g_rc.ring[k & 1][jj][lane] = ent;
+          if (jj + 1 < RC_BATCH) { rw = slot_nx == slot ? nrow : rw_nx; slot = slot_nx; }
         }
       }
     } else if (k > 0) {
       const int base = (k - 1) * RC_BATCH;
-#pragma unroll 2
+      // the batch's 16 entries into registers at once (the reads are independent of the coder's state); an entry beyond this tile's
+      // count is coded as "the whole range" (fl = 32768, fh = 0 of a one-symbol alphabet): it changes nothing and emits nothing
+      uint32_t ce[RC_BATCH];
+#pragma unroll
+      for (int j = 0; j < RC_BATCH; j++) ce[j] = g_rc.ring[(k - 1) & 1][j][lane];
+#pragma unroll
       for (int j = 0; j < RC_BATCH; j++) {
-        if (base + j < count) {
-          const uint32_t ent = g_rc.ring[(k - 1) & 1][j][lane];
+        {
+          const uint32_t ent = base + j < count ? ce[j] : ENT_RESOLVED(512, 0, 0);
           const uint32_t fl6 = (ent >> 14) & 0x3FF, fh6 = (ent >> 4) & 0x3FF, ns = ent & 15;
           // range update (od_ec_encode_q15, the mirror of spec §8.2.6), branch-free: fl6 == 512 <=> s == 0
           uint32_t l = low, r = rng;
