@@ -508,6 +508,8 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     // on the context's own stream: hipMemset would run on the null stream, which a non-blocking stream does not wait
     // for - the fill could land after the first reconstruction kernel had written its block info
     HIPCHK(c, hipMemsetAsync(c->d_blk, 0, nf * nb8 * sizeof(Av1miBlkInfo), c->stream));
+    // (the range coder forms an entry's byte offset in 32 bits: slots of a chunk stay below 4 GB - 2 000 frames of 1080p)
+    if (nf * ntile * (size_t)slot * 2 >= ((size_t)1 << 32)) { set_err(c, "chunk too long: %zu frames need %zu bytes of bitstream slots (limit 4 GB)", nf, nf * ntile * (size_t)slot * 2); return AV1MI_E_UNSUPPORTED; }
     HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * ntile * slot * 2));  // 16-bit pre-carry entries, one per output byte
     c->out_cap = nf * (ntile * (size_t)(slot + 4) + 256);
     HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));

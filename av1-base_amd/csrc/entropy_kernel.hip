@@ -838,13 +838,18 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
   // has to be added to the bytes before it (od_ec's precarry buffer).  Nothing already written is ever touched here;
   // pack_tiles_kernel resolves the carries of a whole tile with a wave-parallel carry-lookahead when it copies the
   // tile to its final place.  This keeps the serial chain per symbol short: the kernel lasts as long as its longest tile.
-  uint16_t *const out = reinterpret_cast<uint16_t *>(slots) + (size_t)(live ? tile : 0) * P.tile_slot_bytes;
+  // (the byte offset of an entry is formed in 32 bits - the host refuses chunks whose slots exceed 4 GB - so the store takes its
+  // address as scalar base + vector offset; an entry beyond the slot's capacity goes to the last one: the overflow is reported
+  // through tile_bytes, what the slot then holds does not matter)
+  char *const out_base = reinterpret_cast<char *>(slots);
+  const uint32_t out_tile = (uint32_t)(live ? tile : 0) * (uint32_t)P.tile_slot_bytes;
   const int out_cap = P.tile_slot_bytes;  // entries
-#define EMIT(v_)                                                                               \
-  do {                                                                                         \
-    if (out_pos < out_cap) out[out_pos] = (uint16_t)((v_) & 0x1FFu);                           \
-    out_pos++;                                                                                 \
+#define PUT(pos_, v_)                                                                                                    \
+  do {                                                                                                                   \
+    const uint32_t ix_ = out_tile + (uint32_t)((pos_) < out_cap ? (pos_) : out_cap - 1);                                 \
+    *reinterpret_cast<uint16_t *>(out_base + ix_ * 2u) = (uint16_t)((v_) & 0x1FFu);                                      \
   } while (0)
+#define EMIT(v_) do { PUT(out_pos, v_); out_pos++; } while (0)
 
   __syncthreads();
   // batch k is resolved by wave 0 in trip k and coded by wave 1 in trip k + 1.  The resolver's stream reads are one
@@ -936,13 +941,14 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
           r = u - v;
           const int d = __builtin_clz(r) - 16;
           int s2 = cnt + d;
-          if (s2 >= 0) {
+          if (s2 >= 0) {   // one byte, or two when at least 8 bits are ready (od_ec_enc_normalize)
             int c = cnt + 16;
-            if (s2 >= 8) {
-              EMIT(l >> c);
-              l &= (1u << c) - 1;
-              c -= 8;
-            }
+            const bool two = s2 >= 8;
+            // no inner branch: the first byte is stored in any case and, if it was not due, overwritten by the second at the same position
+            PUT(out_pos, l >> c);
+            out_pos += two;
+            l = two ? l & ((1u << c) - 1) : l;
+            c = two ? c - 8 : c;
             EMIT(l >> c);
             l &= (1u << c) - 1;
             s2 = c + d - 24;
@@ -978,6 +984,7 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
   }
 }
 #undef EMIT
+#undef PUT
 
 }  // namespace
 
