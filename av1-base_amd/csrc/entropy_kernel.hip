@@ -129,21 +129,31 @@ __device__ __forceinline__ int scan_index(int row, int col, int n) {
   int lo = d - (n - 1) > 0 ? d - (n - 1) : 0;
   return before + ((d & 1) ? row - lo : col - lo);
 }
-// position (row << log2n | col) of scan index c in the default zig-zag of an n x n block: the inverse of scan_index,
-// computed (anti-diagonal by a float square root + integer fix-up) instead of looked up - the table cost 2.7 KB of LDS
-// per wave, i.e. a quarter of the kernel's occupancy
+// position (row << log2n | col) of scan index c in the default zig-zag of an n x n block: the inverse of scan_index, from a table
+// in device memory built at compile time (2.7 KB for 4x4 .. 32x32; L1 / L2 resident).  In LDS the table cost a quarter of the
+// kernel's occupancy, computed (anti-diagonal by a float square root + integer fix-up) it was 30 instructions per lane and pass
+// of a kernel that is bound by instruction issue.
+struct ScanTab { uint16_t v[16 + 64 + 256 + 1024]; };
+constexpr ScanTab make_scan_tab() {
+  ScanTab t{};
+  int off = 0;
+  for (int l = 2; l <= 5; l++) {
+    const int n = 1 << l;
+    for (int row = 0; row < n; row++)
+      for (int col = 0; col < n; col++) {
+        const int d = row + col;
+        const int before = d < n ? (d * (d + 1)) >> 1 : n * n - (((2 * n - 1 - d) * (2 * n - d)) >> 1);
+        const int lo = d - (n - 1) > 0 ? d - (n - 1) : 0;
+        t.v[off + before + ((d & 1) ? row - lo : col - lo)] = (uint16_t)((row << l) | col);
+      }
+    off += n * n;
+  }
+  return t;
+}
+__device__ const ScanTab c_scan_tab = make_scan_tab();
 __device__ __forceinline__ int scan_pos(int c, int log2n) {
-  const int n = 1 << log2n, half = (n * (n + 1)) >> 1;
-  const bool lower = c >= half;
-  const int cm = lower ? n * n - 1 - c : c;          // mirrored index in the lower-right triangle
-  int e = (int)((__builtin_sqrtf(8.0f * (float)cm + 1.0f) - 1.0f) * 0.5f);
-  e += ((e + 1) * (e + 2)) >> 1 <= cm;
-  e -= (e * (e + 1)) >> 1 > cm;
-  const int d = lower ? 2 * n - 2 - e : e;
-  const int before = lower ? n * n - (((2 * n - 1 - d) * (2 * n - d)) >> 1) : (d * (d + 1)) >> 1;
-  const int k = c - before, lo = lower ? d - (n - 1) : 0;
-  const int row = (d & 1) ? lo + k : d - (lo + k), col = d - row;
-  return (row << log2n) | col;
+  const int off = log2n == 2 ? 0 : (log2n == 3 ? 16 : (log2n == 4 ? 80 : 336));
+  return c_scan_tab.v[off + c];
 }
 
 __constant__ uint8_t c_base_ctx_off[5][5] = { { 0, 1, 6, 6, 21 }, { 1, 6, 6, 21, 21 }, { 6, 6, 21, 21, 21 }, { 6, 21, 21, 21, 21 }, { 21, 21, 21, 21, 21 } };
@@ -159,13 +169,17 @@ struct TileGeo {
   int max_x4_y, max_y4_y, max_x4_c, max_y4_c;  // frame limits in 4x4 units, superblock-local
 };
 
+// exclusive prefix sum over the wave with DPP row shifts and broadcasts (seven additions; the shuffle form went through LDS six times)
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
   int x = v;
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(x, o, 64);
-    if (lane >= o) x += t;
-  }
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8   (inclusive within rows of 16)
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
   *total = __builtin_amdgcn_readlane(x, 63);
+  (void)lane;
   return x - v;
 }
 
