@@ -276,7 +276,9 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
         const int a01 = LVA(row, col + 1), a10 = LVA(row + 1, col), a11 = LVA(row + 1, col + 1), a02 = LVA(row, col + 2), a20 = LVA(row + 2, col);
 #undef LVA
         const int mag = imin(a01, 3) + imin(a10, 3) + imin(a11, 3) + imin(a02, 3) + imin(a20, 3);
-        cb = pos == 0 ? 0 : imin((mag + 1) >> 1, 4) + c_base_ctx_off[imin(row, 4)][imin(col, 4)];
+        // Coeff_Base_Ctx_Offset of a square block depends on row + col only: 0, 1, 6, 6, 21, 21 ... (a table load per lane otherwise)
+        const int rc = row + col;
+        cb = pos == 0 ? 0 : imin((mag + 1) >> 1, 4) + (rc < 2 ? rc : (rc < 4 ? 6 : 21));
         int mb = imin(a01, 15) + imin(a10, 15) + imin(a11, 15);
         mb = imin((mb + 1) >> 1, 6);
         cbr = pos == 0 ? mb : ((row < 2 && col < 2) ? mb + 7 : mb + 14);
