@@ -324,9 +324,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       int v = 0;
       if (c < eob) v = S->lv[scan(c)];
       const int level = iabs(v);
-      int lsum = level;
-      for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
-      cul += uni(lsum);
+      { int lsum; (void)wave_excl_scan(level, lane, &lsum); cul += lsum; }   // (the DPP prefix sum's total)
       if (c0 == 0) {
         const int v0 = __builtin_amdgcn_readlane(v, 0);
         if (v0 != 0) {
