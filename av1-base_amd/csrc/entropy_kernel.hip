@@ -207,7 +207,11 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
     if (x4 + lane < max_x4) { nb_or |= (a_lvl[x4 + lane] | a_dc[x4 + lane]) ? 1 : 0; int sg = a_dc[x4 + lane]; dsum += sg == 1 ? -1 : (sg == 2 ? 1 : 0); }
     if (y4 + lane < max_y4) { nb_or |= (l_lvl[y4 + lane] | l_dc[y4 + lane]) ? 2 : 0; int sg = l_dc[y4 + lane]; dsum += sg == 1 ? -1 : (sg == 2 ? 1 : 0); }
   }
-  for (int o = 8; o > 0; o >>= 1) { nb_or |= __shfl_xor(nb_or, o, 64); dsum += __shfl_xor(dsum, o, 64); }   // w4 <= 16 lanes hold values
+  // w4 <= 16 lanes hold values: an all-reduce inside the first row of 16 lanes by DPP rotations (row_ror 8, 4, 2, 1)
+  nb_or |= __builtin_amdgcn_update_dpp(0, nb_or, 0x128, 0xF, 0xF, false); dsum += __builtin_amdgcn_update_dpp(0, dsum, 0x128, 0xF, 0xF, false);
+  nb_or |= __builtin_amdgcn_update_dpp(0, nb_or, 0x124, 0xF, 0xF, false); dsum += __builtin_amdgcn_update_dpp(0, dsum, 0x124, 0xF, 0xF, false);
+  nb_or |= __builtin_amdgcn_update_dpp(0, nb_or, 0x122, 0xF, 0xF, false); dsum += __builtin_amdgcn_update_dpp(0, dsum, 0x122, 0xF, 0xF, false);
+  nb_or |= __builtin_amdgcn_update_dpp(0, nb_or, 0x121, 0xF, 0xF, false); dsum += __builtin_amdgcn_update_dpp(0, dsum, 0x121, 0xF, 0xF, false);
   nb_or = uni(nb_or); dsum = uni(dsum);
   // luma: TX_MODE_LARGEST with square blocks => transform == block => ctx 0
   const int zctx = plane == 0 ? 0 : 7 + (nb_or & 1) + (nb_or >> 1);
