@@ -161,13 +161,53 @@ __device__ __forceinline__ void stamp_phase(int cls, int phase) {
 #endif
 __constant__ int16_t c_subpel[2][16][8] = AV1_SUBPEL_FILTERS_INIT;  // EIGHTTAP, and its 4-tap form for 4-sample blocks
 
+// Wave reductions by DPP row shifts and broadcasts (an addition or a maximum each) instead of butterfly shuffles: a shuffle is an LDS
+// round trip, six of them in a row were ~400 cycles of pure latency per reduction, and a block pass makes five.
+// Inclusive "scan" with OP along the wave: afterwards lane 31 holds the reduction of lanes 0-31 and lane 63 that of all 64.
+#define AV1MI_DPP_SCAN(x_, OP)                                                                 \
+  do {                                                                                         \
+    x_ = OP(x_, __builtin_amdgcn_update_dpp(x_, x_, 0x111, 0xF, 0xF, false)); /* row_shr:1 */   \
+    x_ = OP(x_, __builtin_amdgcn_update_dpp(x_, x_, 0x112, 0xF, 0xF, false)); /* row_shr:2 */   \
+    x_ = OP(x_, __builtin_amdgcn_update_dpp(x_, x_, 0x114, 0xF, 0xF, false)); /* row_shr:4 */   \
+    x_ = OP(x_, __builtin_amdgcn_update_dpp(x_, x_, 0x118, 0xF, 0xF, false)); /* row_shr:8 */   \
+    x_ = OP(x_, __builtin_amdgcn_update_dpp(x_, x_, 0x142, 0xA, 0xF, false)); /* row_bcast:15 */\
+  } while (0)
+__device__ __forceinline__ int dpp_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int dpp_max(int a, int b) { return a > b ? a : b; }
+// (the shifted-in value of lanes without a source is the lane's own value, `old` = x: harmless for a maximum; for a sum the lanes
+// that matter - the last lane of every row - always have a source)
 __device__ __forceinline__ int wave_sum(int v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  return __builtin_amdgcn_readlane(x, 63);
+}
+// sum inside each half of the wave (lanes 0-31 | 32-63), returned to every lane of the half
+__device__ __forceinline__ int half_sum(int v, int lane) {
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  const int lo = __builtin_amdgcn_readlane(x, 31), hi = __builtin_amdgcn_readlane(x, 63);
+  return lane < 32 ? lo : hi;
 }
 __device__ __forceinline__ int wave_max(int v) {
-  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-  return v;
+  int x = v;
+  AV1MI_DPP_SCAN(x, dpp_max);
+  x = dpp_max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));
+  return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ int half_max(int v, int lane) {
+  int x = v;
+  AV1MI_DPP_SCAN(x, dpp_max);
+  const int lo = __builtin_amdgcn_readlane(x, 31), hi = __builtin_amdgcn_readlane(x, 63);
+  return lane < 32 ? lo : hi;
 }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int rshift_round(int v, int s) { return s ? (v + (1 << (s - 1))) >> s : v; }
@@ -562,7 +602,9 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       S->edge_l[eo] = (uint16_t)tl;
     }
     constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
-    if (lane < N) S->smw[lane] = c_sm_weights[WOFF + lane];
+    // (only when a smooth mode can be asked for: a per-lane table load whose latency the following barrier would expose in every item;
+    // chroma follows luma's mode, so the candidate mask covers both)
+    if ((P->mode_mask & 0xE00u) && lane < N) S->smw[lane] = c_sm_weights[WOFF + lane];
   }
   wave_sync();
   STAMP(0);   // source -> LDS, edges from the line buffers
@@ -570,7 +612,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   {
     int s = 0;
     if (sl < N) s = (have_above ? S->edge_a[eo + 1 + sl] : 0) + (have_left ? S->edge_l[eo + 1 + sl] : 0);
-    for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = NPL == 1 ? wave_sum(s) : half_sum(s, lane);
     if (have_above && have_left) dcv = (s + N) >> (LOG2N + 1);
     else if (have_above || have_left) dcv = (s + (N >> 1)) >> LOG2N;
     else dcv = 1 << (bd - 1);
@@ -675,7 +717,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   if constexpr (EXT && NPL == 2 && !INTER && PH == 0 && N <= 16) {
     if (P->cfl) {
       const int16_t *AC = S->scratch + CFL_ACO;
-      auto group_sum = [&](int v) { for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+      auto group_sum = [&](int v) { return half_sum(v, lane); };   // (NPL == 2 here)
       int ang, dx, dy;
       dir_params(best_mode, best_delta, ang, dx, dy);
       const uint16_t *EA = nullptr, *EL = nullptr;
@@ -975,7 +1017,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       for (int j = CW; j < N; j++) x[j] = 0;
     }
   }
-  for (int o = G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(my_key, o, 64); my_key = t > my_key ? t : my_key; }
+  my_key = NPL == 1 ? wave_max(my_key) : half_max(my_key, lane);
   int eob = 0;
   if (my_key >= 0) {
     const int d0 = my_key >> 6, w = my_key & 63;
