@@ -93,7 +93,7 @@ template <int TSB> struct LinesSel;
 template <> struct LinesSel<1> { static __device__ __forceinline__ LineLds<1> &get() { return g_lines1; } };
 template <> struct LinesSel<2> { static __device__ __forceinline__ LineLds<2> &get() { return g_lines2; } };
 #define LN (LinesSel<TSB>::get())
-struct SbLds {
+struct alignas(16) SbLds {
   uint16_t blkpix[MAXN * MAXN];     // prediction, then reconstruction, of the current transform block
   uint16_t srcblk[MAXN * MAXN];     // source pixels of the block; reused for the quantised levels
   int16_t scratch[MAXN * (MAXN + 1)];     // 2-D transform staging (every intermediate fits 16 bits)
@@ -557,16 +557,35 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       }
     }
   }
-  // ---- source block -> LDS (coalesced rows)
+  // ---- source block -> LDS.  16-bit samples of a block inside the frame go as 16-byte pieces of a row (8 samples: two loads per
+  // lane for a 32x32 block instead of sixteen 2-byte ones, full cache lines; the stamps build had the sixteen at 25 - 30 % of a
+  // block pass); 8-bit samples, 4-wide blocks and blocks that overhang the frame edge (clamped coordinates) sample by sample.
   {
     const PIX *pl = frame + poff;
+    bool wide = false;
+    if constexpr (sizeof(PIX) == 2 && N >= 8) {
+      wide = uniform_i(!overhang && ((gs | gx) & 7) == 0);
+      if (wide) {
+        constexpr int CPR = N / 8;   // 16-byte pieces per row
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = sl; q < N * CPR; q += G) {
+          const int r = q / CPR, c8 = q - r * CPR;
+          const u4 v = *reinterpret_cast<const u4 *>(pl + (size_t)(gy + r) * gs + gx + 8 * c8);
+          *reinterpret_cast<u4 *>(&S->srcblk[po + r * N + 8 * c8]) = v;
+        }
+      }
+    }
+    if (!wide) {
 #pragma unroll   // all of the block's loads in flight together (N*N/G <= 16 per lane)
-    for (int p = sl; p < N * N; p += G) {
-      int r = p >> LOG2N, c = p & (N - 1);
-      if (overhang) { r = r < ph_lim ? r : ph_lim - 1; c = c < pw_lim ? c : pw_lim - 1; }
-      S->srcblk[po + p] = (uint16_t)pl[(size_t)(gy + r) * gs + gx + c];
+      for (int p = sl; p < N * N; p += G) {
+        int r = p >> LOG2N, c = p & (N - 1);
+        if (overhang) { r = r < ph_lim ? r : ph_lim - 1; c = c < pw_lim ? c : pw_lim - 1; }
+        S->srcblk[po + p] = (uint16_t)pl[(size_t)(gy + r) * gs + gx + c];
+      }
     }
   }
+  STAMP(7);   // (diagnostic build: the source loads alone)
   // ---- edges from the line buffers (spec §7.11.2; tile == superblock: nothing outside it is available)
   int dcv = 0;
   if constexpr (PH != 1) {

@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "av1-base_amd")
 OUT = os.path.join(PKG, "build_stamps", "libav1mi_stamps.so")
-PHASES = ["src+edges", "dc+3 SADs", "decide+pred+resid", "fwd cols", "fwd rows+q+dq+inv rows", "inv cols+levels", "recon out", "-"]
+PHASES = ["edges", "dc+3 SADs", "decide+pred+resid", "fwd", "q+dq+inv rows", "inv cols+levels", "recon out", "src load"]
 CLASSES = ["luma 32", "luma 16", "luma 8", "chroma 16", "chroma 8", "chroma 4"]
 
 
@@ -73,10 +73,10 @@ def main():
         print("== %s: recon stage %.3f ms; %d tile-walk waves, %.0f cycles = %.1f us per wave (s_memrealtime): shader clock %.2f GHz; stamped %.0f %%" % (
             name, rep.ms_recon, waves, tot / max(waves, 1), real / max(waves, 1) / 100.0, tot / max(real, 1) * 0.1, 100.0 * sum(st[:48]) / max(tot, 1)))
         for c, cn in enumerate(CLASSES):
-            row = [st[c * 8 + k] for k in range(7)]
+            row = [st[c * 8 + k] for k in range(8)]
             if sum(row) == 0:
                 continue
-            print("   %-10s %5.1f %% of the wave |" % (cn, 100.0 * sum(row) / max(tot, 1)), "  ".join("%s %4.1f%%" % (PHASES[k], 100.0 * row[k] / sum(row)) for k in range(7)))
+            print("   %-10s %5.1f %% of the wave |" % (cn, 100.0 * sum(row) / max(tot, 1)), "  ".join("%s %4.1f%%" % (PHASES[k], 100.0 * row[k] / sum(row)) for k in range(8)))
     lib.av1mi_ctx_destroy(h)
 
 
