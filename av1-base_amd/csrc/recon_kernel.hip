@@ -1084,19 +1084,37 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
   }
   if (eob) {  // levels out (32-bit words, coalesced inside the group)
-    constexpr int WORDS = CW * CW / 2;
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(grp ? lv_out1 : lv_out0);
-    for (int i = sl; i < WORDS; i += G) d32[i] = (uint32_t)(uint16_t)lvl[2 * i] | ((uint32_t)(uint16_t)lvl[2 * i + 1] << 16);
+    // (16 bytes = 8 levels per store: the block's area of the level buffer is 32-byte aligned, av1mi_levels_off)
+    constexpr int PIECES = CW * CW / 8;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 *d128 = reinterpret_cast<u4 *>(grp ? lv_out1 : lv_out0);
+    const u4 *l128 = reinterpret_cast<const u4 *>(lvl);
+    for (int i = sl; i < PIECES; i += G) d128[i] = l128[i];
   }
   wave_sync();
   STAMP(5);   // inverse columns, levels -> HBM
   // ---- reconstruction -> HBM (coalesced rows) and -> line buffers for the neighbours to come
   {
     PIX *pl = rec_frame + poff;
+    bool wide_out = false;
+    if constexpr (sizeof(PIX) == 2 && N >= 8) {   // 16-byte pieces of the rows, as the source came in
+      wide_out = uniform_i(!overhang && ((gs | gx) & 7) == 0);
+      if (wide_out) {
+        constexpr int CPR = N / 8;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = sl; q < N * CPR; q += G) {
+          const int r = q / CPR, c8 = q - r * CPR;
+          *reinterpret_cast<u4 *>(pl + (size_t)(gy + r) * gs + gx + 8 * c8) = *reinterpret_cast<const u4 *>(&S->blkpix[po + r * N + 8 * c8]);
+        }
+      }
+    }
+    if (!wide_out) {
 #pragma unroll 4
-    for (int p = sl; p < N * N; p += G) {
-      const int r = p >> LOG2N, c = p & (N - 1);
-      if (!overhang || (r < ph_lim && c < pw_lim)) pl[(size_t)(gy + r) * gs + gx + c] = (PIX)S->blkpix[po + p];
+      for (int p = sl; p < N * N; p += G) {
+        const int r = p >> LOG2N, c = p & (N - 1);
+        if (!overhang || (r < ph_lim && c < pw_lim)) pl[(size_t)(gy + r) * gs + gx + c] = (PIX)S->blkpix[po + p];
+      }
     }
     if constexpr (PH != 1) {
       if (sl < N) {
