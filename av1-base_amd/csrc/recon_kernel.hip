@@ -545,14 +545,31 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   STAMP(-1);
   // ---- sub-sample motion compensation (PH == 1 items of the sub-sample kernels: EXT says so there) - first of all, while the source
   // and staging tiles are still free for its window
-  bool mc_in_lds = false;  // the motion-compensated prediction already sits in blkpix (sub-sample position, EIGHTTAP)
-  if constexpr (INTER && PH == 1 && EXT) {
-    if (P->subpel) {
-      const int ss = plane0 > 0;
-      const int px0 = (gx << 4) + ((2 * ii.mv_col) >> ss), py0 = (gy << 4) + ((2 * ii.mv_row) >> ss);
-      if ((px0 | py0) & 15) {
-        mc_block_8tap<PIX, LOG2N, NPL>(static_cast<const PIX *>(ii.ref) + poff, gs, ((P->true_w + ss) >> ss) - 1, ((P->true_h + ss) >> ss) - 1,
-                                       px0, py0, (1 << bd) - 1, grp, sl, S->srcblk, S->blkpix + po);
+  bool mc_in_lds = false;  // the motion-compensated prediction already sits in blkpix
+  if constexpr (INTER && PH == 1) {
+    const int ss = plane0 > 0;
+    const int px0 = (gx << 4) + ((2 * ii.mv_col) >> ss), py0 = (gy << 4) + ((2 * ii.mv_row) >> ss);
+    const int last_x = ((P->true_w + ss) >> ss) - 1, last_y = ((P->true_h + ss) >> ss) - 1;
+    if constexpr (EXT) {
+      if (P->subpel && ((px0 | py0) & 15)) {   // sub-sample position: EIGHTTAP
+        mc_block_8tap<PIX, LOG2N, NPL>(static_cast<const PIX *>(ii.ref) + poff, gs, last_x, last_y, px0, py0, (1 << bd) - 1, grp, sl, S->srcblk, S->blkpix + po);
+        mc_in_lds = true;
+      }
+    }
+    if constexpr (sizeof(PIX) == 2 && N >= 8) {
+      // whole-sample position with the block inside the reference: the prediction is a copy - 16-byte pieces of the reference's rows
+      // (any 2-byte alignment: the vector points anywhere) instead of one clamped 2-byte load per sample
+      const int ix = px0 >> 4, iy = py0 >> 4;
+      if (!mc_in_lds && uniform_i(((px0 | py0) & 15) == 0 && ix >= 0 && iy >= 0 && ix + N - 1 <= last_x && iy + N - 1 <= last_y)) {
+        constexpr int CPR = N / 8;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        typedef u4 u4_any __attribute__((aligned(2)));
+        const PIX *rp = static_cast<const PIX *>(ii.ref) + poff;
+#pragma unroll
+        for (int q = sl; q < N * CPR; q += G) {
+          const int r = q / CPR, c8 = q - r * CPR;
+          *reinterpret_cast<u4 *>(&S->blkpix[po + r * N + 8 * c8]) = *reinterpret_cast<const u4_any *>(rp + (size_t)(iy + r) * gs + ix + 8 * c8);
+        }
         mc_in_lds = true;
       }
     }
