@@ -97,8 +97,8 @@ struct alignas(16) SbLds {
   uint16_t blkpix[MAXN * MAXN];     // prediction, then reconstruction, of the current transform block
   uint16_t srcblk[MAXN * MAXN];     // source pixels of the block; reused for the quantised levels
   int16_t scratch[MAXN * (MAXN + 1)];     // 2-D transform staging (every intermediate fits 16 bits)
-  uint16_t edge_a[2 * 64 + 8];  // [0] = element -1
-  uint16_t edge_l[2 * 64 + 8];
+  uint16_t edge_a[2 * 72 + 8];  // element i of a lane group's edge at [group * 72 + 8 + i] (i >= -1): element 0 is 16-byte aligned
+  uint16_t edge_l[2 * 72 + 8];
   uint8_t blkdec[2][19][19];    // luma, chroma (U and V decode together)
   uint8_t smw[64];              // smooth weights of the current block size
   int eobs[4];                  // eob of the current block's Y, U, V transform blocks
@@ -493,7 +493,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   constexpr int G = 64 / NPL;              // lanes per group
   constexpr int PIXO = NPL == 1 ? 0 : (N > 16 ? 1024 : 512); // per-group offset inside srcblk / blkpix (NPL == 2: N <= 16, or 32 in the 64x64 build)
   constexpr int SCRO = NPL == 1 ? 0 : (N > 16 ? 32 * 33 : 16 * 17);
-  constexpr int EDGO = NPL == 1 ? 0 : 68;
+  constexpr int EDGO = NPL == 1 ? 0 : 72;
+  constexpr int EB = 8;   // index of element 0 inside a group's edge array
   const Av1miDevParams *P = cx.P;
   const int lane = cx.lane;
   const int grp = NPL == 1 ? 0 : lane >> 5, sl = NPL == 1 ? lane : lane & 31;
@@ -625,8 +626,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         if (lim > max_y) lim = max_y;
         l = LN.left[plane][ly + i < lim ? ly + i : lim];              // pixel (., x0-1)
       }
-      S->edge_a[eo + 1 + i] = (uint16_t)a;
-      S->edge_l[eo + 1 + i] = (uint16_t)l;
+      S->edge_a[eo + EB + i] = (uint16_t)a;
+      S->edge_l[eo + EB + i] = (uint16_t)l;
     }
     if (sl == 0) {
       int tl;
@@ -634,8 +635,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       else if (have_above) tl = LN.above[plane][lx];
       else if (have_left) tl = LN.left[plane][ly];
       else tl = 1 << (bd - 1);
-      S->edge_a[eo] = (uint16_t)tl;
-      S->edge_l[eo] = (uint16_t)tl;
+      S->edge_a[eo + EB - 1] = (uint16_t)tl;
+      S->edge_l[eo + EB - 1] = (uint16_t)tl;
     }
     constexpr int WOFF = LOG2N == 2 ? 0 : (LOG2N == 3 ? 4 : (LOG2N == 4 ? 12 : (LOG2N == 5 ? 28 : 60)));
     // (only when a smooth mode can be asked for: a per-lane table load whose latency the following barrier would expose in every item;
@@ -647,7 +648,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // ---- DC value (sum within the lane group)
   {
     int s = 0;
-    if (sl < N) s = (have_above ? S->edge_a[eo + 1 + sl] : 0) + (have_left ? S->edge_l[eo + 1 + sl] : 0);
+    if (sl < N) s = (have_above ? S->edge_a[eo + EB + sl] : 0) + (have_left ? S->edge_l[eo + EB + sl] : 0);
     s = NPL == 1 ? wave_sum(s) : half_sum(s, lane);
     if (have_above && have_left) dcv = (s + N) >> (LOG2N + 1);
     else if (have_above || have_left) dcv = (s + (N >> 1)) >> LOG2N;
@@ -682,7 +683,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   constexpr int FEL = N >= 64 ? 136 : 72;
   uint16_t *const FA = reinterpret_cast<uint16_t *>(S->scratch + so) + 2, *const FL = FA + FEL;
   auto dir_edges = [&](int ang, const uint16_t *&A, const uint16_t *&L, int &up_a, int &up_l) -> bool {
-    A = S->edge_a + 1 + eo; L = S->edge_l + 1 + eo; up_a = 0; up_l = 0;
+    A = S->edge_a + EB + eo; L = S->edge_l + EB + eo; up_a = 0; up_l = 0;
     if (PH == 1 || !EXT || !P->edge_filter || ang == 0 || ang == 90 || ang == 180) return false;
     const uint16_t *RA = A, *RL = L;
     const int n_top = N < pw_lim ? N : pw_lim, n_left = N < ph_lim ? N : ph_lim;
@@ -724,13 +725,35 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   if (PH != 1 && NPL == 1 && plane0 == 0 && P->mode_mask == 0x7u) {
     // default candidate set {DC, V, H}: the three SADs in one pass over the block instead of three
     int s_dc = 0, s_v = 0, s_h = 0;
-    const uint16_t *A = S->edge_a + 1, *L = S->edge_l + 1;
+    const uint16_t *A = S->edge_a + EB, *L = S->edge_l + EB;
+    if constexpr (LOG2N == 5) {
+      // 32x32: eight samples per lane and step - 128-bit LDS reads of the source row piece and of the above edge, v_sad_u16 on packed
+      // pairs (sixteen steps of one sample each were 10 % of the block pass)
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const uint32_t dc2 = (uint32_t)dcv * 0x10001u;
+      uint32_t a_dc = 0, a_v = 0, a_h = 0;
+#pragma unroll
+      for (int q = lane; q < 128; q += 64) {
+        const int r = q >> 2, c8 = q & 3;
+        const u4 sv = *reinterpret_cast<const u4 *>(&S->srcblk[r * 32 + 8 * c8]);
+        const u4 av = *reinterpret_cast<const u4 *>(&A[8 * c8]);
+        const uint32_t l2 = (uint32_t)L[r] * 0x10001u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          a_dc = __builtin_amdgcn_sad_u16(sv[k], dc2, a_dc);
+          a_v = __builtin_amdgcn_sad_u16(sv[k], av[k], a_v);
+          a_h = __builtin_amdgcn_sad_u16(sv[k], l2, a_h);
+        }
+      }
+      s_dc = (int)a_dc; s_v = (int)a_v; s_h = (int)a_h;
+    } else {
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) {
       const int sv = S->srcblk[p];
       s_dc += iabs(sv - dcv);
       s_v += iabs(sv - (int)A[p & (N - 1)]);
       s_h += iabs(sv - (int)L[p >> LOG2N]);
+    }
     }
     sad_dc = wave_sum(s_dc);
     s_v = wave_sum(s_v);
@@ -834,6 +857,31 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     // (fe: the filtered edges occupy the staging area the residual goes to - it is then written in a pass of its own)
     const bool fe = ((INTER && final_trip && ii.is_inter) || use_cfl) ? false : dir_edges(ang, EA, EL, up_a, up_l);
     int sad = 0;
+    bool vec_done = false;
+    if constexpr (MM) {
+      // final trip of a luma 32x32 block predicted DC, V or H from the raw edges: prediction and residual eight samples per lane and
+      // step (128-bit LDS accesses, packed 16-bit subtraction) instead of one
+      if (final_trip && !(INTER && ii.is_inter) && !fe && (mode == DC_PRED || ang == 90 || ang == 180)) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        typedef short s8 __attribute__((ext_vector_type(8)));
+        const uint16_t *A0 = S->edge_a + EB + eo, *L0 = S->edge_l + EB + eo;
+        const uint32_t dc2 = (uint32_t)dcv * 0x10001u;
+#pragma unroll
+        for (int q = lane; q < 128; q += 64) {
+          const int r = q >> 2, c8 = q & 3;
+          const u4 sv = *reinterpret_cast<const u4 *>(&S->srcblk[po + r * 32 + 8 * c8]);
+          u4 pv4;
+          if (mode == DC_PRED) pv4 = (u4){ dc2, dc2, dc2, dc2 };
+          else if (ang == 90) pv4 = *reinterpret_cast<const u4 *>(&A0[8 * c8]);
+          else { const uint32_t l2 = (uint32_t)L0[r] * 0x10001u; pv4 = (u4){ l2, l2, l2, l2 }; }
+          const u4 rs = __builtin_bit_cast(u4, (s8)(__builtin_bit_cast(s8, sv) - __builtin_bit_cast(s8, pv4)));   // eight 16-bit differences
+          *reinterpret_cast<u4 *>(&S->blkpix[po + r * 32 + 8 * c8]) = pv4;
+          *reinterpret_cast<u4 *>(&S->scratch[so + r * STR + 8 * c8]) = rs;
+        }
+        vec_done = true;
+      }
+    }
+    if (!vec_done)
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) {
       const int r = p >> LOG2N, c = p & (N - 1);
