@@ -489,10 +489,13 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // MM: luma 32x32 blocks run the forward transform as a matrix product on the matrix cores: the residual rows are
   // then read with 128-bit loads, so they lie 32 apart (16-byte aligned) instead of 33
   constexpr bool MM = LOG2N == 5 && NPL == 1;
-  constexpr int STR = MM ? 32 : ST;
+  // VEC: block classes whose DC / V / H prediction and residual are written eight samples per lane and step (128-bit LDS accesses):
+  // luma 32x32 and the chroma 16x16 pair; their residual rows lie 32 / 24 apart (16-byte aligned)
+  constexpr bool VEC = MM || (LOG2N == 4 && NPL == 2);
+  constexpr int STR = MM ? 32 : (VEC ? 24 : ST);
   constexpr int G = 64 / NPL;              // lanes per group
   constexpr int PIXO = NPL == 1 ? 0 : (N > 16 ? 1024 : 512); // per-group offset inside srcblk / blkpix (NPL == 2: N <= 16, or 32 in the 64x64 build)
-  constexpr int SCRO = NPL == 1 ? 0 : (N > 16 ? 32 * 33 : 16 * 17);
+  constexpr int SCRO = NPL == 1 ? 0 : (N > 16 ? 32 * 33 : 16 * 24);   // (16 rows of stride 24: see STR)
   constexpr int EDGO = NPL == 1 ? 0 : 72;
   constexpr int EB = 8;   // index of element 0 inside a group's edge array
   const Av1miDevParams *P = cx.P;
@@ -766,7 +769,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // ---- chroma from luma (spec 7.11.5): key-frame blocks up to 32x32 luma.  The luma item left the block's
   // subsampled reconstruction minus its average (Q3) behind the two groups' staging areas; lanes 0-31 decide U's alpha and lanes
   // 32-63 V's at the same time: least-squares estimate, then the SAD of the estimate and its two neighbours.
-  constexpr int CFL_ACO = 2 * 16 * 17;   // offset of that buffer in S->scratch (chroma blocks up to 16x16, NPL == 2)
+  constexpr int CFL_ACO = 2 * 16 * 24;   // offset of that buffer in S->scratch (behind the two groups' staging areas of chroma blocks up to 16x16)
   int use_cfl = 0, cfl_alpha = 0;
   auto cfl_px = [&](int alpha, int ac) {
     const int sa = alpha * ac, rr = sa >= 0 ? (sa + 32) >> 6 : -((-sa + 32) >> 6);   // Round2Signed(alpha * ac, 6)
@@ -858,24 +861,25 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     const bool fe = ((INTER && final_trip && ii.is_inter) || use_cfl) ? false : dir_edges(ang, EA, EL, up_a, up_l);
     int sad = 0;
     bool vec_done = false;
-    if constexpr (MM) {
-      // final trip of a luma 32x32 block predicted DC, V or H from the raw edges: prediction and residual eight samples per lane and
-      // step (128-bit LDS accesses, packed 16-bit subtraction) instead of one
-      if (final_trip && !(INTER && ii.is_inter) && !fe && (mode == DC_PRED || ang == 90 || ang == 180)) {
+    if constexpr (VEC) {
+      // final trip of a luma 32x32 block / a chroma 16x16 pair predicted DC, V or H from the raw edges: prediction and residual eight
+      // samples per lane and step (128-bit LDS accesses, packed 16-bit subtraction) instead of one
+      if (final_trip && !(INTER && ii.is_inter) && !fe && !use_cfl && (mode == DC_PRED || ang == 90 || ang == 180)) {
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         typedef short s8 __attribute__((ext_vector_type(8)));
         const uint16_t *A0 = S->edge_a + EB + eo, *L0 = S->edge_l + EB + eo;
         const uint32_t dc2 = (uint32_t)dcv * 0x10001u;
+        constexpr int CPR = N / 8;
 #pragma unroll
-        for (int q = lane; q < 128; q += 64) {
-          const int r = q >> 2, c8 = q & 3;
-          const u4 sv = *reinterpret_cast<const u4 *>(&S->srcblk[po + r * 32 + 8 * c8]);
+        for (int q = sl; q < N * CPR; q += G) {
+          const int r = q / CPR, c8 = q - r * CPR;
+          const u4 sv = *reinterpret_cast<const u4 *>(&S->srcblk[po + r * N + 8 * c8]);
           u4 pv4;
           if (mode == DC_PRED) pv4 = (u4){ dc2, dc2, dc2, dc2 };
           else if (ang == 90) pv4 = *reinterpret_cast<const u4 *>(&A0[8 * c8]);
           else { const uint32_t l2 = (uint32_t)L0[r] * 0x10001u; pv4 = (u4){ l2, l2, l2, l2 }; }
           const u4 rs = __builtin_bit_cast(u4, (s8)(__builtin_bit_cast(s8, sv) - __builtin_bit_cast(s8, pv4)));   // eight 16-bit differences
-          *reinterpret_cast<u4 *>(&S->blkpix[po + r * 32 + 8 * c8]) = pv4;
+          *reinterpret_cast<u4 *>(&S->blkpix[po + r * N + 8 * c8]) = pv4;
           *reinterpret_cast<u4 *>(&S->scratch[so + r * STR + 8 * c8]) = rs;
         }
         vec_done = true;
@@ -1016,7 +1020,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   } else {
     if (tx_lane) {
   #pragma unroll
-      for (int i = 0; i < N; i++) x[i] = (int)S->scratch[so + i * ST + sl] << SH0;
+      for (int i = 0; i < N; i++) x[i] = (int)S->scratch[so + i * STR + sl] << SH0;   // (the residual's row stride; the passes' own tile is ST)
       Tx1d<LOG2N>::fwd(x, vt);
   #pragma unroll
       for (int i = 0; i < CW; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
@@ -1206,7 +1210,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     // average, for the chroma item that follows (it may predict from it - spec 7.11.5)
     if (plane0 == 0 && P->cfl) {
       constexpr int NC = N / 2, L2C = LOG2N - 1;
-      int16_t *AC = S->scratch + 2 * 16 * 17;
+      int16_t *AC = S->scratch + 2 * 16 * 24;
       int sum = 0;
       for (int p = lane; p < NC * NC; p += 64) {
         const int i = p >> L2C, j = p & (NC - 1);
