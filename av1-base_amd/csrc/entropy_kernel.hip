@@ -48,7 +48,7 @@ struct InterLds {
 __shared__ InterLds g_inter;
 struct SymLds {
   uint16_t cdf[CL::COEFF_BASE + 18];   // wide rows; + 18: whole-row reads by 17 lanes may run past the last row
-  int16_t lv[32 * 32];
+  alignas(16) int16_t lv[32 * 32];
   uint8_t left_lvl[3][16], left_dc[3][16];   // per superblock row of the tile
 };
 __shared__ SymLds g_sym;
@@ -219,8 +219,11 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
   int cul = 0, dc_cat = 0;
   if (eob != 0) {
     {
-      const uint32_t *g32 = reinterpret_cast<const uint32_t *>(lv_global);
-      for (int i = lane; i < n * n / 2; i += 64) { const uint32_t w = g32[i]; S->lv[2 * i] = (int16_t)(w & 0xFFFF); S->lv[2 * i + 1] = (int16_t)(w >> 16); }
+      // the block's levels, 16 bytes (8 levels) per lane and step, straight into the LDS copy (same row-major layout)
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const u4 *g128 = reinterpret_cast<const u4 *>(lv_global);
+      u4 *l128 = reinterpret_cast<u4 *>(S->lv);
+      for (int i = lane; i < n * n / 8; i += 64) l128[i] = g128[i];
       __syncthreads();
     }
     if (plane == 0 && is_inter) {
