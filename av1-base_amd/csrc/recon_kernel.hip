@@ -597,6 +597,26 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         }
       }
     }
+    if constexpr (sizeof(PIX) == 1 && N >= 16) {   // 8-bit samples: 16 of them per 16-byte load, widened to the tile's 16-bit layout
+      wide = uniform_i(!overhang && ((gs | gx) & 15) == 0);
+      if (wide) {
+        constexpr int CPR = N / 16;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = sl; q < N * CPR; q += G) {
+          const int r = q / CPR, c16 = q - r * CPR;
+          const u4 v = *reinterpret_cast<const u4 *>(pl + (size_t)(gy + r) * gs + gx + 16 * c16);
+          u4 lo, hi;
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            lo[2 * k] = __builtin_amdgcn_perm(0u, v[k], 0x0c010c00u); lo[2 * k + 1] = __builtin_amdgcn_perm(0u, v[k], 0x0c030c02u);
+            hi[2 * k] = __builtin_amdgcn_perm(0u, v[2 + k], 0x0c010c00u); hi[2 * k + 1] = __builtin_amdgcn_perm(0u, v[2 + k], 0x0c030c02u);
+          }
+          *reinterpret_cast<u4 *>(&S->srcblk[po + r * N + 16 * c16]) = lo;
+          *reinterpret_cast<u4 *>(&S->srcblk[po + r * N + 16 * c16 + 8]) = hi;
+        }
+      }
+    }
     if (!wide) {
 #pragma unroll   // all of the block's loads in flight together (N*N/G <= 16 per lane)
       for (int p = sl; p < N * N; p += G) {
@@ -1175,6 +1195,22 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         for (int q = sl; q < N * CPR; q += G) {
           const int r = q / CPR, c8 = q - r * CPR;
           *reinterpret_cast<u4 *>(pl + (size_t)(gy + r) * gs + gx + 8 * c8) = *reinterpret_cast<const u4 *>(&S->blkpix[po + r * N + 8 * c8]);
+        }
+      }
+    }
+    if constexpr (sizeof(PIX) == 1 && N >= 16) {   // 8-bit samples: 16 per 16-byte store
+      wide_out = uniform_i(!overhang && ((gs | gx) & 15) == 0);
+      if (wide_out) {
+        constexpr int CPR = N / 16;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = sl; q < N * CPR; q += G) {
+          const int r = q / CPR, c16 = q - r * CPR;
+          const u4 lo = *reinterpret_cast<const u4 *>(&S->blkpix[po + r * N + 16 * c16]), hi = *reinterpret_cast<const u4 *>(&S->blkpix[po + r * N + 16 * c16 + 8]);
+          u4 v;
+          v[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x06040200u); v[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x06040200u);
+          v[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x06040200u); v[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x06040200u);
+          *reinterpret_cast<u4 *>(pl + (size_t)(gy + r) * gs + gx + 16 * c16) = v;
         }
       }
     }
