@@ -41,7 +41,7 @@ hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void 
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
                                 const uint8_t *lr_choice, uint32_t *tile_order, int frame0, int count,
-                                hipStream_t s, hipEvent_t mid);
+                                hipStream_t s, hipEvent_t mid, hipStream_t aux, hipEvent_t fork, hipEvent_t join);
 hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, const uint16_t *dirtab, hipStream_t s);
 hipError_t av1mi_launch_cdef_dir(const Av1miDevParams *P, const void *rec, const Av1miBlkInfo *blk, uint16_t *dirtab, hipStream_t s);
 hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
@@ -408,7 +408,7 @@ struct av1mi_ctx {
   hipStream_t stream2 = nullptr;  // CDEF + SSE run here, beside the entropy kernels on `stream`
   hipStream_t stream3 = nullptr;  // inter chunks: entropy coding of finished groups of frames, beside the frame-by-frame chain
   hipStream_t stream4 = nullptr;  // all-key-frame chunks pipelined over groups: the groups' entropy coding alternates between stream3 and this one
-  hipEvent_t ev[12] = {};
+  hipEvent_t ev[14] = {};
   std::vector<hipEvent_t> me_ev;       // per frame: its motion search has finished (second stream -> main stream)
   std::vector<hipEvent_t> grp_ev;      // per group of frames of an inter chunk: reconstructed (main stream -> third stream)
   std::string err;
@@ -923,7 +923,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         HIPCHK(c, hipEventRecord(c->grp_ev[n_grp], s));
         HIPCHK(c, hipStreamWaitEvent(sg, c->grp_ev[n_grp], 0));
         HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
-                                       c->d_tile_off, (int)f0, (int)cnt, sg, nullptr));
+                                       c->d_tile_off, (int)f0, (int)cnt, sg, nullptr, nullptr, nullptr, nullptr));
         n_grp++;
         entropy_from = f0 + cnt;
       }
@@ -994,7 +994,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         HIPCHK(c, hipEventRecord(c->grp_ev[n_grp], s));
         HIPCHK(c, hipStreamWaitEvent(c->stream3, c->grp_ev[n_grp], 0));
         HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
-                                       c->d_tile_off, (int)(f + 1 - grp), (int)grp, c->stream3, nullptr));
+                                       c->d_tile_off, (int)(f + 1 - grp), (int)grp, c->stream3, nullptr, nullptr, nullptr, nullptr));
         n_grp++;
       }
     }
@@ -1011,7 +1011,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   hipStream_t s2 = getenv("AV1MI_SERIAL") ? c->stream : c->stream2;  // AV1MI_SERIAL: single-stream timing experiments
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
-                                 c->d_tile_off /* scratch until the packing kernels fill it */, (int)entropy_from, (int)(n_frames - entropy_from), s, c->ev[7]));
+                                 c->d_tile_off /* scratch until the packing kernels fill it */, (int)entropy_from, (int)(n_frames - entropy_from), s, c->ev[7],
+                                 c->stream4, c->ev[12], c->ev[13]));   // the frame-edge tiles' symbolize variant beside the regular one
   if (entropy_joined) HIPCHK(c, hipStreamWaitEvent(s, c->ev[10], 0));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   // (AV1MI_CDEF_SPLIT: the direction search as a kernel of its own beside symbolize - measured slower overall: it takes symbolize's slots)
