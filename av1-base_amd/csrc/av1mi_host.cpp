@@ -961,7 +961,11 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     // range-coded (third stream) as soon as its last frame is reconstructed (and, with restoration on, its unit choices are
     // known) while the chain reconstructs the following frames; only the last group's entropy coding is left after the chain.
     // (AV1MI_ENTROPY_GROUP=k: groups of k frames - tests force small groups on short chunks; 0 = no overlap)
-    uint32_t grp = n_frames <= 8 ? n_frames : ((n_frames + 5) / 6 < 8 ? 8 : (n_frames + 5) / 6);
+    // Group size: since the chain's kernels got short (walk 76, inter pass 38 us per 1080p frame) a range-coder launch beside them costs
+    // more than it hides - 60-frame chunks, groups of 10 / 20 / none: 5 320 / 5 450 / 5 530 frames/s for one chunk, 7 670 / 8 050 / 7 970
+    // with four in flight, 2 440 / 2 460 / 2 540 at the production point - so chunks of up to 64 frames code everything after the
+    // chain and longer ones in groups of 32.
+    uint32_t grp = n_frames <= 64 ? n_frames : 32;
     if (const char *eg = getenv("AV1MI_ENTROPY_GROUP")) { const int k = atoi(eg); grp = k > 0 ? (uint32_t)k : n_frames; }
     uint32_t n_grp = 0;
     for (uint32_t f = 0; f < n_frames; f++) {
