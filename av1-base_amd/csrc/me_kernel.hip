@@ -215,11 +215,26 @@ __global__ void __launch_bounds__(64) me64_reduce_kernel(Av1miDevParams P, const
 // loads in flight together.  Per candidate: horizontal pass, a lane = 8 consecutive outputs of a row from 16 window
 // samples read as two 16-byte words (64 multiply-adds per 2 LDS reads); vertical pass, a lane = n^2/64 consecutive
 // outputs of a column from its (n^2/64 + 7) intermediate values; SAD against the source block, wave sum.
-// The Hadamard transform runs as butterflies (24 additions per 8 values, rows through LDS, then columns): as a dense
-// product H X H^T it would be 2 x 512 multiply-adds per sub-block, and the matrix cores' integer path takes 8-bit operands
-// (the difference has 11 bits), so MFMA has nothing to offer here.
+// The Hadamard transform of 32x32 blocks (and of the quadrants of 64x64 ones) runs on the matrix cores straight from the vertical
+// pass's registers (refine_eval, measured against the butterflies with tools/mfma_satd_ab.hip); the smaller blocks' runs as
+// butterflies (24 additions per 8 values, rows through LDS, then columns).
 // Output: (SAD << 36) | (u16 mv.row << 16) | u16 mv.col per leaf, which is what the recon kernel reads.
 __constant__ int16_t c_subpel_me[2][16][8] = AV1_SUBPEL_FILTERS_INIT;
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+// 16 values of at most 15 bits + sign -> the byte fragments of their high bytes (v >> 8) and biased low bytes ((v & 255) - 128)
+__device__ __forceinline__ void satd_split16(const int *v, v4i_t &lo, v4i_t &hi) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const unsigned a = (unsigned)v[4 * i], b = (unsigned)v[4 * i + 1], c = (unsigned)v[4 * i + 2], d = (unsigned)v[4 * i + 3];
+    const unsigned ab = __builtin_amdgcn_perm(b, a, 0x05040100u);   // a.b0 a.b1 b.b0 b.b1
+    const unsigned cd = __builtin_amdgcn_perm(d, c, 0x05040100u);
+    lo[i] = (int)(__builtin_amdgcn_perm(cd, ab, 0x06040200u) ^ 0x80808080u);
+    hi[i] = (int)__builtin_amdgcn_perm(cd, ab, 0x07050301u);
+  }
+}
 
 __device__ __forceinline__ void hadamard8(int *v) {
   int t[8];
@@ -310,6 +325,7 @@ __device__ __forceinline__ void refine_eval(const Av1miDevParams &P, int x, int 
   __syncthreads();
   // vertical pass: lane = column c, rows r0 .. r0 + RPL - 1
   int sad = 0;
+  [[maybe_unused]] int dd[RPL];   // n = 32: the lane's 16 differences D[16h + j][c] - the first matrix product's A fragment
   {
     const int c = lane & (n - 1), r0 = (lane >> LOG2N) * RPL;
     int m[RPL + 7];
@@ -324,8 +340,51 @@ __device__ __forceinline__ void refine_eval(const Av1miDevParams &P, int x, int 
       v = v < 0 ? 0 : (v > maxv ? maxv : v);
       const int d = (int)srcb[(r0 + j) * n + c] - v;
       sad += iabs(d);
-      dif[(r0 + j) * n + c] = (int16_t)d;
+      if constexpr (LOG2N == 5) dd[j] = d;
+      else dif[(r0 + j) * n + c] = (int16_t)d;
     }
+  }
+  if constexpr (LOG2N == 5) {
+    // SATD on the matrix cores (tools/mfma_satd_ab.hip: 0.36 against 0.47 ns per candidate for the butterflies below, and no LDS
+    // round trip or barrier on a kernel that runs two waves per SIMD): Y = H' D^T H' with H' = I4 (x) H8, +-1 / 0 entries, the
+    // operands split into a signed high byte and a biased low byte - v = 256 (v >> 8) + ((v & 255) - 128) + 128, the + 128 being
+    // a constant matrix whose transform (1024 on the Hadamard index 0 of every sub-block) goes into the accumulators' start value.
+    // v_mfma_i32_32x32x32_i8: lane (r, h) holds A[r][16h + j], B[16h + j][r]; accumulator reg of lane (c, h) = row
+    // (reg & 3) + 8 (reg >> 2) + 4h, column c - so the first product's accumulators are the second's B fragment with k in that order.
+    const int c = lane & 31, h = lane >> 5;
+    v4i_t hb = {0, 0, 0, 0}, ha = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int k1 = 16 * h + j, k2 = (j & 3) + 8 * (j >> 2) + 4 * h;
+      const int e1 = (k1 >> 3) == (c >> 3) ? ((__builtin_popcount(k1 & c & 7) & 1) ? 0xFF : 0x01) : 0;
+      const int e2 = (k2 >> 3) == (c >> 3) ? ((__builtin_popcount(k2 & c & 7) & 1) ? 0xFF : 0x01) : 0;
+      hb[j >> 2] |= e1 << (8 * (j & 3));
+      ha[j >> 2] |= e2 << (8 * (j & 3));
+    }
+    const int bias1 = (c & 7) == 0 ? 1024 : 0, bias2 = h == 0 ? 1024 : 0;
+    v4i_t lo, hi;
+    satd_split16(dd, lo, hi);
+    v16i_t acc = {0};
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, hb, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = (acc[r] << 8) + bias1;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, hb, acc, 0, 0, 0);
+    int t[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) t[r] = acc[r];
+    satd_split16(t, lo, hi);
+    v16i_t acc2 = {0};
+    acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ha, hi, acc2, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc2[r] = (acc2[r] << 8) + ((r & 3) == 0 ? bias2 : 0);
+    acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ha, lo, acc2, 0, 0, 0);
+    int satd = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) satd += iabs(acc2[r]);
+    for (int o = 32; o > 0; o >>= 1) { sad += __shfl_xor(sad, o, 64); satd += __shfl_xor(satd, o, 64); }
+    __syncthreads();   // `mid` is rewritten by the next candidate's horizontal pass
+    sad_out = sad; satd_out = satd;
+    return;
   }
   __syncthreads();
   // SATD: 8x8 Hadamard of the difference, rows (8 values of a row of a sub-block per task, written back), then
