@@ -37,7 +37,7 @@ hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, co
 hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop, hipStream_t s);
 hipError_t av1mi_launch_deblock(const Av1miDevParams *P, void *rec, const Av1miBlkInfo *blk, hipStream_t s);
 hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice,
-                           unsigned long long *unit_sse, hipStream_t s);
+                           unsigned long long *unit_sse, int clear, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
                                 const uint8_t *lr_choice, uint32_t *tile_order, int frame0, int count,
@@ -894,7 +894,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     HIPCHK(c, launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
     if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
     HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, nullptr, s));
-    HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, c->d_lrsse, s));
+    HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, c->d_lrsse, 1, s));
   } else if (!inter_chunk) {
     // All-key-frame chunk: the frames are independent, so the chunk CAN run as a software pipeline over groups of frames
     // (AV1MI_INTRA_GROUPS=k) - the main stream reconstructs group g + 1 while auxiliary streams symbolize and range-code group
@@ -968,6 +968,10 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     uint32_t grp = n_frames <= 64 ? n_frames : 32;
     if (const char *eg = getenv("AV1MI_ENTROPY_GROUP")) { const int k = atoi(eg); grp = k > 0 ? (uint32_t)k : n_frames; }
     uint32_t n_grp = 0;
+    if (lr) {   // the restoration units' candidate sums of the whole chunk, cleared once (not a fill per frame on the chain)
+      const size_t upf = (size_t)((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
+      HIPCHK(c, hipMemsetAsync(c->d_lrsse, 0, (size_t)n_frames * upf * 8 * sizeof(unsigned long long), s));
+    }
     for (uint32_t f = 0; f < n_frames; f++) {
       const uint8_t *srcf = (const uint8_t *)d_src + f * fbytes;
       uint8_t *recf = (uint8_t *)c->d_rec + f * fbytes, *finf = (uint8_t *)c->d_fin + f * fbytes, *cdf_ = (uint8_t *)cdef_out + f * fbytes;
@@ -987,7 +991,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, nullptr, s));
       if (lr) {
         const int upf = ((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
-        HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, c->d_lrsse + (size_t)f * upf * 8, s));
+        HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, c->d_lrsse + (size_t)f * upf * 8, 0, s));
       }
       if ((f + 1) % grp == 0 && f + 1 < n_frames) {   // a full group that is not the last: hand it to the third stream
         if (c->grp_ev.size() <= n_grp) {

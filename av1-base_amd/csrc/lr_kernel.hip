@@ -335,13 +335,16 @@ void launch_lr_phases(const Av1miDevParams *P, int grid, const PIX *pre, const P
 
 }  // namespace
 
-// unit_sse: P->n_frames x units x 8 sums (scratch of the two phases; cleared here).
+// unit_sse: P->n_frames x units x 8 sums (scratch of the two phases; cleared here unless the caller did - the frame loop of a P chunk
+// clears the whole chunk's once instead of putting a fill between every frame's kernels on the chain).
 extern "C" hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void *cdef, const void *src, void *out, uint8_t *choice,
-                                      unsigned long long *unit_sse, hipStream_t stream) {
+                                      unsigned long long *unit_sse, int clear, hipStream_t stream) {
   const int urows = (P->true_h + 32) / 64 > 0 ? (P->true_h + 32) / 64 : 1, ucols = (P->true_w + 32) / 64 > 0 ? (P->true_w + 32) / 64 : 1;
   const int units = P->n_frames * urows * ucols, grid = units * LR_SLICES;
-  hipError_t e = hipMemsetAsync(unit_sse, 0, (size_t)units * 8 * sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
+  if (clear) {
+    hipError_t e = hipMemsetAsync(unit_sse, 0, (size_t)units * 8 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+  }
   // enable_lr = 2 (RESTORE_SWITCHABLE): the instantiation with the self-guided candidates (24 KB of LDS per wave)
   if (P->bit_depth == 8) {
     if (P->enable_lr == 2) launch_lr_phases<uint8_t, true>(P, grid, (const uint8_t *)pre, (const uint8_t *)cdef, (const uint8_t *)src, (uint8_t *)out, choice, unit_sse, stream);
