@@ -411,6 +411,7 @@ extern "C" int av1mi_plan_workers(uint32_t workers, int32_t gpu_mask, int n_devi
 }
 
 extern "C" void av1mi_host_release_streams(void);
+extern "C" void av1mi_host_release_buffers(void);
 extern "C" void av1mi_release_caches(void) {
   GlobalCache &g = cache();
   std::vector<std::pair<int, av1mi_ctx *>> cs;
@@ -424,6 +425,7 @@ extern "C" void av1mi_release_caches(void) {
   for (auto &e : cs) av1mi_ctx_destroy(e.second);
   for (auto &s : ss) if (s.p) { if (s.pinned) (void)hipHostFree(s.p); else free(s.p); }
   av1mi_host_release_streams();   // the stream sets destroyed contexts left in av1mi_host.cpp's pool
+  av1mi_host_release_buffers();   // and the page-locked bitstream blocks av1mi_free() put back
 }
 
 extern "C" int av1mi_probe_y4m(const char *path, av1mi_clip_info *info) {

@@ -746,7 +746,64 @@ void av1mi_ctx_destroy(av1mi_ctx *c) {
 
 const char *av1mi_last_error(const av1mi_ctx *c) { return c ? c->err.c_str() : "no context"; }
 
-void av1mi_free(void *p) { free(p); }
+// Bitstream buffers handed to the caller (av1mi_buf.data) are page-locked blocks from a process-wide pool: the packed chunk is
+// copied device -> host straight into the block the caller gets, and av1mi_free() puts the block back for the next chunk - no
+// staging copy and no first-touch page faults on a fresh malloc per chunk (2.35 MB per 1080p all-key-frame chunk, 23 MB at the
+// production point: 0.2 / 1.1 ms of host time per chunk before).  Blocks that do not come from the pool are plain malloc.
+namespace {
+std::mutex g_pin_mu;
+std::vector<std::pair<void *, size_t>> g_pin_out;    // handed out: (block, capacity)
+std::vector<std::pair<void *, size_t>> g_pin_free;   // waiting for the next chunk
+constexpr size_t PIN_FREE_MAX_BLOCKS = 16, PIN_FREE_MAX_BYTES = (size_t)1 << 30;
+
+void *pin_acquire(size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pin_free.size(); i++)
+      if (g_pin_free[i].second >= bytes && (best < 0 || g_pin_free[i].second < g_pin_free[(size_t)best].second)) best = (int)i;
+    if (best >= 0) {
+      const std::pair<void *, size_t> b = g_pin_free[(size_t)best];
+      g_pin_free.erase(g_pin_free.begin() + best);
+      g_pin_out.push_back(b);
+      return b.first;
+    }
+  }
+  void *p = nullptr;
+  const size_t cap = bytes + (bytes >> 2) + 4096;
+  if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pin_out.emplace_back(p, cap);
+  return p;
+}
+}  // namespace
+
+extern "C" void av1mi_host_release_buffers(void) {
+  std::vector<std::pair<void *, size_t>> all;
+  { std::lock_guard<std::mutex> lk(g_pin_mu); all.swap(g_pin_free); }
+  for (auto &b : all) (void)hipHostFree(b.first);
+}
+
+void av1mi_free(void *p) {
+  if (!p) return;
+  bool pooled = false, drop = false;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pin_out.size(); i++)
+      if (g_pin_out[i].first == p) {
+        const std::pair<void *, size_t> b = g_pin_out[i];
+        g_pin_out.erase(g_pin_out.begin() + (long)i);
+        size_t held = 0;
+        for (auto &f : g_pin_free) held += f.second;
+        if (g_pin_free.size() < PIN_FREE_MAX_BLOCKS && held + b.second <= PIN_FREE_MAX_BYTES) g_pin_free.push_back(b);
+        else drop = true;
+        pooled = true;
+        break;
+      }
+  }
+  if (!pooled) free(p);
+  else if (drop) (void)hipHostFree(p);
+}
 
 // Scene-cut rule (include/av1mi.h: av1mi_scene_cuts).  Integer only: d = mean absolute luma difference at 8-bit
 // scale in Q8.  Mirrored by oracle/scenecut.py.
@@ -1056,14 +1113,20 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   }
   const size_t total = (size_t)foff[n_frames];
   if (total > c->out_cap) { (void)hipStreamSynchronize(s2); set_err(c, "internal: packed size exceeds buffer"); return AV1MI_E_OVERFLOW; }
-  uint8_t *host = (uint8_t *)malloc(total ? total : 1);
-  if (!host) { (void)hipStreamSynchronize(s2); return AV1MI_E_OOM; }
-  if (c->h_out_cap < total) {
-    if (c->h_out) (void)hipHostFree(c->h_out);
-    c->h_out = nullptr; c->h_out_cap = 0;
-    if (hipHostMalloc((void **)&c->h_out, total + (total >> 2) + 4096, hipHostMallocDefault) == hipSuccess) c->h_out_cap = total + (total >> 2) + 4096;
+  // the caller's buffer: a page-locked block of the pool (the copy lands in it directly); plain memory + this context's staging
+  // buffer only if page-locked memory cannot be had
+  uint8_t *host = (uint8_t *)pin_acquire(total ? total : 1);
+  const bool direct = host != nullptr;
+  if (!direct) {
+    host = (uint8_t *)malloc(total ? total : 1);
+    if (!host) { (void)hipStreamSynchronize(s2); return AV1MI_E_OOM; }
+    if (c->h_out_cap < total) {
+      if (c->h_out) (void)hipHostFree(c->h_out);
+      c->h_out = nullptr; c->h_out_cap = 0;
+      if (hipHostMalloc((void **)&c->h_out, total + (total >> 2) + 4096, hipHostMallocDefault) == hipSuccess) c->h_out_cap = total + (total >> 2) + 4096;
+    }
   }
-  uint8_t *dst = c->h_out ? c->h_out : host;
+  uint8_t *dst = direct ? host : (c->h_out ? c->h_out : host);
   hipError_t e1 = hipMemcpyAsync(dst, c->d_out, total, hipMemcpyDeviceToHost, s);
   hipError_t e2 = hipEventRecord(c->ev[6], s);
   if (e2 == hipSuccess) e2 = hipStreamWaitEvent(s, c->ev[9], 0);  // join: the final reconstruction and the SSE come from the second stream
@@ -1088,7 +1151,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
   if (e1 != hipSuccess || e2 != hipSuccess) {
     (void)hipStreamSynchronize(s2);
-    free(host);
+    av1mi_free(host);
     set_err(c, "device-to-host copy failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return AV1MI_E_HIP;
   }

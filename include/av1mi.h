@@ -88,7 +88,7 @@ typedef struct {
 } av1mi_params;
 
 typedef struct {
-  uint8_t *data;            /* malloc'ed by the library; release with av1mi_free() */
+  uint8_t *data;            /* owned by the library (a page-locked block of its pool, or malloc); release with av1mi_free() ONLY */
   size_t size;
 } av1mi_buf;
 
