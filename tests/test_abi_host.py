@@ -34,6 +34,15 @@ def test_exports_every_declared_symbol(av1mi):
     assert av1mi._lib.av1mi_abi_version() == 5
 
 
+def test_free_takes_null_and_plain_heap_blocks(av1mi):
+    """av1mi_free: NULL is a no-op; a block that is not one of the pool's page-locked ones goes to free()."""
+    av1mi._lib.av1mi_free(None)
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    av1mi._lib.av1mi_free(libc.malloc(4096))
+
+
 def test_cq_mapping_matches_aom_table(av1mi):
     assert av1mi.cq_to_qindex(30) == 120     # SURVEY.md §8d: CQ 30 <-> base_q_idx 120
     assert av1mi.cq_to_qindex(0) == 0 and av1mi.cq_to_qindex(63) == 255

@@ -157,6 +157,39 @@ def test_device_resident_input_matches_host_input(av1mi, ctx, oracle):
     assert a == b
 
 
+def test_output_blocks_are_recycled_and_bitstreams_stay_exact(av1mi, ctx, oracle):
+    """av1mi_buf.data is a page-locked block of the library's pool (the device -> host copy lands in it directly); av1mi_free() puts
+    it back and the next chunk gets the same block.  Two buffers held at once are distinct, a smaller chunk after a larger one
+    fits the recycled block, and every bitstream equals the oracle's."""
+    import ctypes as C
+    w, h, bd = 200, 120, 8
+    cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5)
+    frames = [oracle.synthclip_frame(w, h, bd, seed=9, t=t) for t in range(3)]
+    want = [oracle.encode_frame(cfg, f)[0] for f in frames]
+    p = av1mi.default_params(w, h, bd)
+
+    def raw_call(n):
+        out, sizes, rep = av1mi.Buf(), (C.c_uint32 * n)(), av1mi.Report()
+        raw = np.frombuffer(b"".join(raw_of(f, bd) for f in frames[:n]), dtype=np.uint8)
+        rc = av1mi._lib.av1mi_encode_chunk(ctx._h, C.byref(p), raw.ctypes.data_as(C.c_void_p), n, 0, C.byref(out), sizes, None, C.byref(rep))
+        assert rc == 0
+        return out
+
+    av1mi._lib.av1mi_release_caches()                 # blocks earlier tests put back: the pool starts empty
+    a = raw_call(3)
+    b = raw_call(3)                                   # a is still held: b must be another block
+    pa, pb = C.cast(a.data, C.c_void_p).value, C.cast(b.data, C.c_void_p).value
+    assert pa != pb
+    assert C.string_at(a.data, a.size) == b"".join(want) == C.string_at(b.data, b.size)
+    av1mi._lib.av1mi_free(a.data)
+    av1mi._lib.av1mi_free(b.data)
+    c = raw_call(1)                                   # smaller chunk: one of the two blocks comes back
+    pc = C.cast(c.data, C.c_void_p).value
+    assert pc in (pa, pb)
+    assert C.string_at(c.data, c.size) == want[0]
+    av1mi._lib.av1mi_free(c.data)
+
+
 def test_encode_file_y4m_to_ivf(av1mi, oracle, tmp_path):
     """The run_av1an drop-in: Y4M in, IVF out (atomic), frames in order across chunk boundaries."""
     w, h, n = 136, 72, 7
