@@ -40,7 +40,7 @@ hipError_t av1mi_launch_lr(const Av1miDevParams *P, const void *pre, const void 
                            unsigned long long *unit_sse, int clear, hipStream_t s);
 hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_init, const int16_t *levels, const Av1miBlkInfo *blk,
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
-                                const uint8_t *lr_choice, uint32_t *tile_order, int frame0, int count,
+                                const uint8_t *lr_choice, uint32_t *tile_order, int frame0, int count, int phase,
                                 hipStream_t s, hipEvent_t mid, hipStream_t aux, hipEvent_t fork, hipEvent_t join);
 hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, const uint16_t *dirtab, hipStream_t s);
 hipError_t av1mi_launch_cdef_dir(const Av1miDevParams *P, const void *rec, const Av1miBlkInfo *blk, uint16_t *dirtab, hipStream_t s);
@@ -944,6 +944,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   auto launch_recon = P.max_bs_log2 >= 6 ? av1mi_launch_recon64 : av1mi_launch_recon;
   const bool lr = P.enable_lr != 0;
   uint32_t entropy_from = 0;      // inter chunks: frames before this one are entropy-coded on the third stream, beside the chain
+  bool sym_groups = false;        // ... or only symbolized there (AV1MI_SYM_GROUP)
   bool entropy_joined = false;
   void *cdef_out = lr ? c->d_cd : c->d_fin;   // with loop restoration CDEF writes d_cd and the restored frame goes to d_fin
   if (!inter_chunk && lr) {
@@ -980,7 +981,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         HIPCHK(c, hipEventRecord(c->grp_ev[n_grp], s));
         HIPCHK(c, hipStreamWaitEvent(sg, c->grp_ev[n_grp], 0));
         HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
-                                       c->d_tile_off, (int)f0, (int)cnt, sg, nullptr, nullptr, nullptr, nullptr));
+                                       c->d_tile_off, (int)f0, (int)cnt, 3, sg, nullptr, nullptr, nullptr, nullptr));
         n_grp++;
         entropy_from = f0 + cnt;
       }
@@ -1024,6 +1025,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     // chain and longer ones in groups of 32.
     uint32_t grp = n_frames <= 64 ? n_frames : 32;
     if (const char *eg = getenv("AV1MI_ENTROPY_GROUP")) { const int k = atoi(eg); grp = k > 0 ? (uint32_t)k : n_frames; }
+    // AV1MI_SYM_GROUP=k: groups of k frames are only SYMBOLIZED beside the chain; one range-coder launch for the whole chunk follows it
+    if (const char *eg = getenv("AV1MI_SYM_GROUP")) { const int k = atoi(eg); if (k > 0) { grp = (uint32_t)k; sym_groups = true; } }
     uint32_t n_grp = 0;
     if (lr) {   // the restoration units' candidate sums of the whole chunk, cleared once (not a fill per frame on the chain)
       const size_t upf = (size_t)((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
@@ -1059,7 +1062,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
         HIPCHK(c, hipEventRecord(c->grp_ev[n_grp], s));
         HIPCHK(c, hipStreamWaitEvent(c->stream3, c->grp_ev[n_grp], 0));
         HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
-                                       c->d_tile_off, (int)(f + 1 - grp), (int)grp, c->stream3, nullptr, nullptr, nullptr, nullptr));
+                                       c->d_tile_off, (int)(f + 1 - grp), (int)grp, sym_groups ? 1 : 3, c->stream3, nullptr, nullptr, nullptr, nullptr));
         n_grp++;
       }
     }
@@ -1076,9 +1079,13 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   hipStream_t s2 = getenv("AV1MI_SERIAL") ? c->stream : c->stream2;  // AV1MI_SERIAL: single-stream timing experiments
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
-                                 c->d_tile_off /* scratch until the packing kernels fill it */, (int)entropy_from, (int)(n_frames - entropy_from), s, c->ev[7],
+                                 c->d_tile_off /* scratch until the packing kernels fill it */, (int)entropy_from, (int)(n_frames - entropy_from),
+                                 sym_groups && entropy_joined ? 1 : 3, s, c->ev[7],
                                  c->stream4, c->ev[12], c->ev[13]));   // the frame-edge tiles' symbolize variant beside the regular one
   if (entropy_joined) HIPCHK(c, hipStreamWaitEvent(s, c->ev[10], 0));
+  if (sym_groups && entropy_joined)   // every frame is symbolized: one range-coder launch for the whole chunk
+    HIPCHK(c, av1mi_launch_entropy(&P, c->d_cdf, c->d_levels, c->d_blk, c->d_streams, c->d_sym, c->d_combos, c->d_slots, c->d_tile_bytes, c->d_lrc,
+                                   c->d_tile_off, 0, (int)n_frames, 2, s, nullptr, nullptr, nullptr, nullptr));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   // (AV1MI_CDEF_SPLIT: the direction search as a kernel of its own beside symbolize - measured slower overall: it takes symbolize's slots)
   const bool split_cdef = !inter_chunk && !lr && P.enable_cdef && getenv("AV1MI_CDEF_SPLIT");

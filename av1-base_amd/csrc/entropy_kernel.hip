@@ -1013,6 +1013,7 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
                                            const Av1miBlkInfo *blk, uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos,
                                            uint8_t *slots, uint32_t *tile_bytes, const uint8_t *lr_choice, uint32_t *tile_order /* n_tiles entries of scratch */,
                                            int frame0, int count /* frames [frame0, frame0 + count) of the chunk: all arrays are chunk-wide */,
+                                           int phase /* bit 0: symbolize, bit 1: range-code (3 = both; the two may be given different frame ranges in two calls) */,
                                            hipStream_t stream, hipEvent_t mid,
                                            hipStream_t aux, hipEvent_t fork, hipEvent_t join /* aux != nullptr: the frame-edge tiles' variant runs there, beside the regular one */) {
   const int tpf = P->tile_rows * P->tile_cols;
@@ -1023,6 +1024,7 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   // with a long serial chain each - 0.14 ms per 60-frame chunk when it ran after the regular one; on a stream of its own it runs
   // beside it.
   hipStream_t fs = stream;
+  if (!(phase & 1)) aux = nullptr;
   if (aux) {
     (void)hipEventRecord(fork, stream);
     (void)hipStreamWaitEvent(aux, fork, 0);
@@ -1031,7 +1033,8 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
 #define SYM_LAUNCH(FULLV, INTERV, TSBV)                                                                                                   \
   hipLaunchKernelGGL((symbolize_tile_kernel<FULLV, INTERV, TSBV>), dim3(n_tiles), dim3(64), 0, (FULLV) ? fs : stream, *P, cdf_init, levels, blk, streams, \
                      stream_len, tile_combos, lr_choice, tile0)
-  if (P->tile_sb == 1) {
+  if (!(phase & 1)) {
+  } else if (P->tile_sb == 1) {
     if (has_key) { SYM_LAUNCH(false, false, 1); SYM_LAUNCH(true, false, 1); }
     if (has_inter) { SYM_LAUNCH(false, true, 1); SYM_LAUNCH(true, true, 1); }
   } else {
@@ -1044,6 +1047,7 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
     (void)hipStreamWaitEvent(stream, join, 0);
   }
   if (mid) (void)hipEventRecord(mid, stream);
+  if (!(phase & 2)) return hipGetLastError();
   // The range coder holds 2 workgroups (of 64 tiles) per CU.  Up to that many workgroups all run at once and the kernel lasts
   // as long as its longest tile: the natural order is best (a workgroup of 64 long tiles would be slower per symbol than
   // one long tile among short ones - measured 1.1 -> 2.1 ms).  Beyond it the workgroups run in rounds, and what counts is

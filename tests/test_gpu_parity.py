@@ -342,12 +342,15 @@ def test_entropy_coding_in_groups_beside_the_chain(av1mi, oracle, monkeypatch, w
     keyint = extra.pop("keyint", 240)
     p = av1mi.default_params(w, h, bd, keyint=keyint, **extra)
     outs = []
-    for g in (group, 0):
-        monkeypatch.setenv("AV1MI_ENTROPY_GROUP", str(g))
+    for env in ({"AV1MI_ENTROPY_GROUP": str(group)}, {"AV1MI_ENTROPY_GROUP": "0"}, {"AV1MI_SYM_GROUP": str(group)}):   # the last: groups symbolized
+        for k in ("AV1MI_ENTROPY_GROUP", "AV1MI_SYM_GROUP"):                                                          # beside the chain, one range-coder
+            monkeypatch.delenv(k, raising=False)                                                                       # launch for the chunk after it
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         with av1mi.Context(0) as c:
             data, sizes, rep, recon = c.encode_chunk(p, raw, n, want_recon=True)
         outs.append((data, list(sizes), recon.tobytes()))
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
     cfg = oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5, enable_lr=extra.get("enable_lr", 0), deblock=extra.get("deblock", 0), subpel=extra.get("subpel", 0))
     tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
     assert outs[0][0] == b"".join(tus) and outs[0][2] == b"".join(raw_of(r, bd) for r in recs)
