@@ -76,9 +76,15 @@ int y4m_open(const char *path, Y4m *y) {
     const long pos = ftell(y->f);
     struct stat sb;
     if (pos >= 0 && fstat(fileno(y->f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > pos) {
-      y->total_frames = (uint64_t)(sb.st_size - pos) / (6 + y->frame_bytes);
-      y->data_off = pos;
-      y->regular = true;
+      // the parallel reader knows where every frame starts only if the markers are the plain six bytes; a clip whose first marker
+      // carries frame parameters ("FRAME Ixx\n") goes through the sequential reader, frame count unknown
+      char mark[6];
+      const bool plain = pread(fileno(y->f), mark, 6, (off_t)pos) == 6 && memcmp(mark, "FRAME\n", 6) == 0;
+      if (plain) {
+        y->total_frames = (uint64_t)(sb.st_size - pos) / (6 + y->frame_bytes);
+        y->data_off = pos;
+        y->regular = true;
+      }
     }
   }
   return 0;
@@ -238,7 +244,9 @@ struct PinnedPool {
   std::mutex mu;
   std::condition_variable cv;
   int device = 0;
-  bool pinned_ok = true;   // falls back to plain memory if the runtime refuses to pin (the encode still works, only slower)
+  // Page-locked bytes this job may hold (AV1MI_PIN_BUDGET_MB, default 24 GiB - what the process-wide cache keeps anyway): slots
+  // beyond it, and slots the runtime refuses to pin, are plain memory (the encode still works, their upload is staged by the runtime)
+  size_t pin_budget = (size_t)24 << 30, pinned_bytes = 0;
   void init(int n, int dev);   // takes idle buffers from the process-wide cache
   void retire();               // gives them back
   Slot *acquire(size_t bytes) {
@@ -250,8 +258,13 @@ struct PinnedPool {
     if (s->cap < bytes) {
       release_mem(s);
       const size_t want = bytes + (bytes >> 3);
-      s->pinned = pinned_ok && hipSetDevice(device) == hipSuccess && hipHostMalloc((void **)&s->p, want, hipHostMallocPortable) == hipSuccess;
-      if (!s->pinned) { pinned_ok = false; s->p = (uint8_t *)malloc(want); }
+      bool may_pin;
+      { std::lock_guard<std::mutex> lk2(mu); may_pin = pinned_bytes + want <= pin_budget; if (may_pin) pinned_bytes += want; }
+      s->pinned = may_pin && hipSetDevice(device) == hipSuccess && hipHostMalloc((void **)&s->p, want, hipHostMallocPortable) == hipSuccess;
+      if (!s->pinned) {
+        if (may_pin) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk2(mu); pinned_bytes -= want; }
+        s->p = (uint8_t *)malloc(want);
+      }
       s->cap = s->p ? want : 0;
     }
     return s;
@@ -262,7 +275,7 @@ struct PinnedPool {
   }
   void release_mem(Slot *s) {
     if (!s->p) return;
-    if (s->pinned) (void)hipHostFree(s->p); else free(s->p);
+    if (s->pinned) { (void)hipHostFree(s->p); std::lock_guard<std::mutex> lk2(mu); pinned_bytes -= s->cap < pinned_bytes ? s->cap : pinned_bytes; } else free(s->p);
     s->p = nullptr; s->cap = 0; s->pinned = false;
   }
   ~PinnedPool() { retire(); }
@@ -293,8 +306,10 @@ void PinnedPool::init(int n, int dev) {
     s = g.slots.back();
     s.busy = false;
     g.slot_bytes -= s.cap;
+    if (s.pinned) pinned_bytes += s.cap;
     g.slots.pop_back();
   }
+  if (const char *e = getenv("AV1MI_PIN_BUDGET_MB")) { const long mb = atol(e); if (mb >= 0) pin_budget = (size_t)mb << 20; }
 }
 void PinnedPool::retire() {
   GlobalCache &g = cache();
@@ -311,6 +326,8 @@ void PinnedPool::retire() {
   slots.clear();
 }
 
+extern "C" void av1mi_host_ctx_recycle(av1mi_ctx *c);
+extern "C" void av1mi_host_expect_blocks(unsigned n);
 int take_ctx(int dev, av1mi_ctx **out) {
   {
     GlobalCache &g = cache();
@@ -322,6 +339,7 @@ int take_ctx(int dev, av1mi_ctx **out) {
 }
 void give_ctx(int dev, av1mi_ctx *c) {
   if (!c) return;
+  av1mi_host_ctx_recycle(c);
   GlobalCache &g = cache();
   {
     std::lock_guard<std::mutex> lk(g.mu);
@@ -492,6 +510,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   // pinned staging: one slot being filled by the reader, one waiting, one per worker being uploaded / encoded
   PinnedPool pool;
   pool.init((int)workers + 2, dev_of[0]);
+  av1mi_host_expect_blocks(2 * workers + 2);   // finished chunks waiting for the writer keep their page-locked output blocks
   int hc = 0;
   { cpu_set_t cs; if (sched_getaffinity(0, sizeof(cs), &cs) == 0) hc = CPU_COUNT(&cs); }   // the cores this process may use, not the host's
   if (hc <= 0) hc = (int)std::thread::hardware_concurrency();

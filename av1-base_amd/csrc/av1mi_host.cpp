@@ -508,8 +508,6 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     // on the context's own stream: hipMemset would run on the null stream, which a non-blocking stream does not wait
     // for - the fill could land after the first reconstruction kernel had written its block info
     HIPCHK(c, hipMemsetAsync(c->d_blk, 0, nf * nb8 * sizeof(Av1miBlkInfo), c->stream));
-    // (the range coder forms an entry's byte offset in 32 bits: slots of a chunk stay below 4 GB - 2 000 frames of 1080p)
-    if (nf * ntile * (size_t)slot * 2 >= ((size_t)1 << 32)) { set_err(c, "chunk too long: %zu frames need %zu bytes of bitstream slots (limit 4 GB)", nf, nf * ntile * (size_t)slot * 2); return AV1MI_E_UNSUPPORTED; }
     HIPCHK(c, hipMalloc((void **)&c->d_slots, nf * ntile * slot * 2));  // 16-bit pre-carry entries, one per output byte
     c->out_cap = nf * (ntile * (size_t)(slot + 4) + 256);
     HIPCHK(c, hipMalloc((void **)&c->d_out, c->out_cap));
@@ -539,7 +537,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     const size_t nc = 2 * (size_t)(p.me_range ? p.me_range : 8) + 1, need = c->cap_frames * nsb * nc * nc * sizeof(uint32_t);
     if (c->me64_bytes < need) {
       if (c->d_me64) (void)hipFree(c->d_me64);
-      c->d_me64 = nullptr; c->me64_bytes = 0; c->d_cdefdir = nullptr;
+      c->d_me64 = nullptr; c->me64_bytes = 0;
       HIPCHK(c, hipMalloc((void **)&c->d_me64, need));
       c->me64_bytes = need;
     }
@@ -674,6 +672,8 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
   av1mi_ctx *c = new (std::nothrow) av1mi_ctx();
   if (!c) return AV1MI_E_OOM;
   c->device = device_id;
+  // test hook: start at a capacity multiplier content would otherwise have to provoke (tests/test_gpu_parity.py: slots beyond 4 GB)
+  if (const char *e = getenv("AV1MI_CAP_SCALE")) { const int k = atoi(e); if (k >= 1 && k <= 64 && (k & (k - 1)) == 0) c->cap_scale = k; }
   // the main stream carries the serial chain of a chunk (and the latency-bound range coder): highest priority, so that
   // the bulk work put beside it on the second stream (CDEF, SSE, the chunk-wide motion search) fills gaps instead of
   // taking its slots
@@ -714,6 +714,8 @@ int av1mi_ctx_create(int device_id, av1mi_ctx **out) {
       hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
     delete c;
     return AV1MI_E_NO_DEVICE;
   }
@@ -744,6 +746,10 @@ void av1mi_ctx_destroy(av1mi_ctx *c) {
   delete c;
 }
 
+// A context that goes back to av1mi_encode_file's cache forgets the capacity multiplier its last job's content raised (it would
+// otherwise size - or, at the limit, refuse - an unrelated job's workspace by it); the next chunk reallocates at scale 1.
+void av1mi_host_ctx_recycle(av1mi_ctx *c) { if (c) c->cap_scale = 1; }
+
 const char *av1mi_last_error(const av1mi_ctx *c) { return c ? c->err.c_str() : "no context"; }
 
 // Bitstream buffers handed to the caller (av1mi_buf.data) are page-locked blocks from a process-wide pool: the packed chunk is
@@ -754,7 +760,10 @@ namespace {
 std::mutex g_pin_mu;
 std::vector<std::pair<void *, size_t>> g_pin_out;    // handed out: (block, capacity)
 std::vector<std::pair<void *, size_t>> g_pin_free;   // waiting for the next chunk
-constexpr size_t PIN_FREE_MAX_BLOCKS = 16, PIN_FREE_MAX_BYTES = (size_t)1 << 30;
+constexpr size_t PIN_FREE_MAX_BYTES = (size_t)1 << 30;
+// parked blocks: a job with w workers has up to 2 w finished chunks waiting for the writer, so the bound follows the largest worker
+// count seen (av1mi_host_expect_blocks) - freeing a block is hipHostFree, which synchronises the whole device
+std::atomic<size_t> g_pin_free_max_blocks{16};
 
 void *pin_acquire(size_t bytes) {
   {
@@ -778,6 +787,11 @@ void *pin_acquire(size_t bytes) {
 }
 }  // namespace
 
+extern "C" void av1mi_host_expect_blocks(unsigned n) {
+  size_t cur = g_pin_free_max_blocks.load();
+  while (n > cur && n <= 256 && !g_pin_free_max_blocks.compare_exchange_weak(cur, n)) { }
+}
+
 extern "C" void av1mi_host_release_buffers(void) {
   std::vector<std::pair<void *, size_t>> all;
   { std::lock_guard<std::mutex> lk(g_pin_mu); all.swap(g_pin_free); }
@@ -795,7 +809,7 @@ void av1mi_free(void *p) {
         g_pin_out.erase(g_pin_out.begin() + (long)i);
         size_t held = 0;
         for (auto &f : g_pin_free) held += f.second;
-        if (g_pin_free.size() < PIN_FREE_MAX_BLOCKS && held + b.second <= PIN_FREE_MAX_BYTES) g_pin_free.push_back(b);
+        if (g_pin_free.size() < g_pin_free_max_blocks.load() && held + b.second <= PIN_FREE_MAX_BYTES) g_pin_free.push_back(b);
         else drop = true;
         pooled = true;
         break;
@@ -1088,7 +1102,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
                                    c->d_tile_off, 0, (int)n_frames, 2, s, nullptr, nullptr, nullptr, nullptr));
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   // (AV1MI_CDEF_SPLIT: the direction search as a kernel of its own beside symbolize - measured slower overall: it takes symbolize's slots)
-  const bool split_cdef = !inter_chunk && !lr && P.enable_cdef && getenv("AV1MI_CDEF_SPLIT");
+  const bool split_cdef = !inter_chunk && !lr && P.enable_cdef && c->d_cdefdir && getenv("AV1MI_CDEF_SPLIT");
   if (!inter_chunk && !lr) {  // deblocking and CDEF's direction search read only the reconstruction and block info: beside symbolize
     HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));
     if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s2));

@@ -859,16 +859,14 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
   // has to be added to the bytes before it (od_ec's precarry buffer).  Nothing already written is ever touched here;
   // pack_tiles_kernel resolves the carries of a whole tile with a wave-parallel carry-lookahead when it copies the
   // tile to its final place.  This keeps the serial chain per symbol short: the kernel lasts as long as its longest tile.
-  // (the byte offset of an entry is formed in 32 bits - the host refuses chunks whose slots exceed 4 GB - so the store takes its
-  // address as scalar base + vector offset; an entry beyond the slot's capacity goes to the last one: the overflow is reported
-  // through tile_bytes, what the slot then holds does not matter)
-  char *const out_base = reinterpret_cast<char *>(slots);
-  const uint32_t out_tile = (uint32_t)(live ? tile : 0) * (uint32_t)P.tile_slot_bytes;
+  // (the tile's slot is a per-lane 64-bit base - chunks whose slots exceed 4 GB are legal: 4K x 140 frames at capacity scale 2 -
+  // and the entry's position inside it a 32-bit offset, one v_lshl_add_u64 per store; an entry beyond the slot's capacity goes to
+  // the last one: the overflow is reported through tile_bytes, what the slot then holds does not matter)
+  uint16_t *const out_tile = reinterpret_cast<uint16_t *>(slots) + (size_t)(live ? tile : 0) * (size_t)P.tile_slot_bytes;
   const int out_cap = P.tile_slot_bytes;  // entries
 #define PUT(pos_, v_)                                                                                                    \
   do {                                                                                                                   \
-    const uint32_t ix_ = out_tile + (uint32_t)((pos_) < out_cap ? (pos_) : out_cap - 1);                                 \
-    *reinterpret_cast<uint16_t *>(out_base + ix_ * 2u) = (uint16_t)((v_) & 0x1FFu);                                      \
+    out_tile[(uint32_t)((pos_) < out_cap ? (pos_) : out_cap - 1)] = (uint16_t)((v_) & 0x1FFu);                           \
   } while (0)
 #define EMIT(v_) do { PUT(out_pos, v_); out_pos++; } while (0)
 

@@ -273,6 +273,30 @@ def test_stress_carries_and_long_tiles(av1mi, ctx, oracle):
             assert rep.max_tile_symbols > 16384 and rep.cap_scale > 1
 
 
+def test_bitstream_slots_beyond_4_gb(av1mi, monkeypatch):
+    """A long chunk at a raised capacity multiplier has more than 4 GB of per-tile bitstream slots (1080p: 510 tiles x 4096 x scale
+    entries x 2 bytes per frame - 136 frames at scale 8): the range coder addresses a tile's slot with a 64-bit base, so such a chunk
+    encodes, and to the same bytes as at scale 1.  (AV1MI_CAP_SCALE is the context's starting multiplier: what content that
+    overflows the x1 capacities - test_stress_carries_and_long_tiles - raises it to.)"""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    w, h, n = 1920, 1080, 136
+    base = bench.make_clip_torch(w, h, 8, 8, 77, torch.device("cuda", 0))   # 8 distinct frames, repeated
+    clip = base.repeat(n // 8, 1).contiguous()
+    torch.cuda.synchronize()
+    p = av1mi.default_params(w, h, 8)
+    with av1mi.Context(0) as c1:
+        d1, s1, r1, _ = c1.encode_chunk(p, clip.data_ptr(), n, on_device=True)
+    monkeypatch.setenv("AV1MI_CAP_SCALE", "8")
+    with av1mi.Context(0) as c8:
+        d8, s8, r8, _ = c8.encode_chunk(p, clip.data_ptr(), n, on_device=True)
+    assert r1.cap_scale == 1 and r8.cap_scale == 8
+    assert n * 510 * 4096 * 8 * 2 > 1 << 32
+    assert list(s1) == list(s8) and d1 == d8
+
+
 def test_film_grain_table_in_frame_headers(av1mi, ctx, oracle):
     """`film_grain = N` (the reference's `--film-grain N`, av1an.rs:14): every frame header carries a
     film-grain table with its own grain_seed; tile data and reconstruction are untouched.  Bit-exact

@@ -51,8 +51,20 @@ def _worker(rank, world, port, n_chunks, q):
     dist.destroy_process_group()
 
 
+def _product_library_or_skip():
+    """the ranks ask libav1mi for the placement: without the built library (or a HIP runtime to dlopen it against) there is
+    nothing to test here - skip in the parent instead of letting a rank die before it reports"""
+    import pytest
+    sys.path.insert(0, os.path.join(ROOT, "av1-base_amd"))
+    try:
+        import av1mi  # noqa: F401
+    except (ImportError, OSError) as e:
+        pytest.skip("libav1mi.so not loadable here: %s" % e)
+
+
 def test_two_rank_chunk_sharding():
     import multiprocessing as mp
+    _product_library_or_skip()
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import av1o
     ctx = mp.get_context("spawn")
@@ -79,7 +91,7 @@ def test_two_rank_chunk_sharding():
 
 def test_worker_placement_rule():
     """av1mi_plan_workers / av1mi_chunk_owner (include/av1mi.h): what av1mi_encode_file builds its contexts from."""
-    sys.path.insert(0, os.path.join(ROOT, "av1-base_amd"))
+    _product_library_or_skip()
     import av1mi
     assert av1mi.plan_workers(0, 0, 8) == [d for _ in range(4) for d in range(8)]          # default: 4 chunks in flight per GPU
     assert av1mi.plan_workers(8, 0, 8) == list(range(8))                                   # the reference's `--workers 8`
