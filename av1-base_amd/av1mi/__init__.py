@@ -36,13 +36,14 @@ E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_OOM, E_OVERFLOW, E_FORMAT, E_UNSUPPORTED = 
 
 # every symbol include/av1mi.h declares
 ABI_SYMBOLS = ["av1mi_default_params", "av1mi_ctx_create", "av1mi_ctx_destroy", "av1mi_last_error", "av1mi_encode_chunk",
-               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute", "av1mi_probe_y4m", "av1mi_chunk_owner", "av1mi_plan_workers", "av1mi_release_caches"]
+               "av1mi_free", "av1mi_encode_file", "av1mi_cq_to_qindex", "av1mi_abi_version", "av1mi_write_headers", "av1mi_scene_cuts", "av1mi_job_execute", "av1mi_probe_y4m", "av1mi_chunk_owner", "av1mi_plan_workers", "av1mi_release_caches", "av1mi_struct_sizes"]
 
 
 class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "bit_depth", "cq_level", "keyint", "block_log2", "cdf_update",
                                           "enable_cdef", "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec",
-                                          "cdef_damping")] + [("intra_mode_mask", C.c_uint32), ("film_grain", C.c_uint32), ("first_frame", C.c_uint32), ("me_range", C.c_uint32), ("enable_lr", C.c_uint32), ("tile_sb", C.c_uint32), ("deblock", C.c_uint32), ("enable_qm", C.c_uint32), ("qm_min", C.c_uint32), ("qm_max", C.c_uint32), ("subpel", C.c_uint32), ("color_range", C.c_uint32), ("intra_angle_delta", C.c_uint32), ("intra_edge_filter", C.c_uint32), ("cfl", C.c_uint32), ("tx_search", C.c_uint32)]
+                                          "cdef_damping")] + [("intra_mode_mask", C.c_uint32), ("film_grain", C.c_uint32), ("first_frame", C.c_uint32), ("me_range", C.c_uint32), ("enable_lr", C.c_uint32), ("tile_sb", C.c_uint32), ("deblock", C.c_uint32), ("enable_qm", C.c_uint32), ("qm_min", C.c_uint32), ("qm_max", C.c_uint32), ("subpel", C.c_uint32), ("color_range", C.c_uint32), ("intra_angle_delta", C.c_uint32), ("intra_edge_filter", C.c_uint32), ("cfl", C.c_uint32), ("tx_search", C.c_uint32),
+                                                              ("color_primaries", C.c_uint32), ("transfer_characteristics", C.c_uint32), ("matrix_coefficients", C.c_uint32)]
 
 
 class Buf(C.Structure):
@@ -53,7 +54,7 @@ class Report(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("bytes", C.c_uint64), ("sse", C.c_double * 3), ("psnr", C.c_double * 3),
                 ("ms_h2d", C.c_float), ("ms_recon", C.c_float), ("ms_cdef", C.c_float), ("ms_entropy", C.c_float),
                 ("ms_pack", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float), ("ms_symbolize", C.c_float),
-                ("n_symbols", C.c_uint64), ("max_tile_symbols", C.c_uint32), ("cap_scale", C.c_uint32), ("chunks", C.c_uint32), ("reserved1", C.c_uint32)]
+                ("n_symbols", C.c_uint64), ("max_tile_symbols", C.c_uint32), ("cap_scale", C.c_uint32), ("chunks", C.c_uint32), ("gpus_used", C.c_uint32)]
 
 
 class Job(C.Structure):
@@ -107,6 +108,9 @@ _lib.av1mi_probe_y4m.argtypes = [C.c_char_p, C.POINTER(ClipInfo)]
 _lib.av1mi_cq_to_qindex.argtypes = [C.c_uint32]
 _lib.av1mi_cq_to_qindex.restype = C.c_uint32
 _lib.av1mi_abi_version.restype = C.c_uint32
+_lib.av1mi_struct_sizes.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+_lib.av1mi_struct_sizes.restype = C.c_uint32
+ABI_VERSION = 6   # include/av1mi.h: AV1MI_ABI_VERSION this mirror was written against
 _lib.av1mi_write_headers.argtypes = [C.POINTER(Params), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t)]
 
 
@@ -147,6 +151,20 @@ def default_params(width, height, bit_depth=8, **kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def struct_sizes():
+    """include/av1mi.h: av1mi_struct_sizes - the library's own sizes / offsets of the ABI structures"""
+    v = (C.c_uint32 * 32)()
+    n = int(_lib.av1mi_struct_sizes(v, 32))
+    return list(v[:n])
+
+
+def mirror_sizes():
+    """the same list computed from this module's ctypes mirror (tests/test_abi_host.py compares the two; check_layout() at import
+    refuses a library whose structures this mirror does not describe)"""
+    return [C.sizeof(Params), C.sizeof(Job), C.sizeof(Report), C.sizeof(Buf), C.sizeof(ClipInfo), C.sizeof(SceneState), C.sizeof(ExecJob),
+            C.sizeof(JobMetrics), Job.params.offset, Report.ms_h2d.offset, ExecJob.params.offset, JobMetrics.frames_encoded.offset]
 
 
 def chunk_owner(chunk_index, n_owners):
@@ -336,3 +354,16 @@ def job_execute(job_id, input_path, output_path, temp_base_dir, workers=0, cq_le
     err = C.create_string_buffer(256)
     rc = _lib.av1mi_job_execute(C.byref(j), cb, None, C.byref(m), err, 256)
     return rc, stages, m, err.value.decode()
+
+
+def check_layout():
+    """Refuse a library whose ABI structures are not the ones this mirror describes (a field added to av1mi_params and forgotten here
+    would otherwise corrupt memory silently).  Runs at import."""
+    if int(_lib.av1mi_abi_version()) != ABI_VERSION:
+        raise ImportError("libav1mi.so has ABI version %d, this mirror is written for %d" % (int(_lib.av1mi_abi_version()), ABI_VERSION))
+    lib_sizes, mine = struct_sizes(), mirror_sizes()
+    if lib_sizes != mine:
+        raise ImportError("libav1mi.so structure layout %s differs from the ctypes mirror %s" % (lib_sizes, mine))
+
+
+check_layout()

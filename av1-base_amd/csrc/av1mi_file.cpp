@@ -166,6 +166,17 @@ struct Muxer {
       priv.push_back(0);
       priv.insert(priv.end(), seq_hdr_obu.begin(), seq_hdr_obu.end());
       ebml_elem(vid, 0xB0, be(w, 2)); ebml_elem(vid, 0xBA, be(h, 2));
+      if (cp | tc | mc) {
+        // Colour (Matroska): what the sequence header's colour description says, for players that read the container first
+        std::vector<uint8_t> col;
+        ebml_elem(col, 0x55B1, be(mc ? mc : 2, 1));            // MatrixCoefficients
+        ebml_elem(col, 0x55B2, be(bit_depth, 1));              // BitsPerChannel
+        ebml_elem(col, 0x55B3, be(1, 1)); ebml_elem(col, 0x55B4, be(1, 1));   // ChromaSubsamplingHorz / Vert: 4:2:0
+        ebml_elem(col, 0x55B9, be(full_range ? 2 : 1, 1));     // Range: 1 = broadcast, 2 = full
+        ebml_elem(col, 0x55BA, be(tc ? tc : 2, 1));            // TransferCharacteristics
+        ebml_elem(col, 0x55BB, be(cp ? cp : 2, 1));            // Primaries
+        ebml_elem(vid, 0x55B0, col);
+      }
       ebml_elem(te, 0xD7, be(1, 1)); ebml_elem(te, 0x73C5, be(1, 1)); ebml_elem(te, 0x83, be(1, 1)); ebml_elem(te, 0x9C, be(0, 1));
       ebml_elem(te, 0x86, str("V_AV1")); ebml_elem(te, 0x63A2, priv);
       ebml_elem(te, 0x23E383, be(1000000000ull * fps_d / (fps_n ? fps_n : 30), 4));  // DefaultDuration, ns
@@ -231,6 +242,8 @@ struct Muxer {
     }
   }
   uint32_t bit_depth = 8;
+  uint32_t cp = 0, tc = 0, mc = 0;   // colour description of the job (av1mi_params), 0 = none
+  bool full_range = false;
 };
 
 // ---- host staging (BASELINE config 5 "per-GPU multi-stream overlap"; SURVEY.md §8e limiter "PCIe H2D of source frames") -------
@@ -500,6 +513,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
   if (!fo) { int e = -errno; give_all(); fclose(y.f); return e; }
   Muxer mux;
   mux.fo = fo; mux.w = y.w; mux.h = y.h; mux.fps_n = y.fps_n; mux.fps_d = y.fps_d; mux.bit_depth = y.bd;
+  mux.cp = prm.color_primaries; mux.tc = prm.transfer_characteristics; mux.mc = prm.matrix_coefficients; mux.full_range = prm.color_range != 0;
   {
     uint8_t sh[64]; size_t shn = sizeof(sh);
     rc = av1mi_write_headers(&prm, sh, &shn, nullptr, nullptr);
@@ -575,6 +589,7 @@ extern "C" int av1mi_encode_file(const av1mi_job *job, av1mi_progress_cb cb, voi
         bytes_out = mux.bytes;
         frames_done += ck->n_frames;
         tot.frames += ck->n_frames; tot.bytes += ck->rep.bytes; tot.n_symbols += ck->rep.n_symbols;
+        tot.gpus_used |= ck->rep.gpus_used;
         for (int p = 0; p < 3; p++) tot.sse[p] += ck->rep.sse[p];
         tot.ms_recon += ck->rep.ms_recon; tot.ms_cdef += ck->rep.ms_cdef; tot.ms_entropy += ck->rep.ms_entropy;
         tot.ms_pack += ck->rep.ms_pack; tot.ms_h2d += ck->rep.ms_h2d; tot.ms_d2h += ck->rep.ms_d2h; tot.ms_total += ck->rep.ms_total;

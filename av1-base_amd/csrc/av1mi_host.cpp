@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cstddef>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -109,6 +110,9 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
   if (p.subpel > 1 || p.enable_lr > 2 || p.color_range > 1 || p.intra_angle_delta > 1 || p.intra_edge_filter > 1 || p.cfl > 1 || p.tx_search > 1) return AV1MI_E_INVALID_ARG;
+  if (p.color_primaries > 255 || p.transfer_characteristics > 255 || p.matrix_coefficients > 255) return AV1MI_E_INVALID_ARG;
+  // CP_BT_709 / TC_SRGB / MC_IDENTITY switches the syntax to 4:4:4 with no color_range bit (spec 5.5.2): not a 4:2:0 description
+  if (p.color_primaries == 1 && p.transfer_characteristics == 13 && p.matrix_coefficients == 0) return AV1MI_E_INVALID_ARG;
   if (p.enable_qm > 1 || p.qm_min > 15 || p.qm_max > 15 || (p.enable_qm && p.qm_min > p.qm_max)) return AV1MI_E_INVALID_ARG;
   // level from the quantiser index, as SVT-AV1 / libaom derive it ("--qm-min", "--qm-max")
   r->qm_level = p.enable_qm ? (int)(p.qm_min + (uint32_t)r->qidx * (p.qm_max + 1 - p.qm_min) / 256) : 15;
@@ -167,7 +171,11 @@ std::vector<uint8_t> make_sequence_header(const Resolved &r) {
   // color_config
   b.put(p.bit_depth > 8, 1);  // high_bitdepth
   b.put(0, 1);                // mono_chrome
-  b.put(0, 1);                // color_description_present_flag
+  {
+    const bool desc = p.color_primaries || p.transfer_characteristics || p.matrix_coefficients;
+    b.put(desc, 1);           // color_description_present_flag (absent: CP / TC / MC = 2 "unspecified")
+    if (desc) { b.put(p.color_primaries, 8); b.put(p.transfer_characteristics, 8); b.put(p.matrix_coefficients, 8); }
+  }
   b.put(p.color_range ? 1 : 0, 1);  // color_range: 0 = studio (limited) range, 1 = full range
   b.put(0, 2);                // chroma_sample_position
   b.put(0, 1);                // separate_uv_delta_q
@@ -621,6 +629,15 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
 extern "C" {
 
 uint32_t av1mi_abi_version(void) { return AV1MI_ABI_VERSION; }
+uint32_t av1mi_struct_sizes(uint32_t *sizes, uint32_t cap) {
+  const uint32_t v[AV1MI_LAYOUT_ENTRIES] = {
+    (uint32_t)sizeof(av1mi_params), (uint32_t)sizeof(av1mi_job), (uint32_t)sizeof(av1mi_report), (uint32_t)sizeof(av1mi_buf),
+    (uint32_t)sizeof(av1mi_clip_info), (uint32_t)sizeof(av1mi_scene_state), (uint32_t)sizeof(av1mi_exec_job), (uint32_t)sizeof(av1mi_job_metrics),
+    (uint32_t)offsetof(av1mi_job, params), (uint32_t)offsetof(av1mi_report, ms_h2d), (uint32_t)offsetof(av1mi_exec_job, params),
+    (uint32_t)offsetof(av1mi_job_metrics, frames_encoded) };
+  for (uint32_t i = 0; i < AV1MI_LAYOUT_ENTRIES && i < cap && sizes; i++) sizes[i] = v[i];
+  return AV1MI_LAYOUT_ENTRIES;
+}
 uint32_t av1mi_cq_to_qindex(uint32_t cq) { return kQuantizerToQindex[cq > 63 ? 63 : cq]; }
 
 void av1mi_default_params(av1mi_params *p, uint32_t w, uint32_t h, uint32_t bd) {
@@ -1183,6 +1200,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     report->frames = n_frames;
     report->bytes = total;
     report->cap_scale = (uint32_t)c->cap_scale;
+    report->gpus_used = 1u << (c->device & 31);
     report->chunks = 1;
     const double mx = (double)((1 << P.bit_depth) - 1);
     for (int pl = 0; pl < 3; pl++) {

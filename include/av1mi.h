@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AV1MI_ABI_VERSION 5
+#define AV1MI_ABI_VERSION 6
 
 /* positive failure codes (-> Av1anFailed(code)) */
 enum {
@@ -85,6 +85,13 @@ typedef struct {
                                blocks up to 32x32 (alpha per plane by least squares over the reconstructed luma); 0 (default) */
   uint32_t tx_search;       /* 1: transform type search - intra luma blocks up to 16x16 whose residual is sparse (at most one sample in
                                eight nonzero) are coded with the identity transform (IDTX); 0 (default): the mode's default type */
+  uint32_t color_primaries, transfer_characteristics, matrix_coefficients;
+                            /* color_config's colour description (AV1 spec 5.5.2; CICP / ISO 23091-2 code points), written into the sequence
+                               header and, for Matroska output, the track's Colour element: what the reference's ffmpeg -> SVT-AV1 pipeline
+                               passes through (`--pix-format yuv420p10le`, av1an.rs:90).  All 0 (default) = no description
+                               (color_description_present_flag 0); BASELINE config 5 "8K 10-bit HDR" = 9 / 16 / 9 (BT.2020 primaries, SMPTE
+                               2084 PQ, BT.2020 non-constant luminance).  Values 0..255 each; the triple 1 / 13 / 0 (sRGB + identity) implies
+                               4:4:4 and is refused */
 } av1mi_params;
 
 typedef struct {
@@ -107,7 +114,8 @@ typedef struct {
   uint32_t cap_scale;       /* per-tile capacity multiplier the chunk finally ran with (1 unless a tile overflowed
                                and the chunk was re-run) */
   uint32_t chunks;          /* av1mi_encode_file: chunks the clip was split into (1 for av1mi_encode_chunk) */
-  uint32_t reserved1;
+  uint32_t gpus_used;       /* bit d = GPU d encoded at least one chunk of the job (av1mi_encode_chunk: the context's device) - what
+                               `gpu_mask` and av1mi_plan_workers resolved to on this host */
 } av1mi_report;
 
 void av1mi_default_params(av1mi_params *p, uint32_t width, uint32_t height, uint32_t bit_depth);
@@ -231,6 +239,16 @@ typedef void (*av1mi_state_cb)(void *user, const char *stage, const av1mi_job_me
 
 int av1mi_job_execute(const av1mi_exec_job *job, av1mi_state_cb state_cb, void *user, av1mi_job_metrics *metrics,
                       char *error, size_t error_cap);
+
+/* Layout pin of this ABI: a binding (integration/mi355x.rs, the ctypes mirror) that was written against another revision of a structure
+ * corrupts memory silently - AV1MI_ABI_VERSION is bumped by hand.  Writes up to `cap` entries
+ *   { sizeof(av1mi_params), sizeof(av1mi_job), sizeof(av1mi_report), sizeof(av1mi_buf), sizeof(av1mi_clip_info), sizeof(av1mi_scene_state),
+ *     sizeof(av1mi_exec_job), sizeof(av1mi_job_metrics), offsetof(av1mi_job, params), offsetof(av1mi_report, ms_h2d),
+ *     offsetof(av1mi_exec_job, params), offsetof(av1mi_job_metrics, frames_encoded) }
+ * and returns how many there are (12); a binding asserts them against its own `size_of` / `offset_of` once at start-up
+ * (integration/mi355x.rs: `check_layout`; tests/test_abi_host.py does it for the ctypes mirror). */
+#define AV1MI_LAYOUT_ENTRIES 12
+uint32_t av1mi_struct_sizes(uint32_t *sizes, uint32_t cap);
 
 /* helpers shared with the host mirror / tests */
 uint32_t av1mi_cq_to_qindex(uint32_t cq_level);

@@ -18,6 +18,7 @@ pub struct Av1miParams {            // include/av1mi.h: av1mi_params
     pub intra_edge_filter: u32,     // 1 = enable_intra_edge_filter (filtered / upsampled prediction edges)
     pub cfl: u32,                   // 1 = chroma-from-luma prediction is a candidate (key frames, blocks up to 32x32)
     pub tx_search: u32,             // 1 = identity transform (IDTX) for sparse intra luma residuals
+    pub color_primaries: u32, pub transfer_characteristics: u32, pub matrix_coefficients: u32,   // CICP colour description (0 / 0 / 0 = none; HDR10: 9 / 16 / 9)
 }
 #[repr(C)]
 pub struct Av1miJob {               // include/av1mi.h: av1mi_job  <->  Av1anEncodeParams (av1an.rs:36-45)
@@ -35,19 +36,41 @@ pub struct Av1miReport {            // fills JobMetrics.{fps, frames_encoded, ps
     pub frames: u32, pub bytes: u64, pub sse: [f64; 3], pub psnr: [f64; 3],
     pub ms_h2d: f32, pub ms_recon: f32, pub ms_cdef: f32, pub ms_entropy: f32, pub ms_pack: f32,
     pub ms_d2h: f32, pub ms_total: f32, pub ms_symbolize: f32, pub n_symbols: u64,
-    pub max_tile_symbols: u32, pub cap_scale: u32, pub chunks: u32, pub reserved1: u32,
+    pub max_tile_symbols: u32, pub cap_scale: u32, pub chunks: u32, pub gpus_used: u32,
 }
 type ProgressCb = Option<extern "C" fn(user: *mut c_void, done: u32, total: u32, fps: f64, bytes: u64)>;
 
 #[link(name = "av1mi")]
 extern "C" {
+    fn av1mi_abi_version() -> u32;
+    fn av1mi_struct_sizes(sizes: *mut u32, cap: u32) -> u32;
     fn av1mi_default_params(p: *mut Av1miParams, w: u32, h: u32, bit_depth: u32);
     fn av1mi_encode_file(job: *const Av1miJob, cb: ProgressCb, user: *mut c_void, total: *mut Av1miReport) -> c_int;
+}
+
+// Layout pin (include/av1mi.h: av1mi_struct_sizes).  Compile time: the sizes this file was written against (ABI version 6, LP64);
+// run time, once: the library's own sizes and offsets - a libav1mi.so built from another revision of the header is refused
+// instead of being handed structures it would read past.
+pub const AV1MI_ABI_VERSION: u32 = 6;
+const _: () = assert!(std::mem::size_of::<Av1miParams>() == 32 * 4);
+const _: () = assert!(std::mem::size_of::<Av1miJob>() == 3 * 8 + 3 * 4 + 32 * 4 + 4 /* tail padding to 8 */);
+const _: () = assert!(std::mem::size_of::<Av1miReport>() == 120);
+pub fn check_layout() -> Result<(), EncodeError> {
+    static ONCE: std::sync::OnceLock<bool> = std::sync::OnceLock::new();
+    let ok = *ONCE.get_or_init(|| unsafe {
+        let mut v = [0u32; 12];
+        av1mi_abi_version() == AV1MI_ABI_VERSION && av1mi_struct_sizes(v.as_mut_ptr(), 12) == 12
+            && v[0] as usize == std::mem::size_of::<Av1miParams>() && v[1] as usize == std::mem::size_of::<Av1miJob>()
+            && v[2] as usize == std::mem::size_of::<Av1miReport>() && v[8] as usize == std::mem::offset_of!(Av1miJob, params)
+            && v[9] as usize == std::mem::offset_of!(Av1miReport, ms_h2d)
+    });
+    if ok { Ok(()) } else { Err(EncodeError::Av1anFailed(7 /* AV1MI_E_UNSUPPORTED: ABI mismatch */)) }
 }
 
 /// Same contract as `run_av1an` (av1an.rs:126-139): blocks until `output_path` is complete.
 pub fn run_mi355x(params: &Av1anEncodeParams, cq_level: u32) -> Result<(), EncodeError> {
     let c = |p: &std::path::Path| CString::new(p.as_os_str().as_encoded_bytes()).map_err(|e| EncodeError::Io(std::io::Error::other(e)));
+    check_layout()?;
     let (i, o, t) = (c(&params.input_path)?, c(&params.output_path)?, c(&params.temp_chunks_dir)?);
     let mut p = Av1miParams::default();
     unsafe { av1mi_default_params(&mut p, 8, 8, 8) };   // geometry comes from the Y4M header

@@ -79,6 +79,8 @@ typedef struct {
                            * edges of spec 7.11.2.9 - 7.11.2.12 (SVT-AV1 and libaom run with it on); 0 = the round-1 streams */
   int cfl;                /* 1: chroma-from-luma prediction (spec 7.11.5) is a candidate for the chroma planes of key-frame blocks up to 32x32 */
   int tx_search;          /* 1: transform type search - intra luma blocks up to 16x16 with a sparse residual take the identity transform (IDTX) */
+  int color_primaries, transfer_characteristics, matrix_coefficients; /* color_config's colour description (§5.5.2, CICP code points): all 0 =
+                           * none (color_description_present_flag 0); BASELINE config 5 "8K 10-bit HDR" = 9 / 16 / 9 (BT.2020, PQ, BT.2020 NCL) */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */

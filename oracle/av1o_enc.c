@@ -133,7 +133,17 @@ static int true_h(const Av1oConfig *cfg) { return cfg->true_height ? cfg->true_h
 static void write_color_config(BitW *b, const Av1oConfig *cfg) {
   bw_put(b, cfg->bit_depth > 8, 1); /* high_bitdepth (profile 0: no twelve_bit) */
   bw_put(b, 0, 1);                  /* mono_chrome */
-  bw_put(b, 0, 1);                  /* color_description_present_flag */
+  {
+    const int desc = cfg->color_primaries || cfg->transfer_characteristics || cfg->matrix_coefficients;
+    bw_put(b, desc, 1);             /* color_description_present_flag */
+    if (desc) {
+      bw_put(b, (unsigned)cfg->color_primaries, 8);
+      bw_put(b, (unsigned)cfg->transfer_characteristics, 8);
+      bw_put(b, (unsigned)cfg->matrix_coefficients, 8);
+    }
+    /* (CP 1 / TC 13 / MC 0 - sRGB with the identity matrix - would imply 4:4:4 and no color_range bit: not a 4:2:0 description,
+     * refused by the product's parameter check, never written here) */
+  }
   bw_put(b, cfg->color_range ? 1 : 0, 1); /* color_range: 0 studio (limited), 1 full */
   bw_put(b, 0, 2);                  /* chroma_sample_position (4:2:0): unknown */
   bw_put(b, 0, 1);                  /* separate_uv_delta_q */

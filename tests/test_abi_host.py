@@ -31,7 +31,26 @@ def test_exports_every_declared_symbol(av1mi):
     lib = C.CDLL(os.path.abspath(av1mi.LIB_PATH))
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert av1mi._lib.av1mi_abi_version() == 5
+    hdr_version = int(re.search(r"#define AV1MI_ABI_VERSION (\d+)", hdr).group(1))
+    assert av1mi._lib.av1mi_abi_version() == hdr_version == av1mi.ABI_VERSION
+
+
+def test_structure_layout_is_pinned(av1mi):
+    """av1mi_struct_sizes: the library's own sizes / offsets of every ABI structure equal the ctypes mirror's (the mirror refuses to
+    import otherwise) and the constants written into the Rust shim (integration/mi355x.rs `const _: () = assert!(...)`), so a field
+    added to av1mi_params and forgotten in a binding fails here instead of corrupting memory."""
+    lib_sizes = av1mi.struct_sizes()
+    assert len(lib_sizes) == 12 and lib_sizes == av1mi.mirror_sizes()
+    rs = open(os.path.join(ROOT, "integration", "mi355x.rs")).read()
+    # the Rust mirror declares one u32 per av1mi_params field
+    body = rs[rs.index("pub struct Av1miParams"):]
+    body = body[:body.index("}")]
+    assert len(re.findall(r"pub \w+: u32", body)) * 4 == lib_sizes[0] == C.sizeof(av1mi.Params)
+    m = re.search(r"size_of::<Av1miParams>\(\) == (\d+) \* 4", rs)
+    assert m and int(m.group(1)) * 4 == lib_sizes[0]
+    m = re.search(r"size_of::<Av1miReport>\(\) == (\d+)", rs)
+    assert m and int(m.group(1)) == lib_sizes[2]
+    assert "pub const AV1MI_ABI_VERSION: u32 = %d;" % av1mi.ABI_VERSION in rs
 
 
 def test_free_takes_null_and_plain_heap_blocks(av1mi):
@@ -86,6 +105,40 @@ def test_color_range_bit_of_the_sequence_header(av1mi, oracle):
     assert seqs[0] != seqs[1] and av1mi.default_params(64, 64, 8).color_range == 0
     with pytest.raises(av1mi.EncodeFailed):
         av1mi.write_headers(av1mi.default_params(64, 64, 8, color_range=2))
+
+
+def test_colour_description_of_the_sequence_header(av1mi, oracle, golden_cases):
+    """color_config's colour description (BASELINE config 5 "8K 10-bit HDR"; the reference's ffmpeg -> SVT-AV1 pipeline passes colour
+    metadata through, av1an.rs:90): av1mi_params.{color_primaries, transfer_characteristics, matrix_coefficients} = 9 / 16 / 9 writes the
+    same sequence header as the oracle - whose stream dav1d decoded and libavif read the code points back from (tests/golden/
+    k200x120_hdr_bt2020_pq_10b, tools/make_golden.py) - and none (0 / 0 / 0) leaves the header as it was."""
+    m = [g for g in golden_cases if g["name"] == "k200x120_hdr_bt2020_pq_10b"][0]
+    p = av1mi.default_params(200, 120, 10, color_primaries=9, transfer_characteristics=16, matrix_coefficients=9)
+    seq, _, _ = av1mi.write_headers(p)
+    assert m["obu"][2:2 + len(seq)] == seq   # temporal delimiter, then the sequence header OBU
+    # color_config: high_bitdepth 1, mono 0, description present 1, then the three code points
+    bits = "".join("{:08b}".format(b) for b in seq[2:])
+    i = bits.find("101" + "{:08b}{:08b}{:08b}".format(9, 16, 9))
+    assert i > 0
+    plain, _, _ = av1mi.write_headers(av1mi.default_params(200, 120, 10))
+    assert len(seq) == len(plain) + 3
+    cfg = oracle.default_config(200, 120, 10, color_primaries=1, transfer_characteristics=1, matrix_coefficients=1, color_range=1)
+    buf = C.create_string_buffer(64)
+    n = oracle.lib().av1o_write_sequence_header(C.byref(cfg), buf, 64)
+    assert buf.raw[:n] == av1mi.write_headers(av1mi.default_params(200, 120, 10, color_primaries=1, transfer_characteristics=1, matrix_coefficients=1, color_range=1))[0]
+    for bad in (dict(color_primaries=256), dict(color_primaries=1, transfer_characteristics=13, matrix_coefficients=0)):   # sRGB + identity implies 4:4:4
+        with pytest.raises(av1mi.EncodeFailed):
+            av1mi.write_headers(av1mi.default_params(64, 64, 8, **bad))
+
+
+def test_y4m_with_frame_parameters_is_read_sequentially(av1mi, tmp_path):
+    """"FRAME <params>\n" markers are legal Y4M: such a clip cannot be cut into frames by offset, so its length is unknown to the probe
+    (0) instead of wrong - av1mi_encode_file reads it frame by frame (GPU test: test_encode_file_ragged_and_empty_inputs)."""
+    w, h = 72, 56
+    f = tmp_path / "p.y4m"
+    f.write_bytes(b"YUV4MPEG2 W%d H%d F25:1 C420jpeg\n" % (w, h) + (b"FRAME Ip\n" + bytes(w * h * 3 // 2)) * 3)
+    ci = av1mi.probe_y4m(f)
+    assert (ci.width, ci.height, ci.frames) == (w, h, 0)
 
 
 def test_probe_y4m_reports_rate_range_and_length(av1mi, tmp_path):

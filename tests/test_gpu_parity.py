@@ -58,6 +58,8 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         p.intra_edge_filter = cfgk.get("intra_edge_filter", 0)
         p.cfl = cfgk.get("cfl", 0)
         p.tx_search = cfgk.get("tx_search", 0)
+        for k in ("color_primaries", "transfer_characteristics", "matrix_coefficients", "color_range"):
+            setattr(p, k, cfgk.get(k, 0))
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
         p.enable_lr = cfgk.get("enable_lr", 0)
         if cfgk.get("deblock", 0) == 2:
@@ -643,6 +645,45 @@ def test_encode_file_matroska_and_obu_outputs(av1mi, oracle, tmp_path):
     # chunks of 4 frames, key frame every 2 frames inside a chunk: frames 0, 2, 4, 6 are key frames
     assert [b[1] for b in blocks] == [0x80, 0, 0x80, 0, 0x80, 0, 0x80]
     assert [b[2] for b in blocks] == [t[2:] for t in tus]
+
+
+def test_encode_file_hdr_colour_frame_parameters_and_gpu_mask(av1mi, oracle, tmp_path):
+    """BASELINE config 5's "HDR": the job's colour description (BT.2020 / PQ / BT.2020 NCL) reaches the sequence header - the same bytes
+    as the oracle's, which dav1d / libavif read back (tests/golden/k200x120_hdr_bt2020_pq_10b) - and the Matroska track's Colour element.
+    The clip's FRAME markers carry parameters ("FRAME Ip"): the sequential reader takes over from the offset-based one.  `workers` = 2 under
+    `gpu_mask` = GPU 0 reports exactly that GPU as used; a mask that allows no visible GPU is AV1MI_E_NO_DEVICE."""
+    import torch
+    w, h, n = 136, 72, 5
+    frames = [oracle.synthclip_frame(w, h, 10, seed=80, t=t) for t in range(n)]
+    y4m = tmp_path / "clip.y4m"
+    with open(y4m, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C420p10 XYSCSS=420P10\n" % (w, h))
+        for fr in frames:
+            f.write(b"FRAME Ip\n" + raw_of(fr, 10))
+    hdr = dict(color_primaries=9, transfer_characteristics=16, matrix_coefficients=9)
+    out = tmp_path / "clip.mkv"
+    plan = av1mi.derive_plan(8)
+    plan.av1an_workers = 2
+    rep = av1mi.run_mi355x(av1mi.EncodeParams(y4m, out, tmp_path, plan, chunk_frames=2, gpu_mask=0b1, **hdr))
+    assert rep.frames == n and rep.chunks == 3 and rep.gpus_used == 0b1
+    mkv = out.read_bytes()
+    top = list(_ebml(mkv, 0, len(mkv)))
+    seg = list(_ebml(mkv, top[1][1], top[1][2]))
+    entry = next(_ebml(mkv, seg[1][1], seg[1][2]))
+    te = {e[0]: (e[1], e[2]) for e in _ebml(mkv, entry[1], entry[2])}
+    vid = {e[0]: (e[1], e[2]) for e in _ebml(mkv, te[0xE0][0], te[0xE0][1])}
+    col = {e[0]: int.from_bytes(mkv[e[1]:e[2]], "big") for e in _ebml(mkv, vid[0x55B0][0], vid[0x55B0][1])}
+    assert col == {0x55B1: 9, 0x55B2: 10, 0x55B3: 1, 0x55B4: 1, 0x55B9: 1, 0x55BA: 16, 0x55BB: 9}
+    priv = mkv[te[0x63A2][0]:te[0x63A2][1]]
+    cfg = oracle.default_config(w, h, 10, min_bs_log2=5, max_bs_log2=5, **hdr)
+    tu, _, _ = oracle.encode_frame(cfg, frames[0])
+    assert priv[4:] == tu[2:2 + 2 + tu[3]]            # CodecPrivate's sequence header == the oracle's, colour description included
+    first_block = next(e for c in seg[2:] for e in list(_ebml(mkv, c[1], c[2]))[1:])
+    assert mkv[first_block[1] + 4:first_block[2]] == tu[2:]   # and the first frame's payload (temporal delimiter dropped)
+    if torch.cuda.device_count() < 2:
+        with pytest.raises(av1mi.EncodeFailed) as ei:
+            av1mi.run_mi355x(av1mi.EncodeParams(y4m, tmp_path / "no.mkv", tmp_path, plan, chunk_frames=2, gpu_mask=0b10, **hdr))
+        assert ei.value.code == av1mi.E_NO_DEVICE and not (tmp_path / "no.mkv").exists()
 
 
 def test_job_execute_segment_states_and_metrics(av1mi, oracle, tmp_path):

@@ -119,6 +119,10 @@ CASES = [
     ("fuzz_idtx_bs3", 200, 120, 8, 106, 0, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=3, tx_search=1)),
     ("fuzz_idtx_bs4_qm_10b", 264, 200, 10, 107, 0, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, fuzz_modes=5, tx_search=1, enable_qm=1, qm_y=4, qm_uv=6)),
     ("fuzz_idtx_levels", 136, 136, 8, 108, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=15, fuzz_coeffs=21, fuzz_density=4, fuzz_maxlevel=20, tx_search=1)),
+    # colour description in the sequence header (BASELINE config 5 "8K 10-bit HDR": BT.2020 primaries, PQ transfer, BT.2020 NCL matrix;
+    # and a BT.709 full-range one): dav1d decodes the stream, libavif's own sequence-header parser reads the code points back
+    ("k200x120_hdr_bt2020_pq_10b", 200, 120, 10, 1080, 12, dict(min_bs_log2=5, max_bs_log2=5, color_primaries=9, transfer_characteristics=16, matrix_coefficients=9)),
+    ("k72x56_bt709_full", 72, 56, 8, 11, 1, dict(min_bs_log2=4, max_bs_log2=4, color_primaries=1, transfer_characteristics=1, matrix_coefficients=1, color_range=1)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -224,6 +228,11 @@ def main():
                     raise SystemExit("%s: plane %d: dav1d's grain is not a bounded perturbation of the reconstruction (max %d)" % (name, p, d.max()))
             elif d.max() != 0:
                 raise SystemExit("%s: dav1d output differs from the oracle reconstruction in plane %d" % (name, p))
+        if kw.get("color_primaries"):
+            cicp = oracle_avif.decode_colour(oracle_avif.wrap_avif(tu, w, h, bd))
+            want = (kw["color_primaries"], kw["transfer_characteristics"], kw["matrix_coefficients"], 1 if kw.get("color_range") else 0)
+            if tuple(cicp) != want:
+                raise SystemExit("%s: libavif reads the colour description as %s, the oracle wrote %s" % (name, cicp, want))
         open(os.path.join(OUT, name + ".obu"), "wb").write(tu)
         meta = dict(name=name, width=w, height=h, bit_depth=bd, seed=seed, t=t, config=kw, src_shift=src_shift, bytes=len(tu),
                     dav1d_sha256=sha(dec), recon_sha256=sha(rec), dav1d_applies_grain=grain, src_sha256=sha(src), n_symbols=int(st.n_symbols),

@@ -65,6 +65,33 @@ class _AvifImageHead(C.Structure):
     ]
 
 
+class _AvifImageColour(C.Structure):
+    # `struct avifImage` up to the CICP fields (libavif 1.x avif.h: avifColorPrimaries & co. are uint16_t typedefs)
+    _fields_ = _AvifImageHead._fields_ + [
+        ("imageOwnsYUVPlanes", C.c_int), ("alphaPlane", C.c_void_p), ("alphaRowBytes", C.c_uint32), ("imageOwnsAlphaPlane", C.c_int),
+        ("alphaPremultiplied", C.c_int), ("icc_data", C.c_void_p), ("icc_size", C.c_size_t),
+        ("colorPrimaries", C.c_uint16), ("transferCharacteristics", C.c_uint16), ("matrixCoefficients", C.c_uint16),
+    ]
+
+
+def decode_colour(avif_bytes):
+    """(color_primaries, transfer_characteristics, matrix_coefficients, full_range) as libavif reports them for a still WITHOUT a colr
+    box: taken from the AV1 sequence header's color_config (its own parser: an independent reading of the header the oracle wrote)."""
+    lib = _load()
+    dec = lib.avifDecoderCreate()
+    img = lib.avifImageCreateEmpty()
+    try:
+        buf = bytes(avif_bytes)
+        r = lib.avifDecoderReadMemory(dec, img, buf, len(buf))
+        if r != 0:
+            raise RuntimeError("libavif/dav1d decode failed: %s" % lib.avifResultToString(r).decode())
+        h = _AvifImageColour.from_address(img)
+        return h.colorPrimaries, h.transferCharacteristics, h.matrixCoefficients, h.yuvRange
+    finally:
+        lib.avifImageDestroy(img)
+        lib.avifDecoderDestroy(dec)
+
+
 # ------------------------------------------------------------------ ISO-BMFF writer
 def _box(kind, payload):
     return struct.pack(">I4s", 8 + len(payload), kind) + payload
