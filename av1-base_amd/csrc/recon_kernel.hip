@@ -46,6 +46,7 @@ static __device__ __forceinline__ int32_t av1_half_btf(int32_t w0, int32_t a, in
 }
 #include "txfm_gen.h"
 #include "fdct32_matrix.h"
+#include "intra_pieces.h"
 
 namespace {
 
@@ -59,11 +60,10 @@ __constant__ uint8_t c_sm_weights[4 + 8 + 16 + 32 + 64] = {
   255, 240, 225, 210, 196, 182, 169, 157, 145, 133, 122, 111, 101, 92, 83, 74, 66, 59, 52, 45, 39, 34, 29, 25, 21, 17, 14, 12, 10, 9, 8, 8,
   255, 248, 240, 233, 225, 218, 210, 203, 196, 189, 182, 176, 169, 163, 156, 150, 144, 138, 133, 127, 121, 116, 111, 106, 101, 96, 91, 86, 82, 77, 73, 69,
   65, 61, 57, 54, 50, 47, 44, 41, 38, 35, 32, 29, 27, 25, 22, 20, 18, 16, 15, 13, 12, 10, 9, 8, 7, 6, 6, 5, 5, 4, 4, 4 };
-// Dr_Intra_Derivative indexed by angle/3 rounded down is not injective, so index by angle
-__constant__ int16_t c_dr_deriv[91] = {
-  0, 0, 0, 1023, 0, 0, 547, 0, 0, 372, 0, 0, 0, 0, 273, 0, 0, 215, 0, 0, 178, 0, 0, 151, 0, 0, 132, 0, 0, 116, 0, 0,
-  102, 0, 0, 0, 90, 0, 0, 80, 0, 0, 71, 0, 0, 64, 0, 0, 57, 0, 0, 51, 0, 0, 45, 0, 0, 0, 40, 0, 0, 35, 0, 0,
-  31, 0, 0, 27, 0, 0, 23, 0, 0, 19, 0, 0, 15, 0, 0, 0, 0, 11, 0, 0, 7, 0, 0, 3, 0, 0, 0 };
+// Dr_Intra_Derivative indexed by angle/3 rounded down is not injective, so index by angle (values: intra_pieces.h)
+__constant__ int16_t c_dr_deriv[91] = AV1MI_DR_DERIV_INIT;
+// floor(64 k / Dr_Intra_Derivative[angle]) for k = 1 .. 32 as (64 k * magic) >> 22 (the row where a 90 < angle < 180 prediction switches edges)
+__constant__ uint32_t c_dr_magic[91] = AV1MI_DR_MAGIC_INIT;
 __constant__ int16_t c_mode_angle[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
 // Mode_To_Txfm (spec §6.10.x): 0 DCT_DCT 1 ADST_DCT 2 DCT_ADST 3 ADST_ADST
 // luma 32x32 forward transform on the matrix cores: per lane the operand fragments of fdct32_matrix.h (stage-1 B low / high bytes,
@@ -498,6 +498,9 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   constexpr int SCRO = NPL == 1 ? 0 : (N > 16 ? 32 * 33 : 16 * 24);   // (16 rows of stride 24: see STR)
   constexpr int EDGO = NPL == 1 ? 0 : 72;
   constexpr int EB = 8;   // index of element 0 inside a group's edge array
+  // PVOK: block classes with the piece-wise intra predictors (eight samples of a row per lane and step; below).  Not in the 64x64 build:
+  // the edge arrays there have no room for the padding of a 64-sample edge.
+  constexpr bool PVOK = !AV1MI_RECON_BIG && N >= 8;
   const Av1miDevParams *P = cx.P;
   const int lane = cx.lane;
   const int grp = NPL == 1 ? 0 : lane >> 5, sl = NPL == 1 ? lane : lane & 31;
@@ -633,7 +636,9 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   {
     const int max_x = ((plane0 ? P->width >> 1 : P->width) - 1) - (gx - lx);   // frame limit, tile-local
     const int max_y = ((plane0 ? P->height >> 1 : P->height) - 1) - (gy - ly);
-    for (int i = sl; i < 2 * N; i += G) {
+    // (PVOK: the piece-wise predictors read up to element 3 N + 8 of an edge - the elements beyond 2 N - 1 repeat the last one, which is
+    // what a prediction at an angle below 90 degrees takes beyond max_base)
+    for (int i = sl; i < (PVOK ? 3 * N + 9 : 2 * N); i += G) {
       int a, l;
       if (!have_above && have_left) a = LN.left[plane][ly];           // pixel (y0, x0-1)
       else if (!have_above) a = (1 << (bd - 1)) - 1;
@@ -703,7 +708,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       ef_type = uniform_i((have_above && LN.sm_above[pc][ux]) || (have_left && LN.sm_left[pc][uy]));
     }
   }
-  constexpr int FEL = N >= 64 ? 136 : 72;
+  constexpr int FEL = PVOK ? 3 * N + 16 : (N >= 64 ? 136 : 72);   // (PVOK: elements -2 .. 3 N + 8, see the padding of the raw edges)
   uint16_t *const FA = reinterpret_cast<uint16_t *>(S->scratch + so) + 2, *const FL = FA + FEL;
   auto dir_edges = [&](int ang, const uint16_t *&A, const uint16_t *&L, int &up_a, int &up_l) -> bool {
     A = S->edge_a + EB + eo; L = S->edge_l + EB + eo; up_a = 0; up_l = 0;
@@ -715,9 +720,10 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     const int st_a = have_above ? ef_strength(2 * N, ef_type, ang - 90) : 0, st_l = have_left ? ef_strength(2 * N, ef_type, ang - 180) : 0;
     const int sz_a = n_top + (ang < 90 ? N : 0) + 1, sz_l = n_left + (ang > 180 ? N : 0) + 1;
     wave_sync();   // the previous candidate's reads of FA / FL are done
-    for (int i = sl - 1; i < 2 * N; i += G) {
-      FA[i] = (uint16_t)ef_element(RA, corner, i, sz_a, st_a);
-      FL[i] = (uint16_t)ef_element(RL, corner, i, sz_l, st_l);
+    for (int i = sl - 1; i < (PVOK ? 3 * N + 9 : 2 * N); i += G) {
+      const int ic = i < 2 * N ? i : 2 * N - 1;   // (padding: the last element again, filtered as it is)
+      FA[i] = (uint16_t)ef_element(RA, corner, ic, sz_a, st_a);
+      FL[i] = (uint16_t)ef_element(RL, corner, ic, sz_l, st_l);
     }
     wave_sync();
     if constexpr (N <= 8) {   // 7.11.2.11: one lane per source element, at most 16 of them
@@ -745,8 +751,35 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     return true;
   };
   int first = (PH != 1 && NPL == 1 && plane0 == 0) ? 0 : 13;
-  if (PH != 1 && NPL == 1 && plane0 == 0 && P->mode_mask == 0x7u) {
-    // default candidate set {DC, V, H}: the three SADs in one pass over the block instead of three
+  // ---- piece-wise intra predictors (PVOK; intra_pieces.h): eight samples of a row per lane and step, packed two to a register, instead
+  // of one sample per lane and step through pred_pixel (whose switch, index arithmetic and dependent 2-byte LDS reads made a candidate
+  // ~ 900 wave instructions on a 32x32 block: with all 13 candidates 89 % of a luma item).  The SADs of candidates that predict from the
+  // left edge at an angle are taken in the transposed layout, against a transposed copy of the source kept where the prediction goes later.
+  uint16_t *const TT = S->blkpix + po;
+  bool have_tt = false;   // the transposed source tile exists (built when the first candidate needs it)
+  // write == false: the lane's part of the candidate's SAD; write == true: the prediction goes to blkpix (the caller forms the residual)
+  auto pv_run = [&](int mode, int ang, int dx, int dy, const uint16_t *EA, const uint16_t *EL, bool write) -> int {
+    if constexpr (PVOK) {
+      namespace pc = av1mi_pieces;
+      mode = uniform_i(mode); ang = uniform_i(ang); dx = uniform_i(dx); dy = uniform_i(dy);
+      const uint16_t *A0 = S->edge_a + EB + eo, *L0 = S->edge_l + EB + eo;
+      const bool left_part = pc::is_dir(mode, ang) && ang > 90;
+      if (left_part && !write && !have_tt) {
+        pc::transpose_lane<N, G>(sl, S->srcblk + po, TT);
+        wave_sync();
+        have_tt = true;
+      }
+      const uint32_t magic = (left_part && ang < 180) ? c_dr_magic[180 - ang] : 0u;   // (dx = c_dr_deriv[180 - ang])
+      uint32_t acc = pc::pass_t<N, G>(sl, mode, ang, dy, magic, EL, TT, S->blkpix + po, write);
+      if (write && left_part && ang < 180) wave_sync();
+      acc += pc::pass_n<N, G>(sl, mode, ang, dx, dcv, EA, A0, L0, S->smw, S->srcblk + po, S->blkpix + po, write);
+      return (int)acc;
+    } else {
+      return 0;
+    }
+  };
+  if (PH != 1 && NPL == 1 && plane0 == 0 && (PVOK ? (P->mode_mask & 0x7u) != 0 : P->mode_mask == 0x7u)) {
+    // DC, V and H - the default candidate set - in one pass over the block instead of three
     int s_dc = 0, s_v = 0, s_h = 0;
     const uint16_t *A = S->edge_a + EB, *L = S->edge_l + EB;
     if constexpr (LOG2N == 5) {
@@ -778,12 +811,12 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       s_h += iabs(sv - (int)L[p >> LOG2N]);
     }
     }
-    sad_dc = wave_sum(s_dc);
-    s_v = wave_sum(s_v);
-    s_h = wave_sum(s_h);
-    if (s_v < best_sad) { best_sad = s_v; best_mode = V_PRED; }   // candidates in mode order, first minimum wins
-    if (s_h < best_sad) { best_sad = s_h; best_mode = H_PRED; }
-    first = 13;
+    // candidates in mode order, first minimum wins; DC does not compete here (see the final trip)
+    const unsigned mm = P->mode_mask;
+    if (mm & 1u) sad_dc = wave_sum(s_dc);
+    if (mm & 2u) { s_v = wave_sum(s_v); if (s_v < best_sad) { best_sad = s_v; best_mode = V_PRED; } }
+    if (mm & 4u) { s_h = wave_sum(s_h); if (s_h < best_sad) { best_sad = s_h; best_mode = H_PRED; } }
+    first = (mm & ~0x7u) ? 3 : 13;
   }
   STAMP(1);   // DC value + the default candidates' SADs
   // ---- chroma from luma (spec 7.11.5): key-frame blocks up to 32x32 luma.  The luma item left the block's
@@ -855,6 +888,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
           int up_a, up_l;
           dir_edges(ang, EA, EL, up_a, up_l);
           int sad = 0;
+          if (PVOK && !(up_a | up_l)) sad = pv_run(best_mode, ang, dx, dy, EA, EL, false);
+          else
 #pragma unroll 4
           for (int p = sl; p < N * N; p += G)
             sad += iabs((int)S->srcblk[po + p] - pred_pixel<LOG2N, WV>(best_mode, p >> LOG2N, p & (N - 1), dcv, ang, dx, dy, EA, EL, up_a, up_l));
@@ -905,7 +940,14 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         vec_done = true;
       }
     }
-    if (!vec_done)
+    // PVOK: an intra candidate's SAD, or the final intra prediction, by the piece-wise predictors (the residual then follows in a pass of
+    // its own, as with filtered edges); upsampled edges (blocks up to 8x8 under the edge filter) keep the sample-by-sample path
+    const bool pv_path = PVOK && !vec_done && !(INTER && final_trip && ii.is_inter) && !use_cfl && !(up_a | up_l);
+    if (pv_path) {
+      if (final_trip) wave_sync();   // (the candidates' reads of the transposed source tile, which the prediction overwrites)
+      sad = pv_run(mode, ang, dx, dy, EA ? EA : S->edge_a + EB + eo, EL ? EL : S->edge_l + EB + eo, final_trip);
+    }
+    if (!vec_done && !pv_path)
 #pragma unroll 4
     for (int p = sl; p < N * N; p += G) {
       const int r = p >> LOG2N, c = p & (N - 1);
@@ -931,10 +973,22 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         sad += iabs(sv - pv);
       }
     }
-    if (final_trip && fe) {
+    if (final_trip && (fe || pv_path)) {
       wave_sync();
+      if constexpr (VEC) {   // eight differences per lane and step (the residual rows of these classes are 16-byte aligned)
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        typedef short s8 __attribute__((ext_vector_type(8)));
+        constexpr int CPR = N / 8;
+#pragma unroll
+        for (int q = sl; q < N * CPR; q += G) {
+          const int r = q / CPR, c8 = q - r * CPR;
+          const u4 sv = *reinterpret_cast<const u4 *>(&S->srcblk[po + r * N + 8 * c8]), pv4 = *reinterpret_cast<const u4 *>(&S->blkpix[po + r * N + 8 * c8]);
+          *reinterpret_cast<u4 *>(&S->scratch[so + r * STR + 8 * c8]) = __builtin_bit_cast(u4, (s8)(__builtin_bit_cast(s8, sv) - __builtin_bit_cast(s8, pv4)));
+        }
+      } else {
 #pragma unroll 4
       for (int p = sl; p < N * N; p += G) S->scratch[so + (p >> LOG2N) * STR + (p & (N - 1))] = (int16_t)((int)S->srcblk[po + p] - (int)S->blkpix[po + p]);
+      }
     }
     if (!final_trip) {
       sad = wave_sum(sad);

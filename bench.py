@@ -7,14 +7,18 @@ Metric (BASELINE.json): encoded frames/s at CQ=30.  Headline workload at N=1 = B
 encode of one chunk per GPU: source frames already resident in HBM -> reconstruction, CDEF,
 entropy coding, bitstream packing on the GPU -> complete OBU bitstream on the host.
 
-At N=1 with default flags the same JSON line carries a `configs` object with the other BASELINE
-configurations a single GPU can run (each with its own fps, roofline and stage times): config 2 with all
-13 intra candidates, config 3 (1080p IPPP, 1 and 4 chunks in flight), config 4's per-GPU unit (4K 10-bit
-IPPP chunk) and the reference's production operating point (av1an.rs:14).
+The headline evaluates all 13 luma intra modes for every block (BASELINE config 2: "DCT/ADST + directional intra pred + CDEF").
 
-Multi-GPU (torchrun, one rank per GPU): scene-chunks are independent, every
-rank encodes its own chunk (seed 1080 + rank), no data-path collective; weak scaling.  The only
-collectives are the timing barrier and the MAX over ranks.
+At N=1 with default flags the same JSON line carries a `configs` object with the other BASELINE
+configurations a single GPU can run (each with its own fps, roofline and stage times): config 2 with the cheapest
+candidate set {DC, V, H}, at 8 bit, with 64x64 blocks and at the quantiser that matches libaom's quality; config 3 (1080p IPPP, 1 and
+4 chunks in flight); config 4's per-GPU unit (4K 10-bit IPPP chunk); config 5's (8K 10-bit HDR chunk with a film-grain table) and the
+reference's production operating point (av1an.rs:14).
+
+Multi-GPU (`--gpus N`: the ranks are started by torchrun / torch.distributed.run, or by this script itself as child processes
+when it is run without a launcher): scene-chunks are independent, every rank encodes its own chunk (seed 1080 + rank),
+no data-path collective; weak scaling.  `--workload cfg4` instead shards BASELINE config 4's job of 8 4K chunks over the ranks with the
+product's placement rule (strong scaling).  The only collectives are the timing barrier and the MAX over ranks.
 
 CPU baseline (reported only; rank 0, N=1): runs BEFORE anything touches the GPU, in SURVEY §8d's order -
 the reference's own av1an / SVT-AV1 if on PATH, else libaom 3.13.2 through the image's libavif (8-bit: this
@@ -177,10 +181,10 @@ def _psnr(sse, n, mx):
 
 def _port_worker(args):
     """the build's own C restatement (oracle/): same algorithm as the GPU path, one process per core"""
-    w, h, bd, bs, seed, t0, cnt, keyint = args
+    w, h, bd, bs, seed, t0, cnt, keyint, mask = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import av1o
-    cfg = av1o.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs)
+    cfg = av1o.default_config(w, h, bd, min_bs_log2=bs, max_bs_log2=bs, mode_mask=mask if mask else 0x7)
     frames = [av1o.synthclip_frame(w, h, bd, seed=seed, t=t0 + i) for i in range(cnt)]
     t = time.perf_counter()
     nbytes, sse, ref, prev = 0, [0, 0, 0], None, None
@@ -265,11 +269,14 @@ def _reference_cli_leg(w, h, cores, keyint, frames):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def cpu_baseline(w, h, bd, bs, keyint, budget_frames_per_core=4):
+def cpu_baseline(w, h, bd, bs, keyint, mask=0x7, budget_frames_per_core=4):
     """Reported-only CPU leg on a bounded sample of the headline workload (must run before the process initialises HIP:
     the worker pool forks).  Order of SURVEY §8d / BASELINE.md §3; the legs that ran besides the chosen one are kept
     under "others"."""
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    # every core this process may run on (north_star: "timed on the box's own host cores, core count stated"); 64 bounds the worker
+    # pool on very wide hosts (the GPU box's process guard), and the line says so when it bites
+    avail = len(os.sched_getaffinity(0))
+    cores = min(avail, 64)
     legs = []
     ref = _reference_cli_leg(w, h, cores, keyint, 16)
     if ref:
@@ -295,7 +302,7 @@ def cpu_baseline(w, h, bd, bs, keyint, budget_frames_per_core=4):
             except Exception as e:   # reported-only: a failing stand-in must not take the benchmark down
                 legs.append({"kind": "libaom", "error": "%s: %s" % (type(e).__name__, e)})
     try:
-        jobs = [(w, h, bd, bs, 1080, c * budget_frames_per_core, budget_frames_per_core, keyint) for c in range(cores)]
+        jobs = [(w, h, bd, bs, 1080, c * budget_frames_per_core, budget_frames_per_core, keyint, mask) for c in range(cores)]
         wall, frames, nbytes, sse = _pool_run(_port_worker, jobs, cores)
         legs.append({"value": round(frames / wall, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                      "encoder": "oracle/: this build's algorithm restated in plain C (bit-identical output to the GPU path), one process per core",
@@ -308,6 +315,7 @@ def cpu_baseline(w, h, bd, bs, keyint, budget_frames_per_core=4):
     if not good:
         return {"value": None, "unit": "frames/s", "cores": cores, "kind": "none", "sample": "no CPU encoder could run", "others": legs}
     best = dict(good[0])
+    best["host"] = {"nproc": os.cpu_count(), "affinity_cores": avail, "cores_used": cores}
     best["others"] = [l for l in legs if l is not good[0]]
     best["vmaf"] = "unavailable offline (no libvmaf)"
     return best
@@ -326,6 +334,12 @@ def workload_string(av1mi, a):
     s += (", deblocking on" if a["deblock"] else "") + (", quantiser matrices 1..15" if a["qm"] else "")
     s += ", loop restoration (Wiener + self-guided) on" if a["sgr"] else (", loop restoration (Wiener) on" if a["lr"] else "")
     s += (", film-grain table %d" % a["film_grain"]) if a["film_grain"] else ""
+    if a.get("hdr"):
+        s += ", colour description BT.2020 / PQ / BT.2020 NCL (HDR10) in the sequence header"
+    if a["width"] > 4096 or a["height"] > 4096:
+        s = s.replace("64x64 tiles", "tiles of 2x2 superblocks")
+    if a.get("job_chunks"):
+        s = s.replace("chunk per GPU", "chunks, a job of %d placed on the GPUs by av1mi_chunk_owner" % a["job_chunks"])
     if a["chunks_per_gpu"] > 1:
         s += ", %d chunks in flight per GPU on their own contexts" % a["chunks_per_gpu"]
     return s
@@ -359,15 +373,16 @@ def algorithmic_bytes(a, rep):
 def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, barrier, max_over_ranks):
     """`steps` timed steps of workload `a` on this rank; returns (elapsed seconds (max over ranks), stage ms per step, last report)"""
     w, h, bd, n = a["width"], a["height"], a["bit_depth"], a["frames"]
-    # a job of `world` scene-chunks, one per GPU: this rank's chunk by the product's own placement rule (av1mi_chunk_owner)
-    mine = av1mi.chunks_of_rank(world, world, rank)
-    assert len(mine) == 1, mine
-    if os.environ.get("AV1MI_BENCH_CLIP_ON_CPU"):
-        # counter-collection runs (rocprofv3 --pmc): torch's own GPU kernels crash under the profiler's counter service on this
-        # image, so the same generator runs on the CPU device and the clip is copied over - no kernel but the library's is launched
-        d_frames = make_clip_torch(w, h, bd, n, a["seed"] + mine[0], "cpu").to(dev)
-    else:
-        d_frames = make_clip_torch(w, h, bd, n, a["seed"] + mine[0], dev)   # HBM-resident input
+    # the job's scene-chunks over the ranks by the product's own placement rule (av1mi_chunk_owner): by default a job of `world` chunks, one
+    # per GPU (weak scaling); job_chunks = J: a job of J chunks whatever the number of GPUs (strong scaling; BASELINE config 4: J = 8)
+    job = int(a.get("job_chunks", 0))
+    mine = av1mi.chunks_of_rank(job if job else world, world, rank)
+    assert job or len(mine) == 1, mine
+    # counter-collection runs (rocprofv3 --pmc, AV1MI_BENCH_CLIP_ON_CPU): torch's own GPU kernels crash under the profiler's counter service
+    # on this image, so the same generator runs on the CPU device and the clip is copied over - no kernel but the library's is launched
+    gen_dev = "cpu" if os.environ.get("AV1MI_BENCH_CLIP_ON_CPU") else dev
+    clips = [make_clip_torch(w, h, bd, n, a["seed"] + c, gen_dev).to(dev) for c in mine]   # HBM-resident input
+    d_frames = clips[0] if clips else None
     torch.cuda.synchronize(dev)
     params = av1mi.default_params(w, h, bd, block_log2=a["block_log2"], cdf_update=0 if a["static_cdf"] else 1, keyint=a["keyint"],
                                   me_range=a["me_range"], cq_level=a["cq"], film_grain=a["film_grain"],
@@ -376,13 +391,36 @@ def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, b
     if a["qm"]:
         params.enable_qm, params.qm_min, params.qm_max = 1, 1, 15
     params.intra_mode_mask = a["mode_mask"]
+    if a.get("hdr"):
+        params.color_primaries, params.transfer_characteristics, params.matrix_coefficients = 9, 16, 9
     C_ = max(1, a["chunks_per_gpu"])
     ctxs = [av1mi.Context(local_rank) for _ in range(C_)]
 
+    def merge(res):
+        rep = max(res, key=lambda r: r.ms_total)   # stage times of the slowest part
+        rep.n_symbols = sum(r.n_symbols for r in res)
+        rep.max_tile_symbols = max(r.max_tile_symbols for r in res)
+        rep.bytes = sum(r.bytes for r in res)
+        return rep
+
     def step():
+        import threading
+        if job:   # this rank's chunks of the job, C_ of them in flight
+            if not clips:
+                return None
+            res = [None] * len(clips)
+
+            def work_job(i):
+                for k in range(i, len(clips), C_):
+                    res[k] = ctxs[i].encode_chunk(params, clips[k].data_ptr(), n, on_device=True, copy_out=False)[2]
+            th = [threading.Thread(target=work_job, args=(i,)) for i in range(min(C_, len(clips)))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            return merge(res)
         if C_ == 1:
             return ctxs[0].encode_chunk(params, d_frames.data_ptr(), n, on_device=True, copy_out=False)[2]
-        import threading
         res = [None] * C_
 
         def work(i):   # every context encodes the whole chunk (its own copy of the work)
@@ -392,11 +430,7 @@ def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, b
             t.start()
         for t in th:
             t.join()
-        rep = max(res, key=lambda r: r.ms_total)   # stage times of the slowest part
-        rep.n_symbols = sum(r.n_symbols for r in res)
-        rep.max_tile_symbols = max(r.max_tile_symbols for r in res)
-        rep.bytes = sum(r.bytes for r in res)
-        return rep
+        return merge(res)
     try:
         for _ in range(warmup):
             step()
@@ -406,6 +440,8 @@ def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, b
         rep = None
         for _ in range(steps):
             rep = step()
+            if rep is None:   # a rank without a chunk of the job (more GPUs than chunks)
+                continue
             stage["recon"] += rep.ms_recon; stage["cdef"] += rep.ms_cdef; stage["entropy"] += rep.ms_entropy
             stage["pack"] += rep.ms_pack; stage["d2h"] += rep.ms_d2h; stage["symbolize"] += rep.ms_symbolize
         barrier()
@@ -413,7 +449,7 @@ def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, b
     finally:
         for c_ in ctxs:
             c_.close()
-        del d_frames
+        del d_frames, clips
     for s in stage:
         stage[s] /= steps
     stage["rangecode"] = stage["entropy"] - stage["symbolize"]
@@ -422,32 +458,42 @@ def run_workload(av1mi, torch, a, dev, local_rank, rank, world, steps, warmup, b
 
 def result_of(av1mi, a, world, steps, elapsed, stage, rep, traffic_db):
     C_, n = max(1, a["chunks_per_gpu"]), a["frames"]
+    job = int(a.get("job_chunks", 0))
     alg, step_bytes = algorithmic_bytes(a, rep)
-    if C_ > 1:   # C_ copies of the work per step; the stage times are those of the slowest copy
-        step_bytes *= C_
+    # frames and algorithmic bytes of one step over ALL ranks: a job of J chunks, or one chunk (x C_ copies in flight) per rank
+    frames_per_step = job * n if job else world * C_ * n
+    step_bytes_all = step_bytes * (job if job else world * C_)
     dom = max(alg, key=lambda s: stage[s])
     achieved = alg[dom] / (stage[dom] * 1e-3) / 1e9
     peak = 8000.0
-    step_gbs = step_bytes * world / (elapsed / steps) / 1e9 / world   # per GPU
-    traffic = traffic_raw = None
+    step_gbs = step_bytes_all / (elapsed / steps) / 1e9 / world   # per GPU
+    traffic = traffic_raw = valu_busy = None
     ent = (traffic_db or {}).get(a["name"], {}).get(dom)
     if ent:
         # separate FETCH_SIZE / WRITE_SIZE passes of this same workload (profiles/); gfx950 correction: FETCH_SIZE counts 64 B per
         # 128-B request, so the fetch side is doubled (an upper estimate for narrow loads)
         traffic_raw = (ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024
         traffic = (2 * ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024
+        if ent.get("SQ_INSTS_VALU"):
+            # what actually bounds the kernel: its vector-instruction issue.  SQ_INSTS_VALU wave-instructions (the committed SQ pass of this
+            # workload) x 4 cycles each on one of 1024 SIMDs, over the kernel's LIVE duration at the 2.4 GHz peak clock (the clock under load is
+            # lower, so this is a lower estimate of the busy fraction)
+            valu_busy = round(ent["SQ_INSTS_VALU"] * 4.0 / (1024 * stage[dom] * 1e-3 * 2.4e9), 4)
     return {
         "workload": workload_string(av1mi, a),
-        "fps": round(world * C_ * n * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
-        "frames_per_step": world * C_ * n,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+        "fps": round(frames_per_step * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+        "frames_per_step": frames_per_step,
+        # `frac` is the contract's figure: the dominant kernel's algorithmic bytes per launch over its duration against the HBM peak.  The
+        # kernel is not HBM bound: `bound` names what is (vector-instruction issue, `valu_busy` of the SIMDs' issue slots)
+        "roofline": {"bound": "valu" if valu_busy is not None and valu_busy > 0.5 else "hbm", "valu_busy": valu_busy, "kernel": dom,
+                     "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
                      "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage[dom], 3),
-                     "step_algorithmic_bytes": step_bytes, "step_achieved": round(step_gbs, 2), "step_frac": round(step_gbs / peak, 5)},
+                     "step_algorithmic_bytes": step_bytes_all, "step_achieved": round(step_gbs, 2), "step_frac": round(step_gbs / peak, 5)},
         "stage_ms": {s: round(v, 3) for s, v in stage.items()},
-        "bytes_per_frame": round(int(rep.bytes) / (C_ * n), 1),
+        "bytes_per_frame": round(int(rep.bytes) / ((len(av1mi.chunks_of_rank(job, world, 0)) if job else C_) * n), 1),
         "psnr_db": [round(rep.psnr[i], 2) for i in range(3)],
-        "symbols_per_frame": int(rep.n_symbols // (C_ * n)), "max_tile_symbols": int(rep.max_tile_symbols),
+        "symbols_per_frame": int(rep.n_symbols // ((len(av1mi.chunks_of_rank(job, world, 0)) if job else C_) * n)), "max_tile_symbols": int(rep.max_tile_symbols),
     }
 
 
@@ -499,18 +545,28 @@ def extra_configs(base):
         d.update(kw)
         d["name"] = name
         return d
-    prod = dict(keyint=240, cq=8, qm=True, film_grain=20, subpel=True, deblock=True, sgr=True)
+    # the inter configurations keep the library's default intra candidate set {DC, V, H} for the intra / inter decision of their P-frame
+    # blocks (a workload string says which set ran)
+    prod = dict(keyint=240, cq=8, qm=True, film_grain=20, subpel=True, deblock=True, sgr=True, mode_mask=0x7)
     # one-chunk configurations first, the ones with four chunks in flight last: a context created after many others' streams exist
     # can get hardware queues that serialise its chain behind its own search stream - latency figures are taken on
     # the first contexts of the process
     return [
-        mk("cfg2_1080p_intra_all13", mode_mask=0x1FFF),
+        mk("cfg2_1080p_intra_dcvh", mode_mask=0x7),   # the encoder's cheapest candidate set (rounds 1-2's headline)
+        mk("cfg2_1080p_intra_8bit", bit_depth=8),     # SURVEY 8d config 2 "run at 8-bit (dav1d-checkable) and 10-bit"
         mk("cfg2_1080p_intra_64x64", block_log2=6),
-        mk("cfg3_1080p_ippp", keyint=240),
-        mk("cfg4_4k_ippp_chunk", width=3840, height=2160, frames=30, keyint=240, seed=2160),
+        mk("cfg3_1080p_ippp", keyint=240, mode_mask=0x7),
+        mk("cfg3_1080p_ippp_all13", keyint=240),
+        mk("cfg4_4k_ippp_chunk", width=3840, height=2160, frames=30, keyint=240, seed=2160, mode_mask=0x7),
+        # BASELINE config 5's per-GPU unit: one 8K 10-bit HDR scene-chunk of 16 frames, film-grain table in every frame header, tiles of 2x2
+        # superblocks (AV1 allows at most 64 x 64 tiles)
+        mk("cfg5_8k_ippp_chunk", width=7680, height=4320, frames=16, keyint=240, seed=4320, film_grain=20, hdr=True, mode_mask=0x7),
+        # iso-quality point against libaom (tools/rd_vs_libaom.py): libaom cq-level 30 reaches 36.0 dB PSNR-Y on this clip at 8 bit; this
+        # encoder reaches it at CQ 19 (base_q_idx 76)
+        mk("cfg2_1080p_intra_8bit_cq19_isoquality", bit_depth=8, cq=19),
         mk("production_1080p", **prod),
         mk("cfg2_1080p_intra_x4", chunks_per_gpu=4),   # the product's default: AV1MI_DEFAULT_WORKERS_PER_GPU chunks in flight per GPU
-        mk("cfg3_1080p_ippp_x4", keyint=240, chunks_per_gpu=4),
+        mk("cfg3_1080p_ippp_x4", keyint=240, chunks_per_gpu=4, mode_mask=0x7),
         mk("production_1080p_x4", chunks_per_gpu=4, **prod),
     ]
 
@@ -539,10 +595,30 @@ def main():
     ap.add_argument("--block-log2", type=int, default=5)
     ap.add_argument("--static-cdf", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode-mask", type=lambda s: int(s, 0), default=0, help="intra mode candidate mask (0 = default {DC, V, H}; 0x1FFF = all 13)")
+    ap.add_argument("--mode-mask", type=lambda s: int(s, 0), default=0x1FFF,
+                    help="intra mode candidate mask.  Default 0x1FFF: all 13 luma intra modes - BASELINE config 2 names \"directional intra pred\", so the "
+                         "headline evaluates the directional, smooth and Paeth predictors for every block; 0x7 = {DC, V, H}, the library's own default")
     ap.add_argument("--configs", choices=["auto", "all", "none"], default="auto",
                     help="the `configs` object with the other BASELINE configurations: auto = at N=1 when the workload flags are the defaults")
+    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2",
+                    help="cfg2 (default, the driver's line): every rank encodes its own 1080p chunk (weak scaling).  cfg4: BASELINE config 4 as "
+                         "worded - a job of 8 scene-chunks of 4K 10-bit x 30 frames (IPPP), placed on the ranks by av1mi_chunk_owner (strong scaling)")
     args = ap.parse_args()
+
+    # `--gpus N` without a launcher: start the N ranks ourselves, as children, BEFORE anything in this process touches the GPU (a process
+    # that has initialised HIP must not be replaced or forked on this pool), and leave with their exit code.  Under torchrun /
+    # torch.distributed.run (the driver's way) WORLD_SIZE is set and this is one of the ranks.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -551,7 +627,9 @@ def main():
                 cq=args.cq, film_grain=args.film_grain, sgr=args.sgr, subpel=args.subpel, qm=args.qm, deblock=args.deblock, lr=args.lr,
                 chunks_per_gpu=args.chunks_per_gpu, bit_depth=args.bit_depth, block_log2=args.block_log2, static_cdf=args.static_cdf,
                 mode_mask=args.mode_mask, seed=1080)
-    default_flags = all(getattr(args, k) == ap.get_default(k) for k in (
+    if args.workload == "cfg4":   # BASELINE config 4: "4K30 10-bit, 8 scene-chunks sharded across 8xMI355X (one chunk/GPU, independent HIP streams)"
+        base.update(name="cfg4_4k_job8", width=3840, height=2160, frames=30, keyint=240, seed=2160, bit_depth=10, job_chunks=8, mode_mask=0x7)
+    default_flags = args.workload == "cfg2" and all(getattr(args, k) == ap.get_default(k) for k in (
         "width", "height", "frames", "keyint", "me_range", "cq", "film_grain", "sgr", "subpel", "qm", "deblock", "lr", "chunks_per_gpu",
         "bit_depth", "block_log2", "static_cdf", "mode_mask"))
     if not default_flags:
@@ -561,7 +639,7 @@ def main():
     # ---- CPU leg first: its worker pool forks, which must happen before this process (or torch) initialises HIP
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(base["width"], base["height"], base["bit_depth"], base["block_log2"], base["keyint"])
+        cpu = cpu_baseline(base["width"], base["height"], base["bit_depth"], base["block_log2"], base["keyint"], base["mode_mask"])
 
     import torch
     dist = None
@@ -612,7 +690,7 @@ def main():
             except Exception as e:   # a secondary configuration must not take the headline down; it is reported as failed
                 configs[a["name"]] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1:
-            for name, kw in (("cfg2_e2e_y4m_to_mkv", dict()), ("cfg3_e2e_y4m_to_mkv_ippp", dict(keyint=240))):
+            for name, kw in (("cfg2_e2e_y4m_to_mkv", dict()), ("cfg3_e2e_y4m_to_mkv_ippp", dict(keyint=240, mode_mask=0x7))):
                 try:
                     d = dict(base)
                     d.update(kw)
@@ -624,9 +702,10 @@ def main():
         out = {
             "metric": metric_label(base), "value": head["fps"], "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if base.get("job_chunks") else "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": head["workload"], "frames_per_chunk": base["frames"], "chunks_per_gpu": max(1, base["chunks_per_gpu"]),
-                       "parallelism": "chunk-per-gpu x%d" % world},
+                       "parallelism": ("job of %d chunks over %d GPUs (av1mi_chunk_owner)" % (base["job_chunks"], world)) if base.get("job_chunks")
+                       else "chunk-per-gpu x%d" % world},
             "roofline": head["roofline"], "stage_ms": head["stage_ms"], "bytes_per_frame": head["bytes_per_frame"], "psnr_db": head["psnr_db"],
             "symbols_per_frame": head["symbols_per_frame"], "max_tile_symbols": head["max_tile_symbols"],
         }

@@ -1,0 +1,87 @@
+"""The product's piece-wise intra predictors (av1-base_amd/csrc/intra_pieces.h: what recon_kernel.hip runs for every intra candidate
+and for the final prediction) compiled for the host and checked, without a GPU, against the oracle's predictor (oracle/av1o_pred.c, the
+restatement of AV1 spec 7.11.2 that dav1d pins through tests/golden/): every mode, every angle delta, block sizes 8 / 16 / 32, 8 and 10 bit,
+a whole wave per block (luma) and half a wave (one plane of a chroma pair) - the prediction itself and the SAD against a source block."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host", "intra_pieces_host.cpp")
+MODE_ANGLE = {1: 90, 2: 180, 3: 45, 4: 135, 5: 113, 6: 157, 7: 203, 8: 67}
+SM_WEIGHTS = {8: [255, 197, 146, 105, 73, 50, 37, 32], 16: [255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16],
+              32: [255, 240, 225, 210, 196, 182, 169, 157, 145, 133, 122, 111, 101, 92, 83, 74, 66, 59, 52, 45, 39, 34, 29, 25, 21, 17, 14, 12, 10, 9, 8, 8]}
+
+
+@pytest.fixture(scope="module")
+def pieces(tmp_path_factory):
+    cxx = next((c for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++") or "") if c and os.path.exists(c)), None)
+    if not cxx:
+        pytest.skip("no clang++ (the header uses ext_vector_type)")
+    so = str(tmp_path_factory.mktemp("pieces") / "libpieces.so")
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", so])
+    lib = C.CDLL(so)
+    lib.pieces_run.restype = C.c_long
+    lib.pieces_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.pieces_magic.restype = C.c_uint
+    return lib
+
+
+def test_division_magic_is_exact(pieces):
+    """(64 k * magic) >> 22 == floor(64 k / Dr_Intra_Derivative) for every angle and k = 1 .. 32, without leaving 32 bits"""
+    n = 0
+    for ang in range(91):
+        d = pieces.pieces_deriv(ang)
+        if not d:
+            assert pieces.pieces_magic(ang) == 0
+            continue
+        m = pieces.pieces_magic(ang)
+        for k in range(1, 33):
+            assert 64 * k * m < 1 << 32 and (64 * k * m) >> 22 == (64 * k) // d
+        n += 1
+    assert n == 27
+
+
+@pytest.mark.parametrize("n,lanes,bd", [(8, 64, 8), (8, 32, 10), (16, 64, 10), (16, 32, 8), (32, 64, 10), (32, 64, 8)])
+def test_pieces_equal_the_oracle_predictor(pieces, oracle, n, lanes, bd):
+    L = oracle.lib()
+    rng = np.random.default_rng(n * 100 + lanes + bd)
+    log2n = {8: 3, 16: 4, 32: 5}[n]
+    maxv = (1 << bd) - 1
+    smw = np.zeros(64, np.uint8)
+    smw[:n] = SM_WEIGHTS[n]
+    checked = 0
+    for trial in range(12):
+        # edges: element -1 (corner) .. 2 n - 1, smooth or noisy; padded as the kernel pads them (3 n + 8, last element repeated)
+        def edge():
+            if trial % 3 == 0:
+                e = rng.integers(0, maxv + 1, 2 * n + 1)
+            else:
+                e = np.clip(int(rng.integers(0, maxv + 1)) + np.cumsum(rng.integers(-6, 7, 2 * n + 1)), 0, maxv)
+            return e.astype(np.uint16)
+        ea, el = edge(), edge()
+        el[0] = ea[0]
+        buf_a, buf_l = np.zeros(8 + 3 * n + 9, np.uint16), np.zeros(8 + 3 * n + 9, np.uint16)
+        for buf, e in ((buf_a, ea), (buf_l, el)):
+            buf[:7] = 0xAAAA                      # elements -8 .. -2: never part of a valid sample
+            buf[7:8 + 2 * n] = e
+            buf[8 + 2 * n:] = e[-1]
+        src = rng.integers(0, maxv + 1, (n, n)).astype(np.uint16)
+        for mode in range(13):
+            for delta in (range(-3, 4) if 1 <= mode <= 8 else (0,)):
+                ang = MODE_ANGLE.get(mode, 0) + 3 * delta
+                want = np.zeros((n, n), np.uint16)
+                L.av1o_predict_intra(want.ctypes.data, n, log2n, mode, delta, ea.ctypes.data, el.ctypes.data, 1, 1, bd)
+                dcv = int(want[0, 0]) if mode == 0 else 0
+                got = np.zeros((n, n), np.uint16)
+                pa, pl = buf_a.ctypes.data + 16, buf_l.ctypes.data + 16   # element 0
+                assert pieces.pieces_run(n, lanes, mode, ang, dcv, pa, pl, smw.ctypes.data, src.ctypes.data, got.ctypes.data, 1) == 0
+                assert (got == want).all(), (mode, ang, np.argwhere(got != want)[:4])
+                sad = pieces.pieces_run(n, lanes, mode, ang, dcv, pa, pl, smw.ctypes.data, src.ctypes.data, None, 0)
+                assert sad == int(np.abs(src.astype(np.int64) - want.astype(np.int64)).sum()), (mode, ang)
+                checked += 1
+    assert checked == 12 * (8 * 7 + 5)
