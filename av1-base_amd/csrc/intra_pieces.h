@@ -59,13 +59,12 @@ AV1MI_PIECE_FN uint32_t sad2(uint32_t a, uint32_t b, uint32_t acc) {
 #endif
 }
 
-// E[st .. st + 8]: eight packed samples X and the same shifted by one element, Y
+// E[st .. st + 8]: eight packed samples X and the same shifted by one element, Y.  Two 16-byte loads at 2-byte alignment: gfx950 runs with
+// unaligned LDS access enabled and the compiler keeps each one ds_read_b128 (nine 2-byte loads and eight packing instructions before)
+typedef pu4 pu4_any __attribute__((aligned(2)));
 AV1MI_PIECE_FN void load_xy(const uint16_t *E, int st, pu4 &X, pu4 &Y) {
-  uint32_t e[9];
-#pragma unroll
-  for (int j = 0; j < 9; j++) e[j] = E[st + j];
-  X = (pu4){ e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16) };
-  Y = (pu4){ e[1] | (e[2] << 16), e[3] | (e[4] << 16), e[5] | (e[6] << 16), e[7] | (e[8] << 16) };
+  X = *reinterpret_cast<const pu4_any *>(&E[st]);
+  Y = *reinterpret_cast<const pu4_any *>(&E[st + 1]);
 }
 
 // 0xFFFF in every halfword j < kinv of a piece (the samples that take the other form)

@@ -44,6 +44,8 @@
 static __device__ __forceinline__ int32_t av1_half_btf(int32_t w0, int32_t a, int32_t w1, int32_t b) {
   return (__mul24(w0, a) + __mul24(w1, b) + 2048) >> 12;
 }
+#define AV1_HALF_BTF1_DEFINED
+static __device__ __forceinline__ int32_t av1_half_btf1(int32_t w, int32_t a) { return (__mul24(w, a) + 2048) >> 12; }
 #include "txfm_gen.h"
 #include "fdct32_matrix.h"
 #include "intra_pieces.h"
@@ -209,6 +211,11 @@ __device__ __forceinline__ int half_max(int v, int lane) {
   const int lo = __builtin_amdgcn_readlane(x, 31), hi = __builtin_amdgcn_readlane(x, 63);
   return lane < 32 ? lo : hi;
 }
+// componentwise maximum of two packed pairs of unsigned 16-bit values (v_pk_max_u16)
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  typedef unsigned short pm2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pm2, a), __builtin_bit_cast(pm2, b)));
+}
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int rshift_round(int v, int s) { return s ? (v + (1 << (s - 1))) >> s : v; }
 __device__ __forceinline__ int clamp_bits(int v, int bits) {
@@ -224,7 +231,9 @@ __device__ __forceinline__ void ident1d(int32_t *x) {
   for (int i = 0; i < (1 << LOG2N); i++) x[i] = LOG2N == 2 ? (x[i] * 5793 + 2048) >> 12 : (LOG2N == 3 ? x[i] * 2 : (x[i] * 11586 + 2048) >> 12);
 }
 template <int LOG2N> struct Tx1d;
+template <int V> struct NzTag { static constexpr int value = V; };
 template <> struct Tx1d<2> {
+  template <int NZ> static __device__ __forceinline__ void inv_nz(int32_t *x, int t) { inv(x, t); }
   static __device__ __forceinline__ void iadst(int32_t *x) {
     // spec §7.13.2.6 inverse ADST4 (sinpi 1321 2482 3344 3803)
     int x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
@@ -244,22 +253,38 @@ template <> struct Tx1d<2> {
   static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t == 3) ident1d<2>(x); else if (t) fadst(x); else av1_fdct4(x); }
   static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t == 3) ident1d<2>(x); else if (t) iadst(x); else av1_idct4(x); }
 };
+// inv_nz<NZ>: the inverse transform of a vector whose elements NZ .. are zero (the caller has made them so) - the pruned networks of
+// txfm_gen.h where one exists for the size, else the full one.  Most blocks' coefficients lie in a small low-frequency corner.
 template <> struct Tx1d<3> {
   static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t == 3) ident1d<3>(x); else if (t) av1_fadst8(x); else av1_fdct8(x); }
   static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t == 3) ident1d<3>(x); else if (t) av1_iadst8(x); else av1_idct8(x); }
+  template <int NZ> static __device__ __forceinline__ void inv_nz(int32_t *x, int t) {
+    if constexpr (NZ == 4) { if (t == 3) ident1d<3>(x); else if (t) av1_iadst8_nz4(x); else av1_idct8_nz4(x); } else inv(x, t);
+  }
 };
 template <> struct Tx1d<4> {
   static __device__ __forceinline__ void fwd(int32_t *x, int t) { if (t == 3) ident1d<4>(x); else if (t) av1_fadst16(x); else av1_fdct16(x); }
   static __device__ __forceinline__ void inv(int32_t *x, int t) { if (t == 3) ident1d<4>(x); else if (t) av1_iadst16(x); else av1_idct16(x); }
+  template <int NZ> static __device__ __forceinline__ void inv_nz(int32_t *x, int t) {
+    if constexpr (NZ == 4) { if (t == 3) ident1d<4>(x); else if (t) av1_iadst16_nz4(x); else av1_idct16_nz4(x); }
+    else if constexpr (NZ == 8) { if (t == 3) ident1d<4>(x); else if (t) av1_iadst16_nz8(x); else av1_idct16_nz8(x); }
+    else inv(x, t);
+  }
 };
 template <> struct Tx1d<5> {
   static __device__ __forceinline__ void fwd(int32_t *x, int) { av1_fdct32(x); }
   static __device__ __forceinline__ void inv(int32_t *x, int) { av1_idct32(x); }
+  template <int NZ> static __device__ __forceinline__ void inv_nz(int32_t *x, int) {
+    if constexpr (NZ == 4) av1_idct32_nz4(x); else if constexpr (NZ == 8) av1_idct32_nz8(x); else if constexpr (NZ == 16) av1_idct32_nz16(x); else av1_idct32(x);
+  }
 };
 #if AV1MI_RECON_BIG
 template <> struct Tx1d<6> {
   static __device__ __forceinline__ void fwd(int32_t *x, int) { av1_fdct64(x); }
   static __device__ __forceinline__ void inv(int32_t *x, int) { av1_idct64(x); }
+  template <int NZ> static __device__ __forceinline__ void inv_nz(int32_t *x, int) {
+    if constexpr (NZ == 8) av1_idct64_nz8(x); else if constexpr (NZ == 16) av1_idct64_nz16(x); else av1_idct64(x);
+  }
 };
 #endif
 
@@ -1020,6 +1045,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   int32_t x[N];
   const bool tx_lane = sl < N, row_lane = sl < CW;
   int my_key = -1;  // (anti-diagonal << 6 | position inside it) of the last nonzero level in scan order
+  uint32_t my_ext = 0;   // {last nonzero row + 1, last nonzero column + 1} of this lane's levels as packed 16-bit values (0: none)
   int16_t *lvl = reinterpret_cast<int16_t *>(S->srcblk) + po;  // source block is dead: reuse for the levels
   if constexpr (MM) {
     // ---- forward 32x32 DCT as Y = Cm * X * Cm^T on the matrix cores (v_mfma_i32_32x32x32_i8; tools/mfma_fwd32_ab.hip is the
@@ -1087,6 +1113,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         if (lv) {
           const int key = (d0 << 6) | ((d0 & 1) ? row : col);
           my_key = key > my_key ? key : my_key;
+          my_ext = ((uint32_t)(row + 1) << 16) | (uint32_t)(col + 1);   // (rows grow with reg)
         }
       }
     }
@@ -1142,7 +1169,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
           }
           x[j] = d;
         }
-        if (lastj >= 0) { const int d0 = row + lastj; my_key = (d0 << 6) | ((d0 & 1) ? row : lastj); }
+        if (lastj >= 0) { const int d0 = row + lastj; my_key = (d0 << 6) | ((d0 & 1) ? row : lastj); my_ext = ((uint32_t)(row + 1) << 16) | (uint32_t)(lastj + 1); }
       } else {
       constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
       const Av1miQmEntry *tab = P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row;
@@ -1167,6 +1194,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
           // scan order: by anti-diagonal, odd ones by increasing row, even ones by increasing column
           const int key = (d0 << 6) | ((d0 & 1) ? row : j);
           my_key = key > my_key ? key : my_key;
+          my_ext = ((uint32_t)(row + 1) << 16) | (uint32_t)(j + 1);   // (columns grow with j)
           d = (int)(((uint32_t)lv * q) & 0xFFFFFF) >> TSH;
           const int lim = 1 << (7 + bd);
           d = v < 0 ? -d : d;
@@ -1185,13 +1213,34 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     const int d0 = my_key >> 6, w = my_key & 63;
     eob = scan_index((d0 & 1) ? w : d0 - w, (d0 & 1) ? d0 - w : w, CW) + 1;
   }
-  if constexpr (MM) {
-    if (row_lane && eob) {   // the row's levels back from LDS, through the normative dequantiser (spec 7.12.3)
+  // ---- the block's nonzero extent: rows / columns beyond it hold no level, so the inverse passes run the networks pruned for that many
+  // inputs (txfm_gen.h: a rotation with a zero input is one multiply, sums with a zero are copies) and, in the matrix-core path, only
+  // that many levels of a row are dequantised - most blocks' levels lie in a small low-frequency corner.  One class for the whole wave
+  // (both planes of a chroma pair): ext = {columns, rows} as packed 16-bit maxima.
+  int nzc, nzr;
+  {
+    uint32_t ext = my_ext;
+    ext = pk_max(ext, (uint32_t)__builtin_amdgcn_update_dpp((int)ext, (int)ext, 0x111, 0xF, 0xF, false));
+    ext = pk_max(ext, (uint32_t)__builtin_amdgcn_update_dpp((int)ext, (int)ext, 0x112, 0xF, 0xF, false));
+    ext = pk_max(ext, (uint32_t)__builtin_amdgcn_update_dpp((int)ext, (int)ext, 0x114, 0xF, 0xF, false));
+    ext = pk_max(ext, (uint32_t)__builtin_amdgcn_update_dpp((int)ext, (int)ext, 0x118, 0xF, 0xF, false));
+    ext = pk_max(ext, (uint32_t)__builtin_amdgcn_update_dpp((int)ext, (int)ext, 0x142, 0xA, 0xF, false));
+    ext = pk_max(ext, (uint32_t)__builtin_amdgcn_update_dpp((int)ext, (int)ext, 0x143, 0xC, 0xF, false));
+    ext = (uint32_t)__builtin_amdgcn_readlane((int)ext, 63);
+    const int ec = (int)(ext & 0xFFFF), er = (int)(ext >> 16);
+    // the classes this size has pruned networks for (64 = the full network)
+    auto cls = [](int v) { return LOG2N >= 5 ? (v <= 8 ? 8 : (v <= 16 ? 16 : 64)) : (LOG2N == 4 ? (v <= 4 ? 4 : (v <= 8 ? 8 : 64)) : (LOG2N == 3 && v <= 4 ? 4 : 64)); };
+    nzc = cls(ec); nzr = cls(er);
+  }
+  // row pass of one class: [matrix-core path: the row's levels back from LDS through the normative dequantiser (spec 7.12.3),] inverse rows
+  auto row_pass = [&](auto tag) {
+    constexpr int NZT = decltype(tag)::value, NZ = NZT < CW ? NZT : CW;
+    if constexpr (MM) {
       const int row = sl, lim = 1 << (7 + bd);
       const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + AV1MI_QM_32X32 + row : nullptr;
       const uint32_t *lw = reinterpret_cast<const uint32_t *>(lvl + row * 32);
 #pragma unroll
-      for (int j2 = 0; j2 < 16; j2++) {
+      for (int j2 = 0; j2 < NZ / 2; j2++) {
         const uint32_t w = lw[j2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -1207,24 +1256,37 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         }
       }
     }
-  }
-  if (row_lane && eob) {
-    Tx1d<LOG2N>::inv(x, ht);
+#pragma unroll
+    for (int j = NZ; j < N; j++) x[j] = 0;
+    Tx1d<LOG2N>::template inv_nz<NZ>(x, ht);
 #pragma unroll
     for (int j = 0; j < N; j++) S->scratch[so + sl * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
+  };
+  if (row_lane && eob && sl < nzr) {   // (rows beyond the extent are all zero: the column pass does not read them)
+    if (LOG2N >= 4 && nzc == 8) row_pass(NzTag<8>{});
+    else if (LOG2N >= 5 && nzc == 16) row_pass(NzTag<16>{});
+    else if ((LOG2N == 3 || LOG2N == 4) && nzc == 4) row_pass(NzTag<4>{});
+    else row_pass(NzTag<64>{});
   }
   wave_sync();
   STAMP(4);   // forward rows, quantiser, dequantiser, eob, inverse rows
-  if (tx_lane && eob) {
+  auto col_pass = [&](auto tag) {
+    constexpr int NZT = decltype(tag)::value, NZ = NZT < CW ? NZT : CW;
     const int maxv = (1 << bd) - 1;
 #pragma unroll
-    for (int i = 0; i < N; i++) x[i] = i < CW ? (int)S->scratch[so + i * ST + sl] : 0;
-    Tx1d<LOG2N>::inv(x, vt);
+    for (int i = 0; i < N; i++) x[i] = i < NZ ? (int)S->scratch[so + i * ST + sl] : 0;
+    Tx1d<LOG2N>::template inv_nz<NZ>(x, vt);
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int v = S->blkpix[po + i * N + sl] + ((x[i] + 8) >> 4);
       S->blkpix[po + i * N + sl] = (uint16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
     }
+  };
+  if (tx_lane && eob) {
+    if (LOG2N >= 4 && nzr == 8) col_pass(NzTag<8>{});
+    else if (LOG2N >= 5 && nzr == 16) col_pass(NzTag<16>{});
+    else if ((LOG2N == 3 || LOG2N == 4) && nzr == 4) col_pass(NzTag<4>{});
+    else col_pass(NzTag<64>{});
   }
   if (eob) {  // levels out (32-bit words, coalesced inside the group)
     // (16 bytes = 8 levels per store: the block's area of the level buffer is 32-byte aligned, av1mi_levels_off)

@@ -320,6 +320,118 @@ def emit_straightline(name, stages, lines):
     lines.append("")
 
 
+def emit_pruned(name, stages, nz, lines):
+    """The same network with x[nz ..] known to be zero (the inverse transform of a block whose coefficients beyond row / column nz are
+    all zero: most blocks): zeros are propagated symbolically - a rotation with one zero input is ONE multiply (Round2(w * a, 12), exactly
+    what the full form computes), with two it is zero; sums with a zero are copies.  Reads x[0 .. nz), writes all n outputs."""
+    n = len(stages[0])
+    lines.append("AV1_TXFM_FN void %s_nz%d(int32_t *x) {" % (name, nz))
+    cur = [("x[%d]" % i) if i < nz else None for i in range(n)]   # None = zero
+    tmp_id = 0
+    for si, st in enumerate(stages):
+        nxt = [None] * n
+        decl = []
+        for dst, op in enumerate(st):
+            if op[0] == 'cp':
+                nxt[dst] = cur[op[1]]
+                continue
+            if op[0] == 'neg':
+                if cur[op[1]] is None:
+                    continue
+                e = "-%s" % cur[op[1]]
+            elif op[0] == 'add':
+                a, b = cur[op[1]], cur[op[2]]
+                if a is None and b is None:
+                    continue
+                if b is None:
+                    if op[3] == 1:
+                        nxt[dst] = a
+                        continue
+                    e = "-%s" % a
+                elif a is None:
+                    if op[4] == 1:
+                        nxt[dst] = b
+                        continue
+                    e = "-%s" % b
+                else:
+                    e = "%s%s %s %s" % ("" if op[3] == 1 else "-", a, "+" if op[4] == 1 else "-", b)
+            else:
+                a, b = cur[op[1]], cur[op[2]]
+                if a is None and b is None:
+                    continue
+                if b is None:
+                    e = "av1_half_btf1(%d, %s)" % (op[3], a)
+                elif a is None:
+                    e = "av1_half_btf1(%d, %s)" % (op[4], b)
+                else:
+                    e = "av1_half_btf(%d, %s, %d, %s)" % (op[3], a, op[4], b)
+            v = "t%d" % tmp_id
+            tmp_id += 1
+            decl.append("const int32_t %s = %s;" % (v, e))
+            nxt[dst] = v
+        if decl:
+            lines.append("  /* stage %d */" % (si + 1))
+            for d_ in decl:
+                lines.append("  " + d_)
+        cur = nxt
+    for i in range(n):
+        if cur[i] is not None and cur[i].startswith("x["):
+            lines.append("  const int32_t o%d = %s;" % (i, cur[i]))
+            cur[i] = "o%d" % i
+    for i in range(n):
+        lines.append("  x[%d] = %s;" % (i, cur[i] if cur[i] is not None else "0"))
+    lines.append("}")
+    lines.append("")
+
+
+def run_pruned(stages, x, nz):
+    """executes what emit_pruned emits (same zero propagation), for check_pruned"""
+    n = len(stages[0])
+    cur = [int(v) if i < nz else None for i, v in enumerate(x)]
+    for st in stages:
+        nxt = [None] * n
+        for dst, op in enumerate(st):
+            if op[0] == 'cp':
+                nxt[dst] = cur[op[1]]
+            elif op[0] == 'neg':
+                nxt[dst] = None if cur[op[1]] is None else -cur[op[1]]
+            elif op[0] == 'add':
+                a, b = cur[op[1]], cur[op[2]]
+                if a is None and b is None:
+                    nxt[dst] = None
+                else:
+                    nxt[dst] = op[3] * (a or 0) + op[4] * (b or 0)
+            else:
+                a, b = cur[op[1]], cur[op[2]]
+                if a is None and b is None:
+                    nxt[dst] = None
+                elif b is None:
+                    nxt[dst] = round2(op[3] * a, 12)
+                elif a is None:
+                    nxt[dst] = round2(op[4] * b, 12)
+                else:
+                    nxt[dst] = round2(op[3] * a + op[4] * b, 12)
+        cur = nxt
+    return [0 if v is None else v for v in cur]
+
+
+# inverse networks that get pruned forms, and the input counts (the kernels pick the smallest that covers a block's nonzero extent)
+PRUNED = {"av1_idct8": (4,), "av1_iadst8": (4,), "av1_idct16": (4, 8), "av1_iadst16": (4, 8), "av1_idct32": (4, 8, 16), "av1_idct64": (8, 16)}
+
+
+def check_pruned(nets):
+    rng = np.random.default_rng(2)
+    for name, nzs in PRUNED.items():
+        st = nets[name]
+        n = len(st[0])
+        for nz in nzs:
+            for _ in range(200):
+                x = [int(v) for v in rng.integers(-(1 << 17), 1 << 17, n)]
+                x[nz:] = [0] * (n - nz)
+                assert run_pruned(st, x, nz) == run(st, x), (name, nz)
+    print("pruned networks == full networks on zero-extended inputs")
+
+
 def emit_tables(name, stages, lines):
     """int16 ops: kind, a, b, w0, w1 per lane per stage. kind: 0 cp 1 neg 2 add 3 rot"""
     n = len(stages[0])
@@ -362,8 +474,15 @@ def main():
            "#ifndef AV1_HALF_BTF_DEFINED  /* an includer may bring its own (the HIP kernels: 24-bit multiplies) */",
            "AV1_TXFM_FN int32_t av1_half_btf(int32_t w0, int32_t a, int32_t w1, int32_t b) {",
            "  return (int32_t)(((int64_t)w0 * a + (int64_t)w1 * b + 2048) >> 12);", "}", "#endif", ""]
+    hdr += ["/* Round2(w * a, 12): a rotation whose other input is known to be zero (the pruned networks below) */",
+            "#ifndef AV1_HALF_BTF1_DEFINED",
+            "AV1_TXFM_FN int32_t av1_half_btf1(int32_t w, int32_t a) { return (int32_t)(((int64_t)w * a + 2048) >> 12); }", "#endif", ""]
     for name, st in nets.items():
         emit_straightline(name, st, hdr)
+    check_pruned(nets)
+    for name, nzs in PRUNED.items():
+        for nz in nzs:
+            emit_pruned(name, nets[name], nz, hdr)
     hdr.append("#endif")
     p1 = os.path.join(HERE, "..", "av1-base_amd", "csrc", "txfm_gen.h")
     open(p1, "w").write("\n".join(hdr) + "\n")
