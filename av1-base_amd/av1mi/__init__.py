@@ -43,7 +43,8 @@ class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "bit_depth", "cq_level", "keyint", "block_log2", "cdf_update",
                                           "enable_cdef", "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec",
                                           "cdef_damping")] + [("intra_mode_mask", C.c_uint32), ("film_grain", C.c_uint32), ("first_frame", C.c_uint32), ("me_range", C.c_uint32), ("enable_lr", C.c_uint32), ("tile_sb", C.c_uint32), ("deblock", C.c_uint32), ("enable_qm", C.c_uint32), ("qm_min", C.c_uint32), ("qm_max", C.c_uint32), ("subpel", C.c_uint32), ("color_range", C.c_uint32), ("intra_angle_delta", C.c_uint32), ("intra_edge_filter", C.c_uint32), ("cfl", C.c_uint32), ("tx_search", C.c_uint32),
-                                                              ("color_primaries", C.c_uint32), ("transfer_characteristics", C.c_uint32), ("matrix_coefficients", C.c_uint32)]
+                                                              ("color_primaries", C.c_uint32), ("transfer_characteristics", C.c_uint32), ("matrix_coefficients", C.c_uint32),
+                                                              ("partition_search", C.c_uint32), ("min_block_log2", C.c_uint32), ("me_presearch", C.c_uint32)]
 
 
 class Buf(C.Structure):
@@ -110,7 +111,7 @@ _lib.av1mi_cq_to_qindex.restype = C.c_uint32
 _lib.av1mi_abi_version.restype = C.c_uint32
 _lib.av1mi_struct_sizes.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
 _lib.av1mi_struct_sizes.restype = C.c_uint32
-ABI_VERSION = 6   # include/av1mi.h: AV1MI_ABI_VERSION this mirror was written against
+ABI_VERSION = 7   # include/av1mi.h: AV1MI_ABI_VERSION this mirror was written against
 _lib.av1mi_write_headers.argtypes = [C.POINTER(Params), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t)]
 
 

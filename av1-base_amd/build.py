@@ -25,7 +25,17 @@ def _newer(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(not os.path.exists(d) or os.path.getmtime(d) > t for d in deps)
+
+
+def _deps_of(obj, fallback):
+    """the headers the object was built from (the compiler's -MMD depfile), or every header if there is no depfile yet"""
+    d = obj + ".d"
+    if not os.path.exists(d):
+        return fallback
+    txt = open(d).read().replace("\\\n", " ")
+    parts = txt.split(":", 1)[1].split() if ":" in txt else []
+    return [x for x in parts if x] or fallback
 
 
 def build(force=False, verbose=False):
@@ -39,8 +49,8 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, s.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        if force or _newer(obj, _deps_of(obj, [src] + hdrs)):
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

@@ -37,6 +37,9 @@ struct Av1miDevParams {
   const Av1miQmEntry *qm_tab;
   int using_qm, qm_y, qm_uv;
   int min_bs_log2, max_bs_log2;
+  // content-driven partition (av1mi_params.partition_search): null, or per frame of the chunk and superblock the split mask
+  // partition_kernel wrote (av1mi_node_split below); a node larger than min_bs_log2 and not larger than max_bs_log2 follows it
+  const uint32_t *part_map;
   uint32_t mode_mask;
   int angle_delta;          // 1: directional winners of the luma mode decision are refined over the angle deltas -3 .. +3
   int edge_filter;          // enable_intra_edge_filter
@@ -70,6 +73,34 @@ struct Av1miDevParams {
   int sgr_code_len[4][3];
   unsigned long long sgr_code_bits[4][3];
 };
+
+// ---- partition: does the node of size 2^bsl at superblock-local (ox, oy) split?  One rule for every kernel that
+// walks blocks (reconstruction, motion search, symbolize).  The syntax forces a split where the node's half point is outside the
+// frame (has_rows / has_cols of spec 5.11.4; a leaf may overhang the frame edge by less than half its size); nodes above max_bs_log2
+// split, nodes at min_bs_log2 (and 8x8) never do; in between the superblock's split mask decides - bit 0: the 64x64 node, bits
+// 1 .. 4: its 32x32 quadrants in Z order, bits 5 .. 20: the sixteen 16x16 nodes in Z order - or, without a mask, the node is a leaf.
+AV1MI_HD inline int av1mi_node_split(int width, int height, int min_bs_log2, int max_bs_log2, int have_mask, uint32_t mask,
+                                     int sb_x, int sb_y, int ox, int oy, int bsl) {
+  const int n = 1 << bsl;
+  if (bsl <= 3) return 0;
+  if (sb_y + oy + (n >> 1) >= height || sb_x + ox + (n >> 1) >= width) return 1;
+  if (bsl <= min_bs_log2) return 0;
+  if (bsl > max_bs_log2) return 1;
+  if (!have_mask) return 0;
+  const int bit = bsl == 6 ? 0 : (bsl == 5 ? 1 + ((oy >> 5) << 1 | (ox >> 5))
+                                           : 5 + (((ox >> 4) & 1) | (((oy >> 4) & 1) << 1) | (((ox >> 5) & 1) << 2) | (((oy >> 5) & 1) << 3)));
+  return (int)((mask >> bit) & 1u);
+}
+// log2 size of the leaf whose origin is superblock-local (bx, by), or 0 if (bx, by) is not the origin of a leaf
+AV1MI_HD inline int av1mi_leaf_bsl_at(int width, int height, int min_bs_log2, int max_bs_log2, int have_mask, uint32_t mask,
+                                      int sb_x, int sb_y, int bx, int by) {
+  for (int bsl = 6; bsl >= 3; bsl--) {
+    const int n = 1 << bsl;
+    const int ox = bx & ~(n - 1), oy = by & ~(n - 1);
+    if (!av1mi_node_split(width, height, min_bs_log2, max_bs_log2, have_mask, mask, sb_x, sb_y, ox, oy, bsl)) return (ox == bx && oy == by) ? bsl : 0;
+  }
+  return 0;
+}
 
 // frame f of a chunk is a key frame iff f % keyint == 0
 AV1MI_HD inline int av1mi_frame_is_inter(const Av1miDevParams &P, int f) { return P.keyint > 1 && (f % P.keyint) != 0; }

@@ -26,10 +26,11 @@
 #include "av1mi_dev.h"
 
 extern "C" {
+hipError_t av1mi_launch_partition(const Av1miDevParams *P, const void *frames, uint32_t *part, hipStream_t stream);
 hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
-                              const unsigned long long *me_best, hipStream_t s);
+                              const unsigned long long *me_best, const uint32_t *part, hipStream_t s);
 hipError_t av1mi_launch_recon64(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
-                                const unsigned long long *me_best, hipStream_t s);
+                                const unsigned long long *me_best, const uint32_t *part, hipStream_t s);
 hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, const unsigned long long *best, unsigned long long *refined,
                                       int me_range, int frame0, int count, hipStream_t stream);
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
@@ -110,6 +111,10 @@ int resolve(const av1mi_params *in, Resolved *r) {
   if (p.cdef_damping < 3 || p.cdef_damping > 6 || p.cdef_y_pri > 15 || p.cdef_uv_pri > 15 || p.cdef_y_sec > 3 || p.cdef_uv_sec > 3) return AV1MI_E_INVALID_ARG;
   r->qidx = kQuantizerToQindex[p.cq_level];
   if (p.subpel > 1 || p.enable_lr > 2 || p.color_range > 1 || p.intra_angle_delta > 1 || p.intra_edge_filter > 1 || p.cfl > 1 || p.tx_search > 1) return AV1MI_E_INVALID_ARG;
+  if (p.partition_search > 1 || p.me_presearch > 1) return AV1MI_E_INVALID_ARG;
+  if (p.me_presearch) return AV1MI_E_UNSUPPORTED;   // (not built yet)
+  if (p.min_block_log2 == 0) p.min_block_log2 = 3;
+  if (p.min_block_log2 < 3 || p.min_block_log2 > p.block_log2) return AV1MI_E_INVALID_ARG;
   if (p.color_primaries > 255 || p.transfer_characteristics > 255 || p.matrix_coefficients > 255) return AV1MI_E_INVALID_ARG;
   // CP_BT_709 / TC_SRGB / MC_IDENTITY switches the syntax to 4:4:4 with no color_range bit (spec 5.5.2): not a 4:2:0 description
   if (p.color_primaries == 1 && p.transfer_characteristics == 13 && p.matrix_coefficients == 0) return AV1MI_E_INVALID_ARG;
@@ -440,6 +445,7 @@ struct av1mi_ctx {
   void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
   unsigned long long *d_me_sub = nullptr;  // sub-sample refinement: refined [frame][8x8 unit] keys (me_kernel.hip)
   uint16_t *d_cdefdir = nullptr;           // chunk-wide CDEF: {adjusted luma primary strength << 3 | direction} per 8x8 block (cdef_dir_kernel)
+  uint32_t *d_part = nullptr;              // content-driven partition: split mask per [frame][superblock] (partition_kernel)
   uint32_t *d_me64 = nullptr;              // 64x64 leaves: the search's [frame][superblock][candidate] SAD table
   size_t me64_bytes = 0;
   Av1miQmEntry *d_qm = nullptr;        // quantiser-matrix steps (Av1miDevParams::qm_tab), valid for qm_key = (level, qidx, bit depth)
@@ -476,11 +482,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params, c->d_me64, c->d_cdefdir };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params, c->d_me64, c->d_cdefdir, c->d_part };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr; c->d_me64 = nullptr; c->me64_bytes = 0; c->d_cdefdir = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr; c->d_me64 = nullptr; c->me64_bytes = 0; c->d_cdefdir = nullptr; c->d_part = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -539,6 +545,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   }
   if ((r.cw != (int)p.width || r.ch != (int)p.height) && !c->d_stage)
     HIPCHK(c, hipMalloc(&c->d_stage, c->cap_frames * (size_t)p.width * p.height * 3 / 2 * bps));
+  if (p.partition_search && !c->d_part) HIPCHK(c, hipMalloc((void **)&c->d_part, c->cap_frames * nsb * sizeof(uint32_t)));
   if (p.subpel && !c->d_me_sub)   // output of the sub-sample refinement
     HIPCHK(c, hipMalloc((void **)&c->d_me_sub, (size_t)c->cap_frames * (r.cw / 8) * (r.ch / 8) * 8));
   if (p.block_log2 >= 6 && p.keyint > 1) {   // candidate table of the 64x64 leaves' motion search
@@ -592,7 +599,9 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
     }
     P.qm_tab = c->d_qm;
   }
-  P.min_bs_log2 = P.max_bs_log2 = (int)p.block_log2;
+  P.max_bs_log2 = (int)p.block_log2;
+  P.min_bs_log2 = p.partition_search ? (int)p.min_block_log2 : (int)p.block_log2;
+  P.part_map = p.partition_search ? c->d_part : nullptr;
   P.mode_mask = p.intra_mode_mask ? (p.intra_mode_mask & 0x1FFF) : 0x0007;  // default candidates: DC, V, H
   P.angle_delta = p.intra_angle_delta ? 1 : 0;
   P.edge_filter = p.intra_edge_filter ? 1 : 0;
@@ -969,6 +978,9 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     HIPCHK(c, av1mi_launch_pad(tight, c->d_src, (int)r.p.width, (int)r.p.height, r.cw, r.ch, P.bit_depth, (int)n_frames, 0, s));
     d_src = c->d_src;
   }
+  // content-driven partition: the split masks of every superblock of the chunk, from the source, before anything walks blocks (the second
+  // stream's motion search waits for ev[1] as well)
+  if (P.part_map) HIPCHK(c, av1mi_launch_partition(&P, d_src, c->d_part, s));
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   const bool inter_chunk = P.keyint > 1 && n_frames > 1;
   // 64x64 leaf blocks run the kernels of recon64_kernel.hip (64-point transforms, larger LDS tiles)
@@ -980,7 +992,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   void *cdef_out = lr ? c->d_cd : c->d_fin;   // with loop restoration CDEF writes d_cd and the restored frame goes to d_fin
   if (!inter_chunk && lr) {
     // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
-    HIPCHK(c, launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, s));
+    HIPCHK(c, launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, P.part_map, s));
     if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
     HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, nullptr, s));
     HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, c->d_lrsse, 1, s));
@@ -1001,7 +1013,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       Av1miDevParams Pg = P;
       Pg.n_frames = (int)cnt;
       HIPCHK(c, launch_recon(&Pg, c->d_params, (const uint8_t *)d_src + f0 * fbytes, (uint8_t *)c->d_rec + f0 * fbytes,
-                             c->d_levels + f0 * nsb * AV1MI_SB_LEVELS, c->d_blk + f0 * nb8, nullptr, nullptr, s));
+                             c->d_levels + f0 * nsb * AV1MI_SB_LEVELS, c->d_blk + f0 * nb8, nullptr, nullptr, P.part_map ? P.part_map + f0 * nsb : nullptr, s));
       if (f0 + cnt < n_frames) {
         if (c->grp_ev.size() <= n_grp) {
           hipEvent_t e;
@@ -1078,13 +1090,13 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       Av1miBlkInfo *blkf = c->d_blk + f * nb8;
       int16_t *lvf = c->d_levels + f * nsb * AV1MI_SB_LEVELS;
       if (!av1mi_frame_is_inter(P, (int)f)) {
-        HIPCHK(c, launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, nullptr, nullptr, s));
+        HIPCHK(c, launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, nullptr, nullptr, P.part_map ? P.part_map + f * nsb : nullptr, s));
       } else {
         const uint8_t *reff = (const uint8_t *)c->d_fin + (f - 1) * fbytes;
         unsigned long long *mef = (P.subpel ? c->d_me_sub : c->d_me) + f * nb8;
         { const int mrc = search_upto(f + 1); if (mrc) return mrc; }
         HIPCHK(c, hipStreamWaitEvent(s, c->me_ev[f], 0));
-        HIPCHK(c, launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, reff, mef, s));
+        HIPCHK(c, launch_recon(&P1, c->d_params, srcf, recf, lvf, blkf, reff, mef, P.part_map ? P.part_map + f * nsb : nullptr, s));
       }
       if (!av1mi_frame_is_inter(P, (int)f)) { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level[i]; }
       else { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level_inter[i]; }

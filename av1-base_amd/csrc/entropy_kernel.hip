@@ -532,16 +532,12 @@ __device__ __forceinline__ void sym_mv_component(Sym &y, int lane, int adapt, in
 
 __device__ __forceinline__ int icdf_prob(int off, int el) { return (el > 0 ? S->cdf[off + el - 1] : 32768) - S->cdf[off + el]; }
 
-// split decision shared with the recon kernel
-__device__ __forceinline__ bool node_split(const Av1miDevParams &P, int sb_x, int sb_y, int ox, int oy, int bsl) {
-  const int n = 1 << bsl;
-  bool split;
-  if (bsl <= P.min_bs_log2 || bsl == 3) split = false;
-  else if (bsl > P.max_bs_log2) split = true;
-  else split = false;
-  if (sb_y + oy + (n >> 1) >= P.height || sb_x + ox + (n >> 1) >= P.width) split = true;   // has_rows / has_cols
-  if (bsl == 3) split = false;
-  return split;
+// Under a content-driven partition (P.part_map): does the superblock keep one block size throughout - no node between min_bs_log2
+// and max_bs_log2 splits by its mask?  (Only then does a tile hold exactly two (transform size, plane type) classes.)
+__device__ __forceinline__ bool sb_unsplit(const Av1miDevParams &P, int f, int sbr, int sbc) {
+  if (!P.part_map || P.min_bs_log2 >= P.max_bs_log2) return true;
+  const uint32_t m = P.part_map[((size_t)f * P.sb_rows + sbr) * P.sb_cols + sbc];
+  return P.max_bs_log2 >= 6 ? !(m & 1u) : (P.max_bs_log2 == 5 ? !(m & 0x1Eu) : !(m & 0x1FFFE0u));
 }
 
 // FULL = false: regular tiles (superblock entirely inside the frame) in adaptive mode - exactly two
@@ -560,7 +556,9 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   const int tr = tile / P.tile_cols, tc = tile % P.tile_cols;
   const int lane = threadIdx.x;
   {
-    const bool regular = !P.disable_cdf_update && (tc + 1) * 64 * TSB <= P.width && (tr + 1) * 64 * TSB <= P.height;
+    bool regular = !P.disable_cdf_update && (tc + 1) * 64 * TSB <= P.width && (tr + 1) * 64 * TSB <= P.height;
+    if (regular)   // (a tile whose superblocks mix block sizes holds more than two classes: the full variant's)
+      for (int si = 0; si < TSB * TSB; si++) regular = regular && sb_unsplit(P, f, tr * TSB + si / TSB, tc * TSB + si % TSB);
     if (regular == FULL) return;
   }
   for (int i = lane; i < CL::COEFF_BASE; i += 64) S->cdf[i] = cdf_init[i];

@@ -90,29 +90,44 @@ AV1MI_PIECE_FN pu4 dir_piece(const uint16_t *E, int d, int rho, int k0, bool nob
   return __builtin_bit_cast(pu4, (pus8)((__builtin_bit_cast(pus8, X) * w0 + __builtin_bit_cast(pus8, Y) * w1 + (unsigned short)16) >> (unsigned short)5));
 }
 
-// one piece of a prediction that is not directional (or is V / H at exactly 90 / 180 degrees): raw edges A0 / L0, smooth weights smw
+// one piece of a prediction that is not directional (or is V / H at exactly 90 / 180 degrees): raw edges A0 / L0, smooth weights smw.
+// One loop per mode (a mode test inside the sample loop compiled to a scalar branch and an LDS wait per sample); the eight above
+// samples of the piece come in one 16-byte load.
 template <int N>
 AV1MI_PIECE_FN pu4 plain_piece(int mode, int rho, int k0, int dcv, const uint16_t *A0, const uint16_t *L0, const uint8_t *smw) {
   if (mode == P_DC || mode == P_H) {
     const uint32_t c2 = (uint32_t)(mode == P_DC ? dcv : (int)L0[rho]) * 0x10001u;
     return (pu4){ c2, c2, c2, c2 };
   }
-  if (mode == P_V) return *reinterpret_cast<const pu4 *>(&A0[k0]);
-  int px[8];
+  const pu4 av = *reinterpret_cast<const pu4 *>(&A0[k0]);
+  if (mode == P_V) return av;
+  int a[8], px[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) a[j] = (int)((av[j >> 1] >> (16 * (j & 1))) & 0xFFFF);
+  const int l = L0[rho];
   if (mode == P_PAETH) {
-    const int tl = A0[-1], l = L0[rho], pt = p_abs(l - tl);
+    const int tl = A0[-1], pt = p_abs(l - tl), l2 = l - 2 * tl;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int t = A0[k0 + j], pl = p_abs(t - tl), ptl = p_abs(t + l - 2 * tl);
+      const int t = a[j], pl = p_abs(t - tl), ptl = p_abs(t + l2);
       px[j] = (pl <= pt && pl <= ptl) ? l : (pt <= ptl ? t : tl);
     }
-  } else {
-    const int wr = smw[rho], l = L0[rho], ar = A0[N - 1], lb = L0[N - 1];
+  } else if (mode == P_SMOOTH_V) {
+    const int wr = smw[rho], kr = (256 - wr) * (int)L0[N - 1] + 128;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int a = A0[k0 + j], wc = smw[k0 + j];
-      px[j] = mode == P_SMOOTH ? (wr * a + (256 - wr) * lb + wc * l + (256 - wc) * ar + 256) >> 9
-            : (mode == P_SMOOTH_V ? (wr * a + (256 - wr) * lb + 128) >> 8 : (wc * l + (256 - wc) * ar + 128) >> 8);
+    for (int j = 0; j < 8; j++) px[j] = (wr * a[j] + kr) >> 8;
+  } else {
+    int wc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) wc[j] = smw[k0 + j];
+    const int ar = A0[N - 1];
+    if (mode == P_SMOOTH_H) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) px[j] = (wc[j] * l + (256 - wc[j]) * ar + 128) >> 8;
+    } else {
+      const int wr = smw[rho], kr = (256 - wr) * (int)L0[N - 1] + 256;
+#pragma unroll
+      for (int j = 0; j < 8; j++) px[j] = (wr * a[j] + kr + wc[j] * l + (256 - wc[j]) * ar) >> 9;
     }
   }
   return (pu4){ (uint32_t)px[0] | ((uint32_t)px[1] << 16), (uint32_t)px[2] | ((uint32_t)px[3] << 16), (uint32_t)px[4] | ((uint32_t)px[5] << 16),

@@ -28,25 +28,22 @@ namespace {
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 
-// Leaf block size (log2) at cell-local 8x8 unit (ux, uy) of the 32x32 cell at (cx, cy), or 0 if the unit is not the
-// origin of a leaf: same rule as the recon kernel's leaf_bsl_at restricted to sizes <= 32.
-__device__ __forceinline__ int leaf_bsl_cell(const Av1miDevParams &P, int cx, int cy, int ux, int uy) {
+// the split mask of frame f's superblock that holds luma position (x, y) (content-driven partition; av1mi_dev.h has the rule)
+__device__ __forceinline__ uint32_t sb_mask(const Av1miDevParams &P, int f, int x, int y) {
+  return P.part_map ? P.part_map[((size_t)f * P.sb_rows + (y >> 6)) * P.sb_cols + (x >> 6)] : 0u;
+}
+// Leaf block size (log2) at cell-local 8x8 unit (ux, uy) of the 32x32 cell at (cx, cy) of frame f, or 0 if the unit is not the
+// origin of a leaf: the recon kernel's rule; a unit inside a 64x64 leaf reports 0 except at the leaf's origin (6).
+__device__ __forceinline__ int leaf_bsl_cell(const Av1miDevParams &P, int f, int cx, int cy, int ux, int uy) {
   const int x = cx + ux * 8, y = cy + uy * 8;
   if (x >= P.width || y >= P.height) return 0;
-  for (int bsl = 5; bsl >= 3; bsl--) {
-    const int n = 1 << bsl;
-    const int ox = x & ~(n - 1), oy = y & ~(n - 1);
-    // (a node splits where its half point is outside the frame; a leaf may overhang the frame edge by less than half its size)
-    const bool split = (bsl > P.max_bs_log2 && bsl > 3) || ((oy + (n >> 1) >= P.height || ox + (n >> 1) >= P.width) && bsl > 3);
-    if (!split) return (ox == x && oy == y) ? bsl : 0;
-  }
-  return 0;
+  return av1mi_leaf_bsl_at(P.width, P.height, P.min_bs_log2, P.max_bs_log2, P.part_map != nullptr, sb_mask(P, f, x, y), x & ~63, y & ~63, x & 63, y & 63);
 }
 
-// The 32x32 cell at (cx, cy) lies in a 64x64 LEAF (block_log2 = 6): the node of its superblock is a leaf when its half point is
-// inside the frame both ways (it may overhang the edge by less than 32 samples).
-__device__ __forceinline__ bool cell_in_leaf64(const Av1miDevParams &P, int cx, int cy) {
-  return P.max_bs_log2 >= 6 && (cx & ~63) + 32 < P.width && (cy & ~63) + 32 < P.height;
+// The 32x32 cell at (cx, cy) lies in a 64x64 LEAF: the node of its superblock does not split (block_log2 = 6, its half point inside
+// the frame both ways - it may overhang the edge by less than 32 samples - and, under a content-driven partition, its mask bit clear).
+__device__ __forceinline__ bool cell_in_leaf64(const Av1miDevParams &P, int f, int cx, int cy) {
+  return !av1mi_node_split(P.width, P.height, P.min_bs_log2, P.max_bs_log2, P.part_map != nullptr, sb_mask(P, f, cx, cy), cx & ~63, cy & ~63, 0, 0, 6);
 }
 
 template <typename PIX, int R>
@@ -124,7 +121,7 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
   __syncthreads();
   // ---- a cell of a 64x64 leaf: the leaf's SAD of a candidate is the sum over its four cells - every (cell, dy) wave adds its
   // cell sums to the leaf's candidate table; me64_reduce_kernel takes the minimum afterwards
-  if (cell_in_leaf64(P, cx, cy)) {
+  if (cell_in_leaf64(P, f, cx, cy)) {
     if (lane < NC) {
       uint32_t sad = 0;
 #pragma unroll
@@ -136,7 +133,7 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
   }
   // ---- the usual cell: one 32x32 leaf.  Lane = dx candidate: each sums the 16 sub-block SADs of its dx, a wave minimum
   // over (cost, candidate) picks the best of this dy (as one lane looping over the candidates it was a third of the kernel)
-  if (leaf_bsl_cell(P, cx, cy, 0, 0) == 5) {
+  if (leaf_bsl_cell(P, f, cx, cy, 0, 0) == 5) {
     if (cy + dy >= -16 && cy + dy + 32 <= H + 16) {
       unsigned long long key = ~0ull;
       if (lane < NC) {
@@ -157,7 +154,7 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
   // ---- other cells (smaller blocks, frame edges): lane u < 16 = 8x8 unit u; a leaf origin sums its sub-blocks for every dx
   if (lane < 16) {
     const int ux = lane & 3, uy = lane >> 2;
-    const int bsl = leaf_bsl_cell(P, cx, cy, ux, uy);
+    const int bsl = leaf_bsl_cell(P, f, cx, cy, ux, uy);
     if (bsl) {
       const int n = 1 << bsl, n8 = n >> 3;
       const int x = cx + ux * 8, y = cy + uy * 8;
@@ -186,7 +183,7 @@ __global__ void __launch_bounds__(64) me64_reduce_kernel(Av1miDevParams P, const
   const int f = frame0 + blockIdx.y;
   if (!av1mi_frame_is_inter(P, f)) return;
   const int sb = blockIdx.x, x = (sb % P.sb_cols) * 64, y = (sb / P.sb_cols) * 64;
-  if (!cell_in_leaf64(P, x, y)) return;
+  if (!cell_in_leaf64(P, f, x, y)) return;
   const int NC = 2 * R + 1, lane = threadIdx.x;
   const uint32_t *tab = acc64 + ((size_t)f * P.sb_rows * P.sb_cols + sb) * NC * NC;
   unsigned long long key = ~0ull;
@@ -496,7 +493,7 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
   const int NC = 2 * R + 1;
   // this wave's cell of the largest block size: one leaf inside the frame, a few smaller ones where it straddles the edge
   const int u = 1 << (cell_log2 - 3);
-  if (cell_log2 == 6 && cell_in_leaf64(P, blockIdx.x * 64, blockIdx.y * 64)) {   // this wave's cell is one 64x64 leaf
+  if (cell_log2 == 6 && cell_in_leaf64(P, f, blockIdx.x * 64, blockIdx.y * 64)) {   // this wave's cell is one 64x64 leaf
     const size_t slot = (size_t)f * P.b8_rows * P.b8_cols + (size_t)(blockIdx.y * 8) * P.b8_cols + blockIdx.x * 8;
     const int cand = (int)(in_all[slot] & 0xFFFF);
     int best_row = (cand / NC - R) * 8, best_col = (cand % NC - R) * 8, best_sad = 0;
@@ -508,7 +505,7 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
   for (int uy = blockIdx.y * u; uy < (int)(blockIdx.y + 1) * u; uy++)
     for (int ux = blockIdx.x * u; ux < (int)(blockIdx.x + 1) * u; ux++) {
       if (ux * 8 >= P.width || uy * 8 >= P.height) continue;
-      const int bsl = leaf_bsl_cell(P, (ux >> 2) * 32, (uy >> 2) * 32, ux & 3, uy & 3);
+      const int bsl = leaf_bsl_cell(P, f, (ux >> 2) * 32, (uy >> 2) * 32, ux & 3, uy & 3);
       if (!bsl) continue;
       const size_t slot = (size_t)f * P.b8_rows * P.b8_cols + (size_t)uy * P.b8_cols + ux;
       const unsigned long long key = in_all[slot];   // the full search's key: (cost << 16) | candidate index

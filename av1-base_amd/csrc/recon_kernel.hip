@@ -1386,30 +1386,17 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   return (idtx << 12) | ((INTER ? ii.is_inter : 0) << 8) | ((best_delta + 3) << 4) | best_mode;
 }
 
-// Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is
-// not the origin of a leaf.  The tree is a pure function of geometry: a node is a leaf iff
-// its size is <= max_bs and its half point lies inside the frame both ways (never below 8x8).
-__device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int sb_x, int sb_y, int bx, int by) {
-  for (int bsl = 6; bsl >= 3; bsl--) {
-    const int n = 1 << bsl;
-    const int ox = bx & ~(n - 1), oy = by & ~(n - 1);
-    bool split;
-    if (bsl <= P.min_bs_log2 || bsl == 3) split = false;
-    else if (bsl > P.max_bs_log2) split = true;
-    else split = false;
-    // the syntax forces a split where the node's half point is outside the frame (has_rows / has_cols of §5.11.4); a leaf may
-    // overhang the frame edge by less than half its size
-    if (sb_y + oy + (n >> 1) >= P.height || sb_x + ox + (n >> 1) >= P.width) split = true;
-    if (bsl == 3) split = false;
-    if (!split) return (ox == bx && oy == by) ? bsl : 0;
-  }
-  return 0;
+// Leaf block size (log2) of the partition tree at superblock-local (bx, by), or 0 if (bx, by) is not the origin of a leaf: the
+// geometry rule of DESIGN.md §3.2 and, with a split mask (content-driven partition, §3.2b), the mask - av1mi_dev.h has the rule.
+__device__ __forceinline__ int leaf_bsl_at(const Av1miDevParams &P, int have_mask, uint32_t mask, int sb_x, int sb_y, int bx, int by) {
+  return av1mi_leaf_bsl_at(P.width, P.height, P.min_bs_log2, P.max_bs_log2, have_mask, mask, sb_x, sb_y, bx, by);
 }
 
 template <typename PIX, bool INTER, int TSB, bool QM, bool SPLIT, bool EXT>
 __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *frame, PIX *rec_frame, int16_t *sb_levels,
                                                   Av1miBlkInfo *info, int b8_stride, const PIX *ref_frame,
-                                                  const unsigned long long *me_best /* this superblock's first unit */, int si) {
+                                                  const unsigned long long *me_best /* this superblock's first unit */, int si,
+                                                  int have_mask, uint32_t mask /* the superblock's split mask (content-driven partition) */) {
   const Av1miDevParams &P = *cx.P;
   // SPLIT: wave 0 of the workgroup walks the luma blocks (and takes the decisions), wave 1 the chroma blocks
   constexpr int WL = SPLIT ? 1 : 0, WC = SPLIT ? 2 : 0;
@@ -1419,7 +1406,7 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     const int bx = (((z >> 0) & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) << 3;
     const int by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) << 3;
     if (cx.sb_y + by >= P.height || cx.sb_x + bx >= P.width) continue;
-    const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
+    const int bsl = leaf_bsl_at(P, have_mask, mask, cx.sb_x, cx.sb_y, bx, by);
     if (bsl == 0) continue;
     const int n = 1 << bsl;
     const int qi = si * 64 + z;
@@ -1512,7 +1499,8 @@ template <typename PIX, bool INTER, int TSB, bool QM, bool EXT>
 __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
-                                                     const unsigned long long *__restrict__ me_best) {
+                                                     const unsigned long long *__restrict__ me_best,
+                                                     const uint32_t *__restrict__ part /* split masks of the launch's first frame on (null: partition by geometry) */) {
   // The parameters come through a pointer to device memory, not by value: the transform items are `noinline` and take the
   // address of the block, and the address of a by-value kernel argument is a private copy - every lane wrote the whole
   // structure (0.6 KB) to scratch at the start of the kernel and read its fields back from there.  Loads through a
@@ -1567,7 +1555,8 @@ __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribut
     Av1miBlkInfo *info = blk + (size_t)f * P.b8_rows * P.b8_cols + (size_t)(sbr * 8) * P.b8_cols + sbc * 8;
     // (inter frames are launched one at a time: f == 0 then, and `ref` / `me_best` belong to that frame)
     encode_superblock<PIX, INTER, TSB, QM, SPLIT, EXT>(cx, frame, rec + (size_t)f * P.frame_samples, sb_levels, info, P.b8_cols, ref,
-                                                  me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr, si);
+                                                  me_best ? me_best + (size_t)(sbr * 8) * P.b8_cols + sbc * 8 : nullptr, si,
+                                                  part != nullptr, part ? part[(size_t)f * sbs_per_frame + sb] : 0u);
   }
 #ifdef AV1MI_STAMPS
   __syncthreads();
@@ -1587,7 +1576,8 @@ template <typename PIX, bool QM, bool SP /* sub-sample motion vectors (P->subpel
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : 4))) recon_inter_pre_kernel(const Av1miDevParams *__restrict__ Pd,
                                                      const PIX *__restrict__ src, PIX *__restrict__ rec, int16_t *__restrict__ levels,
                                                      Av1miBlkInfo *__restrict__ blk, const PIX *__restrict__ ref,
-                                                     const unsigned long long *__restrict__ me_best, int cell_log2) {
+                                                     const unsigned long long *__restrict__ me_best, int cell_log2,
+                                                     const uint32_t *__restrict__ part) {
   const Av1miDevParams &P = *Pd;
   const int u = 1 << (cell_log2 - 3);
   for (int uy = blockIdx.y * u; uy < (int)(blockIdx.y + 1) * u; uy++)
@@ -1597,7 +1587,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
       SbCtx cx;
       cx.P = Pd; cx.lane = threadIdx.x; cx.sb_x = x & ~63; cx.sb_y = y & ~63; cx.tox = 0; cx.toy = 0;
       const int bx = x - cx.sb_x, by = y - cx.sb_y;
-      const int bsl = leaf_bsl_at(P, cx.sb_x, cx.sb_y, bx, by);
+      const int bsl = leaf_bsl_at(P, part != nullptr, part ? part[(cx.sb_y >> 6) * P.sb_cols + (cx.sb_x >> 6)] : 0u, cx.sb_x, cx.sb_y, bx, by);
       if (bsl == 0) continue;
       const int n = 1 << bsl;
       InterInfo ii;
@@ -1665,7 +1655,7 @@ extern "C" int av1mi_debug_stamps(unsigned long long *out, int reset) {
 #define AV1MI_LAUNCH_RECON av1mi_launch_recon     /* leaf blocks up to 32x32 */
 #endif
 extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels,
-                                         Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, hipStream_t stream) {
+                                         Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, const uint32_t *part, hipStream_t stream) {
   const int grid = P->n_frames * P->tile_rows * P->tile_cols;
   const bool inter = ref != nullptr;
   if (inter) {  // first launch of an inter frame: every block as an inter block, all at once (see recon_inter_pre_kernel)
@@ -1674,9 +1664,9 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
 #define PRE_LAUNCH2(PIXT, SPV)                                                                                                               \
     do {                                                                                                                                     \
       if (P->qm_tab) hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, true, SPV>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec, \
-                                        levels, blk, (const PIXT *)ref, me_best, g);                                                         \
+                                        levels, blk, (const PIXT *)ref, me_best, g, part);                                                   \
       else hipLaunchKernelGGL((recon_inter_pre_kernel<PIXT, false, SPV>), pgrid, dim3(64), 0, stream, dP, (const PIXT *)src, (PIXT *)rec,          \
-                              levels, blk, (const PIXT *)ref, me_best, g);                                                                   \
+                              levels, blk, (const PIXT *)ref, me_best, g, part);                                                             \
     } while (0)
 #define PRE_LAUNCH(PIXT) do { if (P->subpel) PRE_LAUNCH2(PIXT, true); else PRE_LAUNCH2(PIXT, false); } while (0)
     if (P->bit_depth == 8) PRE_LAUNCH(uint8_t); else PRE_LAUNCH(uint16_t);
@@ -1687,9 +1677,9 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
 #define RECON_LAUNCH2(PIXT, INTERV, TSBV, EXTV)                                                                                             \
   do {                                                                                                                                      \
     if (P->qm_tab) hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, true, EXTV>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,  \
-                                      (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                \
+                                      (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best, part);                                          \
     else hipLaunchKernelGGL((recon_sb_kernel<PIXT, INTERV, TSBV, false, EXTV>), dim3(grid), dim3(WalkSplit<INTERV>::value ? 128 : 64), 0, stream, dP, (const PIXT *)src,           \
-                            (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best);                                                          \
+                            (PIXT *)rec, levels, blk, (const PIXT *)ref, me_best, part);                                                    \
   } while (0)
   // the optional intra tools (edge filter, chroma from luma) live in instantiations of their own (EXT)
 #define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \

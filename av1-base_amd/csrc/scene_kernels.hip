@@ -86,7 +86,83 @@ __global__ void __launch_bounds__(256) crop_frames_kernel(const PIX *__restrict_
   }
 }
 
+// ---- content-driven partition (av1mi_params.partition_search; SURVEY.md §8a row a10: the block-size decision SVT-AV1
+// spends most of `--preset 3` on, /root/reference/crates/daemon/src/encode/av1an.rs:14).  Open loop, from the SOURCE luma: a node of the
+// partition tree splits when its four quadrants differ in activity - the largest quadrant variance exceeds four times the smallest plus
+// (ac_q / 16)^2 - so every frame of a chunk is decided in one streaming pass before any tile walk.  One wave per superblock: lane = 8x8
+// unit in Z order (sum and sum of squares of its 64 samples, coordinates beyond the frame repeating the last column / row: what the
+// block's transform will see), then one lane per node - sixteen 16x16, four 32x32, one 64x64 - compares its quadrants.  Writes the
+// superblock's split mask (av1mi_dev.h: av1mi_node_split reads it).  Algorithmic bytes L b per frame (L luma samples).
+template <typename PIX>
+__global__ void __launch_bounds__(64) partition_kernel(Av1miDevParams P, const PIX *__restrict__ frames, uint32_t *__restrict__ part) {
+  __shared__ uint32_t uS[64], uQ[64];
+  __shared__ uint32_t bits[21];
+  const int f = blockIdx.y, sb = blockIdx.x, lane = threadIdx.x;
+  const int sb_x = (sb % P.sb_cols) * 64, sb_y = (sb / P.sb_cols) * 64;
+  const PIX *luma = frames + (size_t)f * P.frame_samples;
+  {
+    const int ux = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), uy = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int x0 = sb_x + 8 * ux, y0 = sb_y + 8 * uy;
+    uint32_t S = 0, Q = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int yy = y0 + i < P.height ? y0 + i : P.height - 1;
+      const PIX *row = luma + (size_t)yy * P.stride_y;
+      if (x0 + 8 <= P.width) {   // eight samples of the row in one load (the coded width is a multiple of 8)
+        if (sizeof(PIX) == 2) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(row + x0);
+          const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const uint32_t a = w[k] & 0xFFFF, b = w[k] >> 16; S += a + b; Q += a * a + b * b; }
+        } else {
+          const uint2 v = *reinterpret_cast<const uint2 *>(row + x0);
+          const uint32_t w[2] = { v.x, v.y };
+#pragma unroll
+          for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int b8 = 0; b8 < 4; b8++) { const uint32_t a = (w[k] >> (8 * b8)) & 0xFF; S += a; Q += a * a; }
+        }
+      } else {
+        for (int j = 0; j < 8; j++) { const int xx = x0 + j < P.width ? x0 + j : P.width - 1; const uint32_t a = row[xx]; S += a; Q += a * a; }
+      }
+    }
+    uS[lane] = S; uQ[lane] = Q;
+  }
+  __syncthreads();
+  if (lane < 21) {
+    // node of this lane: 0 .. 15 the 16x16 nodes (Z order; quadrants = 1 unit each), 16 .. 19 the 32x32 nodes (4 units per quadrant), 20 the
+    // 64x64 node (16 units per quadrant); the units of a node are consecutive in Z order
+    const int per_q = lane < 16 ? 1 : (lane < 20 ? 4 : 16);
+    const int first = lane < 16 ? 4 * lane : (lane < 20 ? 16 * (lane - 16) : 0);
+    const unsigned long long m = 64ull * per_q, t = (unsigned long long)(P.ac_q >> 4);
+    unsigned long long vmin = ~0ull, vmax = 0;
+    for (int q = 0; q < 4; q++) {
+      unsigned long long S = 0, Q = 0;
+      for (int u = 0; u < per_q; u++) { S += uS[first + q * per_q + u]; Q += uQ[first + q * per_q + u]; }
+      const unsigned long long V = m * Q - S * S;
+      vmin = V < vmin ? V : vmin;
+      vmax = V > vmax ? V : vmax;
+    }
+    // bit 0: the 64x64 node, bits 1 .. 4: the 32x32 nodes, bits 5 .. 20: the 16x16 nodes
+    bits[lane < 16 ? 5 + lane : (lane < 20 ? 1 + (lane - 16) : 0)] = vmax > 4 * vmin + t * t * m * m;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t mask = 0;
+    for (int b = 0; b < 21; b++) mask |= (bits[b] & 1u) << b;
+    part[(size_t)f * P.sb_rows * P.sb_cols + sb] = mask;
+  }
+}
+
 }  // namespace
+
+// split masks of every superblock of P->n_frames frames (partition_kernel)
+extern "C" hipError_t av1mi_launch_partition(const Av1miDevParams *P, const void *frames, uint32_t *part, hipStream_t stream) {
+  dim3 grid(P->sb_rows * P->sb_cols, P->n_frames);
+  if (P->bit_depth == 8) hipLaunchKernelGGL(partition_kernel<uint8_t>, grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, part);
+  else hipLaunchKernelGGL(partition_kernel<uint16_t>, grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, part);
+  return hipGetLastError();
+}
 
 extern "C" hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop,
                                        hipStream_t stream) {

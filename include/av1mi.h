@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AV1MI_ABI_VERSION 6
+#define AV1MI_ABI_VERSION 7
 
 /* positive failure codes (-> Av1anFailed(code)) */
 enum {
@@ -92,6 +92,14 @@ typedef struct {
                                (color_description_present_flag 0); BASELINE config 5 "8K 10-bit HDR" = 9 / 16 / 9 (BT.2020 primaries, SMPTE
                                2084 PQ, BT.2020 non-constant luminance).  Values 0..255 each; the triple 1 / 13 / 0 (sRGB + identity) implies
                                4:4:4 and is refused */
+  uint32_t partition_search; /* 1: content-driven partition - a node of the partition tree larger than `min_block_log2` and not larger than `block_log2`
+                               splits when its four quadrants differ in activity (largest quadrant variance of the source luma > 4 x the
+                               smallest + (ac_q / 16)^2), so quiet areas keep large blocks and edges / small objects get small ones; decided
+                               for all frames of a chunk by one GPU pass over the source.  0 (default): every block is `block_log2` */
+  uint32_t min_block_log2;  /* smallest leaf under partition_search: 3 (8x8, default when 0) .. block_log2 */
+  uint32_t me_presearch;    /* inter frames: 1 = hierarchical motion search - a quarter-resolution search of +-64 luma samples per 32x32 cell finds the
+                               centre the full-resolution search of +-me_range then runs around (row a13's "1/4-res ... full"); 0 (default): the
+                               full-resolution search runs around the zero vector */
 } av1mi_params;
 
 typedef struct {

@@ -19,6 +19,9 @@ pub struct Av1miParams {            // include/av1mi.h: av1mi_params
     pub cfl: u32,                   // 1 = chroma-from-luma prediction is a candidate (key frames, blocks up to 32x32)
     pub tx_search: u32,             // 1 = identity transform (IDTX) for sparse intra luma residuals
     pub color_primaries: u32, pub transfer_characteristics: u32, pub matrix_coefficients: u32,   // CICP colour description (0 / 0 / 0 = none; HDR10: 9 / 16 / 9)
+    pub partition_search: u32,      // 1 = content-driven partition between min_block_log2 and block_log2
+    pub min_block_log2: u32,        // smallest leaf under partition_search (0 = 3: 8x8)
+    pub me_presearch: u32,          // 1 = quarter-resolution pre-search (+-64) before the full-resolution search
 }
 #[repr(C)]
 pub struct Av1miJob {               // include/av1mi.h: av1mi_job  <->  Av1anEncodeParams (av1an.rs:36-45)
@@ -48,12 +51,12 @@ extern "C" {
     fn av1mi_encode_file(job: *const Av1miJob, cb: ProgressCb, user: *mut c_void, total: *mut Av1miReport) -> c_int;
 }
 
-// Layout pin (include/av1mi.h: av1mi_struct_sizes).  Compile time: the sizes this file was written against (ABI version 6, LP64);
+// Layout pin (include/av1mi.h: av1mi_struct_sizes).  Compile time: the sizes this file was written against (ABI version 7, LP64);
 // run time, once: the library's own sizes and offsets - a libav1mi.so built from another revision of the header is refused
 // instead of being handed structures it would read past.
-pub const AV1MI_ABI_VERSION: u32 = 6;
-const _: () = assert!(std::mem::size_of::<Av1miParams>() == 32 * 4);
-const _: () = assert!(std::mem::size_of::<Av1miJob>() == 3 * 8 + 3 * 4 + 32 * 4 + 4 /* tail padding to 8 */);
+pub const AV1MI_ABI_VERSION: u32 = 7;
+const _: () = assert!(std::mem::size_of::<Av1miParams>() == 35 * 4);
+const _: () = assert!(std::mem::size_of::<Av1miJob>() == 3 * 8 + 3 * 4 + 35 * 4);
 const _: () = assert!(std::mem::size_of::<Av1miReport>() == 120);
 pub fn check_layout() -> Result<(), EncodeError> {
     static ONCE: std::sync::OnceLock<bool> = std::sync::OnceLock::new();

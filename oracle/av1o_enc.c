@@ -1620,6 +1620,38 @@ static void write_lr(Enc *e, int mi_r, int mi_c) {
 /* ------------------------------------------------------------------ partition §5.11.4 */
 static int icdf_prob(const uint16_t *icdf, int el) { return (el > 0 ? icdf[el - 1] : 32768) - icdf[el]; }
 
+/* Content-driven split decision (cfg->partition_search; SURVEY.md §8a row a10 "19 block sizes" - the decision SVT-AV1
+ * spends most of `--preset 3` on, av1an.rs:14).  Open loop, from the SOURCE luma alone (so that the HIP path takes it for all frames of a
+ * chunk in one pass before the tile walks): the node of size n at (x, y) splits when its four quadrants differ in ACTIVITY - the largest
+ * quadrant variance exceeds four times the smallest plus (ac_q / 16)^2, about half a quantiser step in the sample domain, squared: an edge
+ * or a textured object in one corner of an otherwise quiet block.  (A difference in LEVEL between the quadrants is no reason to split:
+ * gradients predict and transform well in large blocks - measured on the 1080p clip, splitting on it coded 60 % more bytes.)
+ * Sums over the quadrants' samples as the decoder will see the block: coordinates beyond the frame repeat its last column / row.
+ * Integer only: S = sum, Q = sum of squares, V = m Q - S^2 = m^2 x variance (m = samples per quadrant). */
+static int partition_wants_split(const Enc *e, int x, int y, int n) {
+  const int h = n >> 1, w_ = e->cfg->width, h_ = e->cfg->height, st = e->src->stride[0];
+  const uint16_t *p = e->src->p[0];
+  const int64_t m = (int64_t)h * h, t = e->ac_q >> 4;
+  int64_t vmin = INT64_MAX, vmax = 0;
+  int q, i, j;
+  for (q = 0; q < 4; q++) {
+    const int x0 = x + (q & 1) * h, y0 = y + (q >> 1) * h;
+    int64_t S = 0, Q = 0, V;
+    for (i = 0; i < h; i++) {
+      const int yy = y0 + i < h_ ? y0 + i : h_ - 1;
+      for (j = 0; j < h; j++) {
+        const int xx = x0 + j < w_ ? x0 + j : w_ - 1;
+        const int64_t v = p[(size_t)yy * st + xx];
+        S += v; Q += v * v;
+      }
+    }
+    V = m * Q - S * S;
+    if (V < vmin) vmin = V;
+    if (V > vmax) vmax = V;
+  }
+  return vmax > 4 * vmin + t * t * m * m;
+}
+
 static void encode_partition(Enc *e, int mi_r, int mi_c, int bsl) {
   const Geom *g = e->g;
   const Av1oConfig *cfg = e->cfg;
@@ -1635,7 +1667,7 @@ static void encode_partition(Enc *e, int mi_r, int mi_c, int bsl) {
    * whole block and keeps what is inside, the encoder sees the source extended by replication there. */
   if (bsl <= cfg->min_bs_log2 || bsl == 3) split = 0;
   else if (bsl > cfg->max_bs_log2) split = 1;
-  else split = 0;
+  else split = cfg->partition_search ? partition_wants_split(e, mi_c * 4, mi_r * 4, 1 << bsl) : 0;
   if (!has_rows || !has_cols) split = 1;
   if (bsl == 3) split = 0;
   /* context (§8.3.2 partition): neighbours' block sizes */

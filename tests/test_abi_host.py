@@ -262,3 +262,24 @@ def test_job_execute_failure_paths_without_gpu(av1mi, tmp_path):
     rc, stages, m, err = av1mi.job_execute("j2", bad, tmp_path / "o.ivf", tmp_path / "tmp")
     assert rc == av1mi.E_FORMAT and stages == ["encoding", "failed"] and err == "MI355X encoder failed with exit code: %d" % av1mi.E_FORMAT
     assert m.stage == b"failed" and not (tmp_path / "tmp" / "chunks_j2").exists()
+
+
+def test_integration_patches_apply_to_the_reference(tmp_path):
+    """integration/*.patch (the backend selector, the startup gate, the call site) apply cleanly to the reference's
+    files.  Runs where the reference tree is present (this container); it is not part of what travels to the GPU box."""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "crates")) or not shutil.which("patch"):
+        pytest.skip("no reference tree / no patch(1) here")
+    work = tmp_path / "ref"
+    shutil.copytree(os.path.join(ref, "crates"), work / "crates")
+    patches = sorted(f for f in os.listdir(os.path.join(ROOT, "integration")) if f.endswith(".patch"))
+    assert len(patches) == 6
+    for f in patches:
+        r = subprocess.run(["patch", "-p1", "--forward", "-i", os.path.join(ROOT, "integration", f)], cwd=work, capture_output=True, text=True)
+        assert r.returncode == 0, (f, r.stdout, r.stderr)
+    shutil.copy(os.path.join(ROOT, "integration", "mi355x.rs"), work / "crates" / "daemon" / "src" / "encode" / "mi355x.rs")
+    ex = (work / "crates" / "daemon" / "src" / "job_executor.rs").read_text()
+    assert "EncoderBackend::Mi355x => run_mi355x(&params, cq_level)" in ex and "EncoderBackend::Av1an => run_av1an(&params)" in ex
+    assert 'pub mod mi355x;' in (work / "crates" / "daemon" / "src" / "encode" / "mod.rs").read_text()

@@ -43,8 +43,8 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
     n = 0
     for m in golden_cases:
         cfgk = dict(m["config"])
-        bs = cfgk.pop("min_bs_log2", 4)
-        cfgk.pop("max_bs_log2", None)
+        min_bs = cfgk.pop("min_bs_log2", 4)
+        bs = cfgk.pop("max_bs_log2", min_bs)   # block_log2 = the largest leaf; under partition_search leaves go down to min_block_log2
         qidx = cfgk.get("base_q_idx", 120)
         # what the C ABI cannot express stays with the oracle tests: fuzzed levels / modes, a film-grain seed other than the ABI's
         # rule, tile layouts other than 1x1 / 2x2 superblocks, quantiser indices no CQ level maps to
@@ -58,6 +58,7 @@ def test_golden_fixtures_through_the_c_abi(av1mi, ctx, oracle, golden_cases):
         p.intra_edge_filter = cfgk.get("intra_edge_filter", 0)
         p.cfl = cfgk.get("cfl", 0)
         p.tx_search = cfgk.get("tx_search", 0)
+        p.partition_search, p.min_block_log2 = cfgk.get("partition_search", 0), min_bs
         for k in ("color_primaries", "transfer_characteristics", "matrix_coefficients", "color_range"):
             setattr(p, k, cfgk.get(k, 0))
         p.film_grain = cfgk.get("fg_c_scaling", 0)  # table N: scaling 2N / N, seed 7391 for frame 0
@@ -299,6 +300,27 @@ def test_bitstream_slots_beyond_4_gb(av1mi, monkeypatch):
     assert list(s1) == list(s8) and d1 == d8
 
 
+@pytest.mark.parametrize("w,h,bd,n,lo,hi,keyint,extra", [
+    (648, 360, 8, 2, 3, 5, 1, dict()), (648, 360, 10, 3, 3, 6, 2, dict(intra_mode_mask=0x1FFF)), (328, 248, 8, 4, 4, 5, 240, dict(subpel=1, deblock=1)),
+    (392, 264, 10, 3, 3, 6, 240, dict(enable_lr=2, me_range=16)), (202, 122, 8, 3, 3, 6, 3, dict(cfl=1, intra_edge_filter=1, intra_mode_mask=0x1FFF, intra_angle_delta=1))])
+def test_content_driven_partition_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, lo, hi, keyint, extra):
+    """partition_search: the split masks come from the GPU's pass over the source (partition_kernel), every kernel that walks blocks -
+    reconstruction, motion search and refinement, symbolize - follows them; bitstream and reconstruction equal the oracle's, whose rule
+    (partition_wants_split) reads the same source, and more than one block size occurs."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=117, t=t) for t in range(n)]
+    p = av1mi.default_params(w, h, bd, block_log2=hi, keyint=keyint, partition_search=1, min_block_log2=lo, **extra)
+    data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, bd) for f in frames), n, want_recon=True)
+    okw = dict(min_bs_log2=lo, max_bs_log2=hi, partition_search=1)
+    for k, v in extra.items():
+        okw[{"intra_mode_mask": "mode_mask", "intra_angle_delta": "angle_delta"}.get(k, k)] = v
+    cfg = oracle.default_config(w, h, bd, **okw)
+    tus, recs = oracle_chunk(oracle, cfg, frames, keyint)
+    assert data == b"".join(tus) and [len(t) for t in tus] == list(sizes)
+    assert recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
+    _, _, st = oracle.encode_frame(cfg, frames[0])
+    assert sum(1 for k in (3, 4, 5, 6) if st.bs_hist[k]) >= 2, list(st.bs_hist)
+
+
 def test_film_grain_table_in_frame_headers(av1mi, ctx, oracle):
     """`film_grain = N` (the reference's `--film-grain N`, av1an.rs:14): every frame header carries a
     film-grain table with its own grain_seed; tile data and reconstruction are untouched.  Bit-exact
@@ -409,7 +431,8 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
     n = 0
     for m in golden_sequences:
         cfgk = dict(m["config"])
-        bs = cfgk.get("min_bs_log2", 4)
+        min_bs = cfgk.get("min_bs_log2", 4)
+        bs = cfgk.get("max_bs_log2", min_bs)
         if any(k.startswith("fuzz") for k in cfgk) or cfgk.get("tile_w_sb", 1) != 1 or cfgk.get("film_grain"):
             continue
         if m["width"] % 8 or m["height"] % 8:
@@ -419,6 +442,7 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
                                  subpel=cfgk.get("subpel", 0), intra_mode_mask=cfgk.get("mode_mask", 0), intra_angle_delta=cfgk.get("angle_delta", 0))
         p.intra_edge_filter = cfgk.get("intra_edge_filter", 0)
         p.cfl = cfgk.get("cfl", 0)
+        p.partition_search, p.min_block_log2 = cfgk.get("partition_search", 0), min_bs
         if cfgk.get("enable_qm"):
             p.enable_qm, p.qm_min, p.qm_max = 1, cfgk["qm_y"], cfgk["qm_y"]
         frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]

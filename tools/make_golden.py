@@ -123,6 +123,11 @@ CASES = [
     # and a BT.709 full-range one): dav1d decodes the stream, libavif's own sequence-header parser reads the code points back
     ("k200x120_hdr_bt2020_pq_10b", 200, 120, 10, 1080, 12, dict(min_bs_log2=5, max_bs_log2=5, color_primaries=9, transfer_characteristics=16, matrix_coefficients=9)),
     ("k72x56_bt709_full", 72, 56, 8, 11, 1, dict(min_bs_log2=4, max_bs_log2=4, color_primaries=1, transfer_characteristics=1, matrix_coefficients=1, color_range=1)),
+    # content-driven partition (partition_search): leaves of 8 .. 32 / 8 .. 64 mixed by the source's activity, with the other tools on top
+    ("k328x248_part_5_3", 328, 248, 8, 111, 0, dict(min_bs_log2=3, max_bs_log2=5, partition_search=1)),
+    ("k264x200_part_6_3_all13_10b", 264, 200, 10, 112, 1, dict(min_bs_log2=3, max_bs_log2=6, partition_search=1, mode_mask=0x1FFF, angle_delta=1)),
+    ("k328x248_part_5_4_cfl_ef_lr2_deblock_10b", 328, 248, 10, 113, 2, dict(min_bs_log2=4, max_bs_log2=5, partition_search=1, cfl=1, intra_edge_filter=1, mode_mask=0x1FFF, enable_lr=2, deblock=1)),
+    ("k202x122_part_6_3_odd_qm", 202, 122, 8, 114, 0, dict(min_bs_log2=3, max_bs_log2=6, partition_search=1, enable_qm=1, qm_y=5, qm_uv=5)),
     ("fuzz_modes", 136, 72, 8, 21, 0, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=121)),
     ("fuzz_coefs_sparse", 64, 64, 8, 22, 0, dict(min_bs_log2=5, max_bs_log2=5, fuzz_coeffs=22, fuzz_density=30, fuzz_maxlevel=300, mode_mask=1)),
     ("fuzz_coefs_dense", 64, 64, 10, 23, 0, dict(min_bs_log2=3, max_bs_log2=3, fuzz_coeffs=23, fuzz_density=2, fuzz_maxlevel=16, mode_mask=1)),
@@ -172,6 +177,8 @@ SEQ_CASES = [
     ("pfuzz_ef_bs3_10b", 136, 120, 10, 94, 3, dict(min_bs_log2=3, max_bs_log2=3, mode_mask=0x1FFF, fuzz_modes=21, intra_edge_filter=1)),
     ("p200x120_cfl", 200, 120, 8, 103, 3, dict(min_bs_log2=5, max_bs_log2=5, cfl=1)),
     ("pfuzz_cfl_bs4_10b", 136, 120, 10, 104, 3, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, fuzz_modes=23, cfl=1)),
+    ("p328x248_part_6_3_subpel", 328, 248, 8, 115, 3, dict(min_bs_log2=3, max_bs_log2=6, partition_search=1, subpel=1)),
+    ("p264x200_part_5_3_lr2_deblock_10b", 264, 200, 10, 116, 3, dict(min_bs_log2=3, max_bs_log2=5, partition_search=1, enable_lr=2, deblock=1, me_range=16)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
@@ -236,6 +243,7 @@ def main():
         open(os.path.join(OUT, name + ".obu"), "wb").write(tu)
         meta = dict(name=name, width=w, height=h, bit_depth=bd, seed=seed, t=t, config=kw, src_shift=src_shift, bytes=len(tu),
                     dav1d_sha256=sha(dec), recon_sha256=sha(rec), dav1d_applies_grain=grain, src_sha256=sha(src), n_symbols=int(st.n_symbols),
+                    **({"block_sizes_8_16_32_64": [int(st.bs_hist[k]) for k in (3, 4, 5, 6)]} if kw.get("partition_search") else {}),
                     psnr=[round(x, 3) for x in av1o.psnr(st, cfg)], decoder="dav1d 1.5.3 via libavif 1.4.1 (Pillow 12.2.0)")
         json.dump(meta, open(os.path.join(OUT, name + ".json"), "w"), indent=1, sort_keys=True)
         index.append(name)
