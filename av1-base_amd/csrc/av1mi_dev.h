@@ -62,6 +62,7 @@ struct Av1miDevParams {
   // inter coding: key frame every `keyint` frames of the chunk (1 = all key frames); motion search range
   int keyint, me_range;
   int subpel;                     // inter frames: 1 = quarter-sample vectors (refined search) + EIGHTTAP filter; 0 = whole-sample vectors, BILINEAR
+  int me_presearch;               // inter frames: 1 = the full search runs around the centre a quarter-resolution pre-search found per superblock
   // deblocking filter: loop_filter_level[0..3] (luma vertical edges, luma horizontal, U, V) of key / inter frames and sharpness
   int lf_level[4], lf_level_inter[4], lf_sharpness;
   // loop restoration (luma Wiener, 64x64 units): literal bits that code candidate k's coefficients against the
@@ -100,6 +101,19 @@ AV1MI_HD inline int av1mi_leaf_bsl_at(int width, int height, int min_bs_log2, in
     if (!av1mi_node_split(width, height, min_bs_log2, max_bs_log2, have_mask, mask, sb_x, sb_y, ox, oy, bsl)) return (ox == bx && oy == by) ? bsl : 0;
   }
   return 0;
+}
+
+// ---- motion search keys (me_kernel.hip -> recon_kernel.hip): per leaf a 64-bit key, the minimum over its candidates of
+//   (centre code << 40) | (cost << 16) | candidate index,   cost = SAD + n (|dx| + |dy|) < 2^24,   index = (dy - Cy + R) (2 R + 1) + (dx - Cx + R)
+// centre code = (Cy / 8 & 0xFFF) << 12 | (Cx / 8 & 0xFFF): the centre (Cx, Cy) of the superblock's search in units of 8 luma samples, 12-bit two's
+// complement - zero without the quarter-resolution pre-search (av1mi_params.me_presearch), the same for every candidate of a leaf, so the
+// minimum is taken over (cost, index) as before.
+AV1MI_HD inline int av1mi_sext12(uint32_t v) { return (int)((v & 0xFFFu) ^ 0x800u) - 0x800; }
+AV1MI_HD inline void av1mi_me_key_decode(unsigned long long key, int R, int *dy, int *dx, int *cost) {
+  const int nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
+  *dy = idx / nc - R + 8 * av1mi_sext12((uint32_t)(key >> 52));
+  *dx = idx % nc - R + 8 * av1mi_sext12((uint32_t)(key >> 40));
+  *cost = (int)((key >> 16) & 0xFFFFFF);
 }
 
 // frame f of a chunk is a key frame iff f % keyint == 0

@@ -34,7 +34,9 @@ hipError_t av1mi_launch_recon64(const Av1miDevParams *P, const Av1miDevParams *d
 hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, const unsigned long long *best, unsigned long long *refined,
                                       int me_range, int frame0, int count, hipStream_t stream);
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
-                                      int count, uint32_t *acc64, hipStream_t s);
+                                      int count, uint32_t *acc64, const uint32_t *centre, hipStream_t stream);
+hipError_t av1mi_launch_quarter_luma(const Av1miDevParams *P, const void *frames, uint16_t *quarter, hipStream_t stream);
+hipError_t av1mi_launch_presearch(const Av1miDevParams *P, const uint16_t *quarter, uint32_t *centre, int frame0, int count, hipStream_t stream);
 hipError_t av1mi_launch_luma_sad(const Av1miDevParams *P, const void *frames, const void *prev0, unsigned long long *sad, hipStream_t s);
 hipError_t av1mi_launch_pad(const void *in, void *out, int w, int h, int cw, int ch, int bit_depth, int n_frames, int crop, hipStream_t s);
 hipError_t av1mi_launch_deblock(const Av1miDevParams *P, void *rec, const Av1miBlkInfo *blk, hipStream_t s);
@@ -112,7 +114,6 @@ int resolve(const av1mi_params *in, Resolved *r) {
   r->qidx = kQuantizerToQindex[p.cq_level];
   if (p.subpel > 1 || p.enable_lr > 2 || p.color_range > 1 || p.intra_angle_delta > 1 || p.intra_edge_filter > 1 || p.cfl > 1 || p.tx_search > 1) return AV1MI_E_INVALID_ARG;
   if (p.partition_search > 1 || p.me_presearch > 1) return AV1MI_E_INVALID_ARG;
-  if (p.me_presearch) return AV1MI_E_UNSUPPORTED;   // (not built yet)
   if (p.min_block_log2 == 0) p.min_block_log2 = 3;
   if (p.min_block_log2 < 3 || p.min_block_log2 > p.block_log2) return AV1MI_E_INVALID_ARG;
   if (p.color_primaries > 255 || p.transfer_characteristics > 255 || p.matrix_coefficients > 255) return AV1MI_E_INVALID_ARG;
@@ -445,6 +446,8 @@ struct av1mi_ctx {
   void *d_cd = nullptr;                // loop restoration on: CDEF output (d_fin then holds the restored frames)
   unsigned long long *d_me_sub = nullptr;  // sub-sample refinement: refined [frame][8x8 unit] keys (me_kernel.hip)
   uint16_t *d_cdefdir = nullptr;           // chunk-wide CDEF: {adjusted luma primary strength << 3 | direction} per 8x8 block (cdef_dir_kernel)
+  uint16_t *d_quarter = nullptr;           // me_presearch: quarter-resolution luma of every frame of the chunk
+  uint32_t *d_centre = nullptr;            // me_presearch: centre code of the full search per [frame][superblock]
   uint32_t *d_part = nullptr;              // content-driven partition: split mask per [frame][superblock] (partition_kernel)
   uint32_t *d_me64 = nullptr;              // 64x64 leaves: the search's [frame][superblock][candidate] SAD table
   size_t me64_bytes = 0;
@@ -482,11 +485,11 @@ void set_err(av1mi_ctx *c, const char *fmt, ...) {
 
 void free_workspace(av1mi_ctx *c) {
   void *ptrs[] = { c->d_src, c->d_rec, c->d_fin, c->d_levels, c->d_blk, c->d_slots, c->d_out, c->d_hdr, c->d_cdf, c->d_tile_bytes,
-                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params, c->d_me64, c->d_cdefdir, c->d_part };
+                   c->d_tile_off, c->d_frame_size, c->d_payload, c->d_sym, c->d_frame_off, c->d_sse, c->d_overflow, c->d_streams, c->d_combos, c->d_me, c->d_cd, c->d_lrc, c->d_stage, c->d_qm, c->d_me_sub, c->d_lrsse, c->d_params, c->d_me64, c->d_cdefdir, c->d_part, c->d_quarter, c->d_centre };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->d_src = c->d_rec = c->d_fin = nullptr; c->d_levels = nullptr; c->d_blk = nullptr; c->d_slots = c->d_out = c->d_hdr = nullptr;
   c->d_cdf = nullptr; c->d_tile_bytes = c->d_tile_off = c->d_frame_size = c->d_payload = c->d_sym = nullptr;
-  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr; c->d_me64 = nullptr; c->me64_bytes = 0; c->d_cdefdir = nullptr; c->d_part = nullptr;
+  c->d_frame_off = c->d_sse = nullptr; c->d_overflow = nullptr; c->d_streams = c->d_combos = nullptr; c->d_me = nullptr; c->d_cd = nullptr; c->d_lrc = nullptr; c->d_stage = nullptr; c->d_qm = nullptr; c->qm_key = -1; c->d_me_sub = nullptr; c->d_lrsse = nullptr; c->d_params = nullptr; c->d_me64 = nullptr; c->me64_bytes = 0; c->d_cdefdir = nullptr; c->d_part = nullptr; c->d_quarter = nullptr; c->d_centre = nullptr;
   if (c->h_out) (void)hipHostFree(c->h_out);
   c->h_out = nullptr; c->h_out_cap = 0;
   c->cap_frames = 0;
@@ -546,6 +549,10 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   if ((r.cw != (int)p.width || r.ch != (int)p.height) && !c->d_stage)
     HIPCHK(c, hipMalloc(&c->d_stage, c->cap_frames * (size_t)p.width * p.height * 3 / 2 * bps));
   if (p.partition_search && !c->d_part) HIPCHK(c, hipMalloc((void **)&c->d_part, c->cap_frames * nsb * sizeof(uint32_t)));
+  if (p.me_presearch && !c->d_quarter) {
+    HIPCHK(c, hipMalloc((void **)&c->d_quarter, c->cap_frames * (size_t)(r.cw / 4) * (r.ch / 4) * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_centre, c->cap_frames * nsb * sizeof(uint32_t)));
+  }
   if (p.subpel && !c->d_me_sub)   // output of the sub-sample refinement
     HIPCHK(c, hipMalloc((void **)&c->d_me_sub, (size_t)c->cap_frames * (r.cw / 8) * (r.ch / 8) * 8));
   if (p.block_log2 >= 6 && p.keyint > 1) {   // candidate table of the 64x64 leaves' motion search
@@ -621,6 +628,7 @@ int ensure_workspace(av1mi_ctx *c, const Resolved &r, uint32_t n_frames) {
   P.keyint = (int)p.keyint;
   P.me_range = (int)p.me_range;
   P.subpel = p.subpel ? 1 : 0;
+  P.me_presearch = p.me_presearch ? 1 : 0;
   P.hdr_slot_bytes = 512;
   for (int i = 0; i < 4; i++) { P.lf_level[i] = deblock_level(r, true); P.lf_level_inter[i] = deblock_level(r, false); }
   P.lf_sharpness = 0;
@@ -1054,12 +1062,19 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       c->me_ev.push_back(e);
     }
+    // hierarchical search: the chunk's luma at a quarter of the resolution (one launch), then per frame the superblocks' search centres
+    const uint32_t *centre = nullptr;
+    if (P.me_presearch) {
+      HIPCHK(c, av1mi_launch_quarter_luma(&P, d_src, c->d_quarter, c->stream2));
+      centre = c->d_centre;
+    }
     uint32_t me_next = 0;
     auto search_upto = [&](uint32_t upto) -> int {   // enqueue the search of the frames below `upto` that are not enqueued yet
       for (; me_next < upto && me_next < n_frames; me_next++) {
         const uint32_t f = me_next;
         if (!av1mi_frame_is_inter(P, (int)f)) continue;
-        HIPCHK(c, av1mi_launch_motion_search(&P, d_src, c->d_me, P.me_range, (int)f, 1, acc64, c->stream2));
+        if (centre) HIPCHK(c, av1mi_launch_presearch(&P, c->d_quarter, c->d_centre, (int)f, 1, c->stream2));
+        HIPCHK(c, av1mi_launch_motion_search(&P, d_src, c->d_me, P.me_range, (int)f, 1, acc64, centre, c->stream2));
         if (P.subpel) HIPCHK(c, av1mi_launch_subpel_refine(&P, d_src, c->d_me, c->d_me_sub, P.me_range, (int)f, 1, c->stream2));
         HIPCHK(c, hipEventRecord(c->me_ev[f], c->stream2));
       }

@@ -50,7 +50,8 @@ template <typename PIX, int R>
 __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, const PIX *__restrict__ frames,
                                                           unsigned long long *__restrict__ best_all /* [frame][8x8 unit] */, int frame0,
                                                           int vec_ok /* frames are 16-byte aligned */,
-                                                          uint32_t *__restrict__ acc64 /* 64x64 leaves: [frame][superblock][candidate] SAD sums, zeroed */) {
+                                                          uint32_t *__restrict__ acc64 /* 64x64 leaves: [frame][superblock][candidate] SAD sums, zeroed */,
+                                                          const uint32_t *__restrict__ centre /* pre-search: [frame][superblock] centre codes, or null */) {
   constexpr int NC = 2 * R + 1;
   __shared__ uint32_t sad8[NC][16];  // [dx][8x8 sub-block of the cell, raster]
   const int f = frame0 + blockIdx.z;
@@ -58,8 +59,13 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
   const PIX *src = frames + (size_t)f * P.frame_samples, *ref = src - P.frame_samples;  // luma of this and of the previous source frame
   unsigned long long *best = best_all + (size_t)f * P.b8_rows * P.b8_cols;
   const int cells_x = (P.width + 31) >> 5;
-  const int cell = blockIdx.x, dyi = blockIdx.y, dy = dyi - R;
+  const int cell = blockIdx.x, dyi = blockIdx.y;
   const int cx = (cell % cells_x) * 32, cy = (cell / cells_x) * 32;
+  // centre of the superblock's search (av1mi_dev.h: motion search keys): whole multiples of 8 luma samples, zero without a pre-search
+  const uint32_t ccode = centre ? centre[((size_t)f * P.sb_rows + (cy >> 6)) * P.sb_cols + (cx >> 6)] : 0u;
+  const int ccx = 8 * av1mi_sext12(ccode), ccy = 8 * av1mi_sext12(ccode >> 12);
+  const unsigned long long ctop = (unsigned long long)ccode << 40;
+  const int dy = dyi - R + ccy;
   const int lane = threadIdx.x, r = lane >> 1, half = lane & 1;
   const int W = P.width, H = P.height;
   // ---- source: 16 samples of row cy + r (edge samples replicated outside the frame), reference: samples
@@ -71,7 +77,7 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
     const int y = cy + r, xs = cx + half * 16;
     int yr = cy + r + dy;
     yr = yr < 0 ? 0 : (yr > H - 1 ? H - 1 : yr);
-    const int xr = xs - R;
+    const int xr = xs - R + ccx;
     const PIX *srow = src + (size_t)(y < H ? y : H - 1) * P.stride_y, *rrow = ref + (size_t)yr * P.stride_y;
     if (sizeof(PIX) == 2 && vec_ok && y < H && xs + 16 <= W && xr >= 0 && xr + 16 + 2 * R <= W) {
       // interior, 16-bit samples: 16-byte loads (xs and xr are multiples of 8 samples)
@@ -137,13 +143,13 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
     if (cy + dy >= -16 && cy + dy + 32 <= H + 16) {
       unsigned long long key = ~0ull;
       if (lane < NC) {
-        const int dx = lane - R;
+        const int dx = lane - R + ccx;
         if (!(cx + dx < -16 || cx + dx + 32 > W + 16)) {
           uint32_t sad = 0;
 #pragma unroll
           for (int i = 0; i < 16; i++) sad += sad8[lane][i];
           const unsigned long long cost = (unsigned long long)sad + (unsigned long long)(32 * (iabs(dx) + iabs(dy)));
-          key = (cost << 16) | (unsigned long long)(dyi * NC + lane);
+          key = ctop | (cost << 16) | (unsigned long long)(dyi * NC + lane);
         }
       }
       for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = t < key ? t : key; }
@@ -161,13 +167,13 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
       if (y + dy >= -16 && y + dy + n <= H + 16) {
         unsigned long long bk = ~0ull;
         for (int dxi = 0; dxi < NC; dxi++) {
-          const int dx = dxi - R;
+          const int dx = dxi - R + ccx;
           if (x + dx < -16 || x + dx + n > W + 16) continue;
           uint32_t sad = 0;
           for (int i = 0; i < n8; i++)
             for (int j = 0; j < n8; j++) sad += sad8[dxi][(uy + i) * 4 + ux + j];
           const unsigned long long cost = (unsigned long long)sad + (unsigned long long)(n * (iabs(dx) + iabs(dy)));
-          const unsigned long long key = (cost << 16) | (unsigned long long)(dyi * NC + dxi);
+          const unsigned long long key = ctop | (cost << 16) | (unsigned long long)(dyi * NC + dxi);
           bk = key < bk ? key : bk;
         }
         if (bk != ~0ull) atomicMin(&best[(size_t)((cy >> 3) + uy) * P.b8_cols + (cx >> 3) + ux], bk);
@@ -179,19 +185,22 @@ __global__ void __launch_bounds__(64) motion_search_kernel(Av1miDevParams P, con
 // One wave per superblock that is a 64x64 leaf: cost and minimum over the candidate table the search filled (same rule: cost =
 // SAD + 64 * (|dx| + |dy|), the displaced block within 16 samples of the frame, ties to the first candidate in raster order).
 __global__ void __launch_bounds__(64) me64_reduce_kernel(Av1miDevParams P, const uint32_t *__restrict__ acc64,
-                                                        unsigned long long *__restrict__ best_all, int frame0, int R) {
+                                                        unsigned long long *__restrict__ best_all, int frame0, int R, const uint32_t *__restrict__ centre) {
   const int f = frame0 + blockIdx.y;
   if (!av1mi_frame_is_inter(P, f)) return;
   const int sb = blockIdx.x, x = (sb % P.sb_cols) * 64, y = (sb / P.sb_cols) * 64;
   if (!cell_in_leaf64(P, f, x, y)) return;
   const int NC = 2 * R + 1, lane = threadIdx.x;
+  const uint32_t ccode = centre ? centre[(size_t)f * P.sb_rows * P.sb_cols + sb] : 0u;
+  const int ccx = 8 * av1mi_sext12(ccode), ccy = 8 * av1mi_sext12(ccode >> 12);
+  const unsigned long long ctop = (unsigned long long)ccode << 40;
   const uint32_t *tab = acc64 + ((size_t)f * P.sb_rows * P.sb_cols + sb) * NC * NC;
   unsigned long long key = ~0ull;
   for (int c = lane; c < NC * NC; c += 64) {
-    const int dy = c / NC - R, dx = c % NC - R;
+    const int dy = c / NC - R + ccy, dx = c % NC - R + ccx;
     if (x + dx < -16 || x + dx + 64 > P.width + 16 || y + dy < -16 || y + dy + 64 > P.height + 16) continue;
     const unsigned long long cost = (unsigned long long)tab[c] + (unsigned long long)(64 * (iabs(dx) + iabs(dy)));
-    const unsigned long long k = (cost << 16) | (unsigned long long)c;
+    const unsigned long long k = ctop | (cost << 16) | (unsigned long long)c;
     key = k < key ? k : key;
   }
   for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = t < key ? t : key; }
@@ -495,8 +504,9 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
   const int u = 1 << (cell_log2 - 3);
   if (cell_log2 == 6 && cell_in_leaf64(P, f, blockIdx.x * 64, blockIdx.y * 64)) {   // this wave's cell is one 64x64 leaf
     const size_t slot = (size_t)f * P.b8_rows * P.b8_cols + (size_t)(blockIdx.y * 8) * P.b8_cols + blockIdx.x * 8;
-    const int cand = (int)(in_all[slot] & 0xFFFF);
-    int best_row = (cand / NC - R) * 8, best_col = (cand % NC - R) * 8, best_sad = 0;
+    int idy, idx_, icost;
+    av1mi_me_key_decode(in_all[slot], R, &idy, &idx_, &icost);
+    int best_row = idy * 8, best_col = idx_ * 8, best_sad = 0;
     refine_leaf64<PIX>(P, src, ref, blockIdx.x * 64, blockIdx.y * 64, best_row, best_col, best_sad, win, mid, srcb, dif);
     if (threadIdx.x == 0)
       out_all[slot] = ((unsigned long long)(uint32_t)best_sad << 36) | ((unsigned long long)(uint16_t)(int16_t)best_row << 16) | (uint16_t)(int16_t)best_col;
@@ -509,8 +519,9 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
       if (!bsl) continue;
       const size_t slot = (size_t)f * P.b8_rows * P.b8_cols + (size_t)uy * P.b8_cols + ux;
       const unsigned long long key = in_all[slot];   // the full search's key: (cost << 16) | candidate index
-      const int cand = (int)(key & 0xFFFF);
-      int best_row = (cand / NC - R) * 8, best_col = (cand % NC - R) * 8;
+      int idy, idx_, icost;
+      av1mi_me_key_decode(key, R, &idy, &idx_, &icost);
+      int best_row = idy * 8, best_col = idx_ * 8;
       int best_sad = 0;
       switch (bsl) {
         case 5: refine_leaf<PIX, 5>(P, src, ref, ux * 8, uy * 8, best_row, best_col, best_sad, win, mid, srcb, dif); break;
@@ -522,7 +533,92 @@ __global__ void __launch_bounds__(64) subpel_refine_kernel(Av1miDevParams P, con
     }
 }
 
+// ---- hierarchical search, first level (av1mi_params.me_presearch; SURVEY.md §8a row a13 "hierarchical: 1/4-res ... full").
+// quarter_luma_kernel: q(Y, X) = (sum of the 4x4 luma samples + 8) >> 4 of every frame of the chunk (16-bit whatever the bit depth);
+// one thread per quarter-resolution sample, four 4-sample loads each.  Algorithmic bytes L b + L / 8 per frame.
+template <typename PIX>
+__global__ void __launch_bounds__(256) quarter_luma_kernel(Av1miDevParams P, const PIX *__restrict__ frames, uint16_t *__restrict__ quarter) {
+  const int qw = P.width >> 2, qh = P.height >> 2, f = blockIdx.y;
+  const PIX *luma = frames + (size_t)f * P.frame_samples;
+  uint16_t *q = quarter + (size_t)f * qw * qh;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < qw * qh; i += gridDim.x * 256) {
+    const int y = i / qw, x = i - y * qw;
+    uint32_t s = 8;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const PIX *row = luma + (size_t)(4 * y + r) * P.stride_y + 4 * x;
+      if (sizeof(PIX) == 2) { const uint2 v = *reinterpret_cast<const uint2 *>(row); s += (v.x & 0xFFFF) + (v.x >> 16) + (v.y & 0xFFFF) + (v.y >> 16); }
+      else { const uint32_t v = *reinterpret_cast<const uint32_t *>(row); s += (v & 0xFF) + ((v >> 8) & 0xFF) + ((v >> 16) & 0xFF) + (v >> 24); }
+    }
+    q[i] = (uint16_t)(s >> 4);
+  }
+}
+
+// presearch_kernel: one wave per superblock of an inter frame.  The superblock's 16x16 quarter-resolution block and the 48x48 window of the
+// previous frame around it (coordinates clamped to the plane) are staged in LDS; per dqy lane = dqx + 16 takes the SAD of its candidate (the
+// block's sample is a broadcast read, the window's consecutive), cost = SAD + 16 (|dqx| + |dqy|); a candidate whose centre would push the
+// superblock more than 16 samples out of the frame is skipped; minimum over (cost, raster index).  Writes the centre code of the winner
+// rounded to whole multiples of 8 luma samples (av1mi_dev.h: motion search keys).
+__global__ void __launch_bounds__(64) presearch_kernel(Av1miDevParams P, const uint16_t *__restrict__ quarter, uint32_t *__restrict__ centre, int frame0) {
+  __shared__ uint16_t cur[16][16];
+  __shared__ uint16_t win[48][50];
+  const int f = frame0 + blockIdx.y;
+  if (!av1mi_frame_is_inter(P, f)) return;
+  const int sb = blockIdx.x, lane = threadIdx.x;
+  const int sx = (sb % P.sb_cols) * 64, sy = (sb / P.sb_cols) * 64;
+  const int W = P.width, H = P.height, qw = W >> 2, qh = H >> 2;
+  const uint16_t *qc = quarter + (size_t)f * qw * qh, *qp = qc - (size_t)qw * qh;
+  for (int i = lane; i < 256; i += 64) {
+    int y = (sy >> 2) + (i >> 4), x = (sx >> 2) + (i & 15);
+    y = y > qh - 1 ? qh - 1 : y; x = x > qw - 1 ? qw - 1 : x;
+    cur[i >> 4][i & 15] = qc[(size_t)y * qw + x];
+  }
+  for (int i = lane; i < 48 * 48; i += 64) {
+    const int r = i / 48, c = i - r * 48;
+    // window sample (r, c) = previous plane at (block row - 16 + r, block column - 16 + c), coordinates clamped to the plane
+    int y = (sy >> 2) - 16 + r, x = (sx >> 2) - 16 + c;
+    y = y < 0 ? 0 : (y > qh - 1 ? qh - 1 : y); x = x < 0 ? 0 : (x > qw - 1 ? qw - 1 : x);
+    win[r][c] = qp[(size_t)y * qw + x];
+  }
+  __syncthreads();
+  const int sbw = W - sx < 64 ? W - sx : 64, sbh = H - sy < 64 ? H - sy : 64;
+  uint32_t best = 0xFFFFFFFFu;
+  const int dqx = lane - 16;
+  for (int dqy = -16; dqy <= 16; dqy++) {
+    if (lane > 32) continue;
+    const int ccx = ((dqx + 1) >> 1) * 8, ccy = ((dqy + 1) >> 1) * 8;
+    if (sx + ccx < -16 || sx + ccx + sbw > W + 16 || sy + ccy < -16 || sy + ccy + sbh > H + 16) continue;
+    uint32_t sad = 0;
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) sad = __builtin_amdgcn_sad_u16((uint32_t)cur[i][j], (uint32_t)win[i + dqy + 16][j + dqx + 16], sad);
+    }
+    const uint32_t cost = sad + 16u * (uint32_t)(iabs(dqx) + iabs(dqy));
+    const uint32_t key = (cost << 11) | (uint32_t)((dqy + 16) * 33 + lane);
+    best = key < best ? key : best;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t < best ? t : best; }
+  if (lane == 0) {
+    const int idx = (int)(best & 0x7FF), bqy = idx / 33 - 16, bqx = idx % 33 - 16;
+    const int c8y = (bqy + 1) >> 1, c8x = (bqx + 1) >> 1;   // centre / 8
+    centre[(size_t)f * P.sb_rows * P.sb_cols + sb] = ((uint32_t)(c8y & 0xFFF) << 12) | (uint32_t)(c8x & 0xFFF);
+  }
+}
+
 }  // namespace
+
+// quarter-resolution luma of all P->n_frames frames of the chunk
+extern "C" hipError_t av1mi_launch_quarter_luma(const Av1miDevParams *P, const void *frames, uint16_t *quarter, hipStream_t stream) {
+  dim3 grid(128, P->n_frames);
+  if (P->bit_depth == 8) hipLaunchKernelGGL(quarter_luma_kernel<uint8_t>, grid, dim3(256), 0, stream, *P, (const uint8_t *)frames, quarter);
+  else hipLaunchKernelGGL(quarter_luma_kernel<uint16_t>, grid, dim3(256), 0, stream, *P, (const uint16_t *)frames, quarter);
+  return hipGetLastError();
+}
+// search centres of frames [frame0, frame0 + count) (key frames are skipped)
+extern "C" hipError_t av1mi_launch_presearch(const Av1miDevParams *P, const uint16_t *quarter, uint32_t *centre, int frame0, int count, hipStream_t stream) {
+  hipLaunchKernelGGL(presearch_kernel, dim3(P->sb_rows * P->sb_cols, count), dim3(64), 0, stream, *P, quarter, centre, frame0);
+  return hipGetLastError();
+}
 
 // Refines the vectors of frames [frame0, frame0 + count): `best` = the full search's keys (av1mi_launch_motion_search on the
 // same stream before), `refined` = same layout, what the recon kernel reads with subpel = 1.
@@ -542,18 +638,18 @@ extern "C" hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const 
 // Searches frames [frame0, frame0 + count) of the chunk.
 extern "C" hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range,
                                                  int frame0, int count, uint32_t *acc64 /* block_log2 = 6: zeroed [frame][superblock][candidate] table, else null */,
-                                                 hipStream_t stream) {
+                                                 const uint32_t *centre /* pre-search centre codes [frame][superblock], or null */, hipStream_t stream) {
   const int cells = ((P->width + 31) >> 5) * ((P->height + 31) >> 5);
   dim3 grid(cells, 2 * me_range + 1, count);
   const int vec_ok = ((uintptr_t)frames & 15) == 0;  // frame size in bytes is a multiple of 32
   if (P->bit_depth == 8) {
-    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint8_t, 8>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok, acc64);
-    else hipLaunchKernelGGL((motion_search_kernel<uint8_t, 16>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok, acc64);
+    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint8_t, 8>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok, acc64, centre);
+    else hipLaunchKernelGGL((motion_search_kernel<uint8_t, 16>), grid, dim3(64), 0, stream, *P, (const uint8_t *)frames, best, frame0, vec_ok, acc64, centre);
   } else {
-    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint16_t, 8>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok, acc64);
-    else hipLaunchKernelGGL((motion_search_kernel<uint16_t, 16>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok, acc64);
+    if (me_range == 8) hipLaunchKernelGGL((motion_search_kernel<uint16_t, 8>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok, acc64, centre);
+    else hipLaunchKernelGGL((motion_search_kernel<uint16_t, 16>), grid, dim3(64), 0, stream, *P, (const uint16_t *)frames, best, frame0, vec_ok, acc64, centre);
   }
   if (P->max_bs_log2 >= 6)
-    hipLaunchKernelGGL(me64_reduce_kernel, dim3(P->sb_rows * P->sb_cols, count), dim3(64), 0, stream, *P, acc64, best, frame0, me_range);
+    hipLaunchKernelGGL(me64_reduce_kernel, dim3(P->sb_rows * P->sb_cols, count), dim3(64), 0, stream, *P, acc64, best, frame0, me_range, centre);
   return hipGetLastError();
 }

@@ -1420,10 +1420,10 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         ii.mv_row = (int16_t)(key >> 16); ii.mv_col = (int16_t)key;
         ii.sad_inter = (int)(key >> 36);
       } else {
-        const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
-        const int dyv = idx / nc - R, dxv = idx % nc - R;
+        int dyv, dxv, cost;
+        av1mi_me_key_decode(key, P.me_range, &dyv, &dxv, &cost);
         ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
-        ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
+        ii.sad_inter = cost - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
       }
       // the block's inter version is done (recon_inter_pre_kernel): its eobs, in case motion compensation wins
       const Av1miBlkInfo &pre = info[(by >> 3) * b8_stride + (bx >> 3)];
@@ -1597,10 +1597,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
         ii.mv_row = (int16_t)(key >> 16); ii.mv_col = (int16_t)key;
         ii.sad_inter = (int)(key >> 36);
       } else {
-        const int R = P.me_range, nc = 2 * R + 1, idx = (int)(key & 0xFFFF);
-        const int dyv = idx / nc - R, dxv = idx % nc - R;
+        int dyv, dxv, cost;
+        av1mi_me_key_decode(key, P.me_range, &dyv, &dxv, &cost);
         ii.mv_row = dyv * 8; ii.mv_col = dxv * 8;
-        ii.sad_inter = (int)(key >> 16) - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
+        ii.sad_inter = cost - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
       }
       const int sb = (cx.sb_y >> 6) * P.sb_cols + (cx.sb_x >> 6);
       int16_t *sb_levels = levels + (size_t)sb * AV1MI_SB_LEVELS;

@@ -276,7 +276,19 @@ def cpu_baseline(w, h, bd, bs, keyint, mask=0x7, budget_frames_per_core=4):
     # every core this process may run on (north_star: "timed on the box's own host cores, core count stated"); 64 bounds the worker
     # pool on very wide hosts (the GPU box's process guard), and the line says so when it bites
     avail = len(os.sched_getaffinity(0))
-    cores = min(avail, 64)
+    quota = None   # the container's CPU share (cgroup v2 cpu.max / v1 cfs quota): what this process can actually run on at once
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per) + 0.5))
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    cores = min(avail, quota if quota else avail, 64)
     legs = []
     ref = _reference_cli_leg(w, h, cores, keyint, 16)
     if ref:
@@ -315,7 +327,7 @@ def cpu_baseline(w, h, bd, bs, keyint, mask=0x7, budget_frames_per_core=4):
     if not good:
         return {"value": None, "unit": "frames/s", "cores": cores, "kind": "none", "sample": "no CPU encoder could run", "others": legs}
     best = dict(good[0])
-    best["host"] = {"nproc": os.cpu_count(), "affinity_cores": avail, "cores_used": cores}
+    best["host"] = {"nproc": os.cpu_count(), "affinity_cores": avail, "cgroup_cpu_quota": quota, "cores_used": cores}
     best["others"] = [l for l in legs if l is not good[0]]
     best["vmaf"] = "unavailable offline (no libvmaf)"
     return best

@@ -83,6 +83,8 @@ typedef struct {
                            * none (color_description_present_flag 0); BASELINE config 5 "8K 10-bit HDR" = 9 / 16 / 9 (BT.2020, PQ, BT.2020 NCL) */
   int partition_search;   /* 1: content-driven partition - a node larger than min_bs_log2 and not larger than max_bs_log2 splits when its quadrants
                            * differ in level or activity (partition_wants_split in av1o_enc.c); 0 = every node of size <= max_bs_log2 is a leaf */
+  int me_presearch;       /* inter frames: 1 = hierarchical motion search - a quarter-resolution search of +-64 luma samples per superblock gives the
+                           * centre the full-resolution search of +-me_range runs around (presearch_centres in av1o_enc.c); 0 = around zero */
   /* test hooks (fuzzing the normative paths against dav1d) */
   int fuzz_coeffs;        /* !=0: replace quantised levels by pseudo-random ones (seeded by this) */
   int fuzz_density;       /* 1/N chance a coefficient is nonzero */

@@ -28,7 +28,7 @@ class Config(C.Structure):
         "cdef_y_pri", "cdef_y_sec", "cdef_uv_pri", "cdef_uv_sec", "cdef_damping", "enable_cdef")] + [
         ("mode_mask", C.c_uint32), ("still_picture", C.c_int), ("disable_cdf_update", C.c_int),
         ("film_grain", C.c_int), ("fg_y_scaling", C.c_int), ("fg_c_scaling", C.c_int), ("fg_seed", C.c_int), ("deblock", C.c_int), ("lf_level", C.c_int * 4), ("lf_sharpness", C.c_int), ("enable_lr", C.c_int), ("true_width", C.c_int), ("true_height", C.c_int), ("me_range", C.c_int), ("subpel", C.c_int), ("enable_qm", C.c_int), ("qm_y", C.c_int), ("qm_uv", C.c_int), ("angle_delta", C.c_int), ("color_range", C.c_int), ("intra_edge_filter", C.c_int), ("cfl", C.c_int), ("tx_search", C.c_int),
-        ("color_primaries", C.c_int), ("transfer_characteristics", C.c_int), ("matrix_coefficients", C.c_int), ("partition_search", C.c_int), ("fuzz_coeffs", C.c_int), ("fuzz_density", C.c_int),
+        ("color_primaries", C.c_int), ("transfer_characteristics", C.c_int), ("matrix_coefficients", C.c_int), ("partition_search", C.c_int), ("me_presearch", C.c_int), ("fuzz_coeffs", C.c_int), ("fuzz_density", C.c_int),
         ("fuzz_maxlevel", C.c_int), ("fuzz_modes", C.c_int)]
 
 

@@ -488,6 +488,7 @@ typedef struct Enc_ {
   /* inter frames */
   const Av1oFrame *ref; /* LAST_FRAME: the previous frame's final reconstruction; NULL on key frames */
   const Av1oFrame *prev_src; /* the previous SOURCE frame: what the motion search looks at */
+  int16_t *me_centre;   /* cfg->me_presearch: per superblock {row, col} of the full search's centre, whole luma samples (multiples of 8) */
   uint8_t *mi_is_inter; /* 1: block predicted from LAST_FRAME */
   uint8_t *mi_newmv;    /* 1: coded as NEWMV (counts towards NewMvCount of later blocks) */
   int16_t *mi_mv;       /* [mi][2] = {row, col} in 1/8 luma samples */
@@ -943,16 +944,70 @@ static int block_satd8(const uint16_t *a, int as, const uint16_t *b, int bs, int
   return (int)(total >> 3);
 }
 
+/* Hierarchical motion search, first level (cfg->me_presearch; SURVEY.md §8a row a13 "hierarchical: 1/4-res ... full"): the
+ * luma of the source and of the previous source at a quarter of the resolution - q(Y, X) = (sum of the 4x4 samples + 8) >> 4 - and per
+ * 64x64 superblock a full search of its 16x16 quarter-resolution block over |dqx|, |dqy| <= 16 (+-64 luma samples): cost = SAD + 16 (|dqx|
+ * + |dqy|), quarter-resolution coordinates clamped to the plane, ties to the first candidate in (dqy, dqx) raster order.  The winner,
+ * rounded to whole multiples of 8 luma samples - C = ((dq + 1) >> 1) << 3 - is the CENTRE of the superblock's full-resolution search: every
+ * leaf in it searches dx in [Cx - R, Cx + R], dy likewise, with the rules of the one-level search (cost with the absolute vector).  A
+ * candidate is skipped when the superblock displaced by its centre would leave the frame by more than 16 samples (so the centre itself is
+ * always a legal full-resolution candidate for every leaf). */
+static void presearch_centres(Enc *e) {
+  const int W = e->cfg->width, H = e->cfg->height, qw = W >> 2, qh = H >> 2;
+  const int sb_cols = (W + 63) >> 6, sb_rows = (H + 63) >> 6;
+  uint16_t *qc = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)qw * qh), *qp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)qw * qh);
+  int pass, y, x, i, j, sbr, sbc;
+  for (pass = 0; pass < 2; pass++) {
+    const Av1oFrame *f = pass ? e->prev_src : e->src;
+    uint16_t *q = pass ? qp : qc;
+    for (y = 0; y < qh; y++)
+      for (x = 0; x < qw; x++) {
+        int s = 8;
+        for (i = 0; i < 4; i++)
+          for (j = 0; j < 4; j++) s += f->p[0][(size_t)(4 * y + i) * f->stride[0] + 4 * x + j];
+        q[(size_t)y * qw + x] = (uint16_t)(s >> 4);
+      }
+  }
+  for (sbr = 0; sbr < sb_rows; sbr++)
+    for (sbc = 0; sbc < sb_cols; sbc++) {
+      const int sx = sbc * 64, sy = sbr * 64, sbw = W - sx < 64 ? W - sx : 64, sbh = H - sy < 64 ? H - sy : 64;
+      long best_cost = -1;
+      int bqx = 0, bqy = 0, dqy, dqx;
+      for (dqy = -16; dqy <= 16; dqy++)
+        for (dqx = -16; dqx <= 16; dqx++) {
+          const int cx = ((dqx + 1) >> 1) * 8, cy = ((dqy + 1) >> 1) * 8;
+          long sad = 0;
+          if (sx + cx < -16 || sx + cx + sbw > W + 16 || sy + cy < -16 || sy + cy + sbh > H + 16) continue;
+          for (i = 0; i < 16; i++)
+            for (j = 0; j < 16; j++) {
+              int ya = sy / 4 + i, xa = sx / 4 + j, yb = ya + dqy, xb = xa + dqx;
+              ya = ya > qh - 1 ? qh - 1 : ya; xa = xa > qw - 1 ? qw - 1 : xa;
+              yb = yb < 0 ? 0 : (yb > qh - 1 ? qh - 1 : yb); xb = xb < 0 ? 0 : (xb > qw - 1 ? qw - 1 : xb);
+              sad += abs((int)qc[(size_t)ya * qw + xa] - (int)qp[(size_t)yb * qw + xb]);
+            }
+          sad += 16 * (abs(dqx) + abs(dqy));
+          if (best_cost < 0 || sad < best_cost) { best_cost = sad; bqx = dqx; bqy = dqy; }
+        }
+      e->me_centre[2 * (sbr * sb_cols + sbc)] = (int16_t)(((bqy + 1) >> 1) * 8);
+      e->me_centre[2 * (sbr * sb_cols + sbc) + 1] = (int16_t)(((bqx + 1) >> 1) * 8);
+    }
+  free(qc);
+  free(qp);
+}
+
 static int motion_search(const Enc *e, int x, int y, int n, Mv *best) {
   const int R = e->cfg->me_range, W = e->cfg->width, H = e->cfg->height;
+  /* centre of the search: zero, or the superblock's quarter-resolution winner (presearch_centres) */
+  const int sbi = (y >> 6) * ((W + 63) >> 6) + (x >> 6);
+  const int cdy = e->me_centre ? e->me_centre[2 * sbi] : 0, cdx = e->me_centre ? e->me_centre[2 * sbi + 1] : 0;
   const uint16_t *src = e->src->p[0] + (size_t)y * e->src->stride[0] + x;
   const uint16_t *ref = e->prev_src->p[0];
   const int rs = e->prev_src->stride[0], sstr = e->src->stride[0];
   long best_cost = -1;
   int best_sad = 0, dy, dx, i, j;
   best->row = best->col = 0;
-  for (dy = -R; dy <= R; dy++)
-    for (dx = -R; dx <= R; dx++) {
+  for (dy = cdy - R; dy <= cdy + R; dy++)
+    for (dx = cdx - R; dx <= cdx + R; dx++) {
       int sad = 0;
       long cost;
       if (x + dx < -16 || x + dx + n > W + 16 || y + dy < -16 || y + dy + n > H + 16) continue;
@@ -1851,6 +1906,7 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   e->mi_uvmode = (uint8_t *)calloc(n_mi, 1);
   e->ref = ref;
   e->prev_src = prev_src;
+  e->me_centre = NULL;
   e->mi_is_inter = (uint8_t *)calloc(n_mi, 1);
   e->mi_newmv = (uint8_t *)calloc(n_mi, 1);
   e->mi_mv = (int16_t *)calloc(n_mi * 2, sizeof(int16_t));
@@ -1865,6 +1921,10 @@ long av1o_encode_frame2(const Av1oConfig *cfg, const Av1oFrame *src, const Av1oF
   e->stats = stats;
   e->rng_state = (uint32_t)(cfg->fuzz_coeffs ? cfg->fuzz_coeffs : (cfg->fuzz_modes ? cfg->fuzz_modes : 1)) * 2654435761u + 1u;
   if (stats) memset(stats, 0, sizeof(*stats));
+  if (cfg->me_presearch && ref && prev_src) {
+    e->me_centre = (int16_t *)calloc((size_t)g.sb_rows * g.sb_cols * 2, sizeof(int16_t));
+    presearch_centres(e);
+  }
 
   payload_cap = (size_t)cfg->width * cfg->height * 4 + (size_t)g.tile_cols * g.tile_rows * 64 + 4096;
   payload = (uint8_t *)malloc(payload_cap);
@@ -1964,7 +2024,7 @@ done:
   free(tilebuf);
   for (p = 0; p < 3; p++) { free(e->above_lvl[p]); free(e->above_dc[p]); }
   free(e->mi_bsl); free(e->mi_skip); free(e->mi_ymode); free(e->mi_uvmode); free(e->cdef_idx_sb);
-  free(e->mi_is_inter); free(e->mi_newmv); free(e->mi_mv);
+  free(e->mi_is_inter); free(e->mi_newmv); free(e->mi_mv); free(e->me_centre);
   free(lr_units); av1o_frame_free(lr_out);
   av1o_frame_free(src_ext);
   av1o_frame_free(e->rec);

@@ -321,6 +321,30 @@ def test_content_driven_partition_equals_oracle(av1mi, ctx, oracle, w, h, bd, n,
     assert sum(1 for k in (3, 4, 5, 6) if st.bs_hist[k]) >= 2, list(st.bs_hist)
 
 
+@pytest.mark.parametrize("w,h,bd,n,bs,me,step,extra", [
+    (648, 360, 8, 3, 5, 8, 12, dict()), (392, 264, 10, 3, 6, 16, 20, dict(subpel=1)), (328, 248, 8, 4, 5, 8, 7, dict(partition_search=1, min_block_log2=3, deblock=1)),
+    (202, 122, 8, 3, 4, 8, 12, dict())])
+def test_hierarchical_motion_search_equals_oracle(av1mi, ctx, oracle, w, h, bd, n, bs, me, step, extra):
+    """me_presearch: quarter-resolution luma + a +-64 pre-search per superblock on the GPU give the centres the full search runs around;
+    on a clip that moves (2 step, step) samples per frame - beyond the one-level search's reach - bitstream and reconstruction equal the
+    oracle's (presearch_centres), and the hierarchy pays: fewer bytes than the one-level search of the same range."""
+    frames = [oracle.synthclip_frame(w, h, bd, seed=120, t=t * step) for t in range(n)]
+    raw = b"".join(raw_of(f, bd) for f in frames)
+    p = av1mi.default_params(w, h, bd, block_log2=bs, keyint=240, me_range=me, me_presearch=1, **extra)
+    data, sizes, rep, recon = ctx.encode_chunk(p, raw, n, want_recon=True)
+    okw = dict(min_bs_log2=extra.get("min_block_log2", bs), max_bs_log2=bs, me_range=me, me_presearch=1)
+    for k, v in extra.items():
+        if k != "min_block_log2":
+            okw[k] = v
+    cfg = oracle.default_config(w, h, bd, **okw)
+    tus, recs = oracle_chunk(oracle, cfg, frames, 240)
+    assert data == b"".join(tus) and recon.tobytes() == b"".join(raw_of(r, bd) for r in recs)
+    if w >= 600:   # (on the small clips the pre-search has little to find: a handful of superblocks)
+        p.me_presearch = 0
+        flat, _, _, _ = ctx.encode_chunk(p, raw, n)
+        assert len(data) < len(flat)
+
+
 def test_film_grain_table_in_frame_headers(av1mi, ctx, oracle):
     """`film_grain = N` (the reference's `--film-grain N`, av1an.rs:14): every frame header carries a
     film-grain table with its own grain_seed; tile data and reconstruction are untouched.  Bit-exact
@@ -443,9 +467,10 @@ def test_golden_inter_sequences_through_the_c_abi(av1mi, ctx, oracle, golden_seq
         p.intra_edge_filter = cfgk.get("intra_edge_filter", 0)
         p.cfl = cfgk.get("cfl", 0)
         p.partition_search, p.min_block_log2 = cfgk.get("partition_search", 0), min_bs
+        p.me_presearch = cfgk.get("me_presearch", 0)
         if cfgk.get("enable_qm"):
             p.enable_qm, p.qm_min, p.qm_max = 1, cfgk["qm_y"], cfgk["qm_y"]
-        frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t) for t in range(m["frames"])]
+        frames = [oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t * m.get("t_step", 1)) for t in range(m["frames"])]
         data, sizes, rep, recon = ctx.encode_chunk(p, b"".join(raw_of(f, m["bit_depth"]) for f in frames), m["frames"], want_recon=True)
         assert data == m["obu"], m["name"]
         fb = m["width"] * m["height"] * 3 // 2 * (2 if m["bit_depth"] > 8 else 1)

@@ -39,7 +39,7 @@ def test_golden_inter_sequences(oracle, golden_sequences):
         cfg = oracle.default_config(m["width"], m["height"], m["bit_depth"], **m["config"])
         ref, prev, pos = None, None, 0
         for t in range(m["frames"]):
-            src = oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t)
+            src = oracle.synthclip_frame(m["width"], m["height"], m["bit_depth"], seed=m["seed"], t=t * m.get("t_step", 1))
             tu, rec, st = oracle.encode_frame(cfg, src, with_seq_hdr=(t == 0), ref=ref, prev_src=prev)
             assert tu == m["obu"][pos:pos + m["frame_bytes"][t]], (m["name"], t)
             assert sha(rec) == m["dav1d_sha256"][t], (m["name"], t)

@@ -67,7 +67,7 @@ def main():
         dst = os.path.join(ROOT, "profiles", "%s_pmc_%s.txt" % (tag, what))
         with open(dst, "w") as f:
             f.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --configs none%s\n"
-                    % (" --keyint 240" if what == "ippp" else ""))
+                    % (" --keyint 240 --mode-mask 7" if what == "ippp" else ""))
             f.write("# separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*; sums over the dispatches of one 60-frame 1080p 10-bit chunk; FETCH/WRITE in KiB (raw)\n")
             for k in sorted(acc):
                 f.write(k + "\n")
@@ -78,17 +78,18 @@ def main():
         for k, cs in acc.items():
             for pat, stage in STAGE_OF:
                 if k.startswith(pat) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-                    e = ent.setdefault(stage, {"FETCH_SIZE": 0, "WRITE_SIZE": 0, "dispatches": 0})
+                    e = ent.setdefault(stage, {"FETCH_SIZE": 0, "WRITE_SIZE": 0, "dispatches": 0, "SQ_INSTS_VALU": 0})
                     e["FETCH_SIZE"] += int(cs["FETCH_SIZE"]); e["WRITE_SIZE"] += int(cs["WRITE_SIZE"]); e["dispatches"] += calls[(k, "FETCH_SIZE")]
+                    e["SQ_INSTS_VALU"] += int(cs.get("SQ_INSTS_VALU", 0))   # wave-instructions (bench.py: valu_busy)
         if what == "ippp":   # the P-frame kernels run once per frame: per-launch figures
             for e in ent.values():
                 if e["dispatches"] > 2:
-                    e["FETCH_SIZE"] //= e["dispatches"]; e["WRITE_SIZE"] //= e["dispatches"]; e["per"] = "launch (one frame)"
+                    e["FETCH_SIZE"] //= e["dispatches"]; e["WRITE_SIZE"] //= e["dispatches"]; e["SQ_INSTS_VALU"] //= e["dispatches"]; e["per"] = "launch (one frame)"
         traffic[wl] = ent
     if traffic:
         dst = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         json.dump({"source": "profiles/%s_pmc_*.txt (tools/collect_evidence.sh %s; rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % (tag, tag),
-                   "unit": "KiB per launch, raw counter values (gfx950: FETCH_SIZE counts 64 B per 128-B request - bench.py doubles it)",
+                   "unit": "FETCH_SIZE / WRITE_SIZE: KiB per launch, raw counter values (gfx950: FETCH_SIZE counts 64 B per 128-B request - bench.py doubles it); SQ_INSTS_VALU: wave-instructions per launch",
                    "workloads": traffic}, open(dst, "w"), indent=1)
         print(dst)
 

@@ -179,6 +179,10 @@ SEQ_CASES = [
     ("pfuzz_cfl_bs4_10b", 136, 120, 10, 104, 3, dict(min_bs_log2=4, max_bs_log2=4, mode_mask=0x1FFF, fuzz_modes=23, cfl=1)),
     ("p328x248_part_6_3_subpel", 328, 248, 8, 115, 3, dict(min_bs_log2=3, max_bs_log2=6, partition_search=1, subpel=1)),
     ("p264x200_part_5_3_lr2_deblock_10b", 264, 200, 10, 116, 3, dict(min_bs_log2=3, max_bs_log2=5, partition_search=1, enable_lr=2, deblock=1, me_range=16)),
+    # hierarchical motion search (me_presearch): the clip sampled every 12th frame - the pan moves (24, 12) samples per frame, the rectangles
+    # (+-36, +-24): beyond the +-8 / +-16 of the one-level search
+    ("p328x248_presearch_fast", 328, 248, 8, 118, 3, dict(min_bs_log2=5, max_bs_log2=5, me_presearch=1, t_step=12)),
+    ("p392x264_presearch_part_6_3_subpel_10b", 392, 264, 10, 119, 3, dict(min_bs_log2=3, max_bs_log2=6, partition_search=1, me_presearch=1, subpel=1, me_range=16, t_step=12)),
     ("pfuzz_bs4", 200, 120, 8, 21, 4, dict(min_bs_log2=4, max_bs_log2=4, fuzz_modes=7)),
     ("pfuzz_bs3_all13", 200, 120, 8, 22, 3, dict(min_bs_log2=3, max_bs_log2=3, fuzz_modes=9, mode_mask=0x1FFF)),
     ("pfuzz_bs6", 136, 136, 8, 23, 3, dict(min_bs_log2=6, max_bs_log2=6, fuzz_modes=3)),
@@ -190,10 +194,12 @@ SEQ_CASES = [
 def make_sequences():
     index = []
     for name, w, h, bd, seed, n, kw in SEQ_CASES:
+        kw = dict(kw)
+        t_step = kw.pop("t_step", 1)   # frame i of the sequence is frame i * t_step of the clip (fast motion)
         cfg = av1o.default_config(w, h, bd, **kw)
         tus, recs, ref, prev, modes, ninter = [], [], None, None, [0, 0, 0, 0], 0
         for t in range(n):
-            src = av1o.synthclip_frame(w, h, bd, seed=seed, t=t)
+            src = av1o.synthclip_frame(w, h, bd, seed=seed, t=t * t_step)
             tu, rec, st = av1o.encode_frame(cfg, src, with_seq_hdr=(t == 0), ref=ref, prev_src=prev)
             tus.append(tu)
             recs.append(rec)
@@ -209,6 +215,7 @@ def make_sequences():
                     raise SystemExit("%s: frame %d plane %d: dav1d output differs from the oracle reconstruction" % (name, t, p))
         open(os.path.join(OUT, name + ".obu"), "wb").write(b"".join(tus))
         meta = dict(name=name, width=w, height=h, bit_depth=bd, seed=seed, frames=n, config=kw, frame_bytes=[len(x) for x in tus],
+                    **({"t_step": t_step} if t_step != 1 else {}),
                     dav1d_sha256=[sha(d) for d in dec], inter_blocks=ninter, inter_modes_nearest_near_global_new=modes,
                     decoder="dav1d 1.5.3 via libavif 1.4.1 (Pillow 12.2.0), AVIF image sequence")
         json.dump(meta, open(os.path.join(OUT, name + ".json"), "w"), indent=1, sort_keys=True)
