@@ -10,14 +10,17 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libav1mi.so")
-OBJDIR = os.path.join(HERE, "build")
+# AV1MI_BUILD_VARIANT=<name> + AV1MI_EXTRA_FLAGS="-D...": a second library av1-base_amd/ab/libav1mi_<name>.so from objects of its own
+# (same-box A/B runs: AV1MI_LIB selects the library at run time); the product build is untouched
+_VARIANT = os.environ.get("AV1MI_BUILD_VARIANT", "")
+OUT = os.path.join(HERE, "ab", "libav1mi_%s.so" % _VARIANT) if _VARIANT else os.path.join(HERE, "libav1mi.so")
+OBJDIR = os.path.join(HERE, "build_" + _VARIANT if _VARIANT else "build")
 SOURCES = ["recon_kernel.hip", "recon64_kernel.hip", "entropy_kernel.hip", "cdef_pack_kernels.hip", "scene_kernels.hip", "me_kernel.hip", "lr_kernel.hip", "deblock_kernel.hip", "av1mi_host.cpp", "av1mi_file.cpp", "av1mi_exec.cpp"]
 # -fno-optimize-sibling-calls: keeps LLVM from marking the calls of the `noinline` transform items `tail`.  With the marker the
 # backend's interprocedural register allocation treats the items as ordinary ABI functions that save and restore every
 # callee-saved VGPR they touch - 33 stores + 29 loads of 256 B per call, 60 % of the reconstruction kernel's HBM traffic
 # (profiles/r02_a_pmc_intra.txt vs r02_c); without it the items save nothing and their callers keep nothing in those registers.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-optimize-sibling-calls", "-Wall", "-Wno-unused-function", "-Wno-missing-braces",
+FLAGS = os.environ.get("AV1MI_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-optimize-sibling-calls", "-Wall", "-Wno-unused-function", "-Wno-missing-braces",
          "-Wno-pass-failed"]
 
 
@@ -40,6 +43,7 @@ def _deps_of(obj, fallback):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(HERE, "..", "include", "av1mi.h"), os.path.join(CSRC, "recon_kernel.hip")]   # (recon64_kernel.hip includes recon_kernel.hip)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

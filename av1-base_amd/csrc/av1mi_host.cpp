@@ -1053,10 +1053,9 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     HIPCHK(c, hipMemsetAsync(c->d_me, 0xFF, (size_t)n_frames * nb8 * 8, c->stream2));
     uint32_t *acc64 = P.max_bs_log2 >= 6 ? c->d_me64 : nullptr;
     if (acc64) HIPCHK(c, hipMemsetAsync(acc64, 0, (size_t)n_frames * nsb * (2 * P.me_range + 1) * (2 * P.me_range + 1) * sizeof(uint32_t), c->stream2));
-    // one launch + one event per frame, enqueued a few frames AHEAD of the chain from inside the frame loop below: the search of the later
-    // frames fills the SIMDs the chain's one-frame kernels leave idle, and the chain's first kernel is enqueued at once.  (Enqueuing every
-    // frame's search up front - 120 to 180 API calls for a 60-frame chunk - kept the key frame's reconstruction waiting on the HOST: the
-    // chain's first kernel started 1.4 ms after the chunk's first, 6.4 ms under the profiler; VERDICT r2 weak #4.)
+    // one launch + one event per frame, enqueued from inside the frame loop below, behind the first frame's chain kernels: the chain's first
+    // kernel (the key frame's reconstruction needs no vectors) no longer waits on the host for 120 - 180 API calls (under
+    // the profiler the chain started 6.4 ms after the chunk's first kernel; unprofiled the calls take ~ 8 us each and one chunk gains nothing)
     while (c->me_ev.size() < n_frames) {
       hipEvent_t e;
       HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1080,7 +1079,10 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       }
       return AV1MI_OK;
     };
-    uint32_t me_ahead = 4;   // frames the search runs ahead of the chain (a frame's search is ~ 40 us, ~ 150 with the refinement; a chain step ~ 140 - 250)
+    // Frames the search is enqueued ahead of the chain.  Default: everything, right behind the FIRST frame's chain kernels - measured (1080p
+    // IPPP x 60, one chunk / four in flight, frames/s): all 5 420 / 7 560; 8 ahead 5 390 / 7 220; 4 ahead 5 410 / 6 970; 2 ahead 5 370 / 6 900 -
+    // with several chunks in flight a search that is enqueued late competes with the other chunks' chains instead of filling their gaps.
+    uint32_t me_ahead = n_frames;
     if (const char *ea = getenv("AV1MI_ME_AHEAD")) { const int k = atoi(ea); me_ahead = k > 0 ? (uint32_t)k : n_frames; }
     // Entropy coding beside the chain: every frame starts from the default CDFs, so a group of frames can be symbolized and
     // range-coded (third stream) as soon as its last frame is reconstructed (and, with restoration on, its unit choices are

@@ -21,6 +21,7 @@
 //        range coder in VGPRs, and walks its stream.  The serial chain now runs 64-wide on the
 //        vector units of every CU instead of on 256 scalar units.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "av1mi_dev.h"
 
 namespace {
@@ -1048,9 +1049,13 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   // as long as its longest tile: the natural order is best (a workgroup of 64 long tiles would be slower per symbol than
   // one long tile among short ones - measured 1.1 -> 2.1 ms).  Beyond it the workgroups run in rounds, and what counts is
   // the sum over workgroups of their longest tile: sorted order (4K, 30 frames: 3.9 -> 2.9 ms).
-  const bool sorted = (n_tiles + 63) / 64 > 2 * 256;
+  // experiment knob AV1MI_RC_LDS_PAD=<bytes>: dynamic LDS on top of the kernel's 73 KB - 16384 leaves room for ONE workgroup per CU, i.e. half
+  // of every CU's LDS for another chunk's kernels while the range coder takes two rounds
+  static const int lds_pad = [] { const char *e = getenv("AV1MI_RC_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 65536 ? v : 0; }();
+  const int per_cu = lds_pad >= 8192 ? 1 : 2;
+  const bool sorted = (n_tiles + 63) / 64 > per_cu * 256;
   if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len + tile0, tile_order + tile0);
-  hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
+  hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), (size_t)lds_pad, stream, *P, n_tiles, cdf_init, streams, stream_len,
                      tile_combos, slots, tile_bytes, sorted ? tile_order + tile0 : (uint32_t *)nullptr, tile0);
   return hipGetLastError();
 }

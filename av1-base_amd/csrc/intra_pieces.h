@@ -5,7 +5,7 @@
 // source also compiles for the host: tests/test_intra_pieces.py builds it with clang++ and checks every mode, angle delta and block size
 // against the oracle's predictor without a GPU (the only device-specific line is the v_sad_u16 builtin).
 //
-// A block of N x N samples (N = 8, 16, 32) is N * N / 8 pieces; piece q = row q / (N / 8), samples 8 (q % (N / 8)) .. + 7 of that row;
+// A block of N x N samples (N = 8, 16, 32, 64) is N * N / 8 pieces; piece q = row q / (N / 8), samples 8 (q % (N / 8)) .. + 7 of that row;
 // lane sl of a group of G lanes takes the pieces q = sl, sl + G, ...
 //  * A directional prediction is, row by row, a copy of an edge shifted by a whole number of elements and blended with its neighbour: with
 //    idx = d (rho + 1), off = idx >> 6, sh = (idx >> 1) & 31, sample kappa of row rho is (E[kappa + off] (32 - sh) + E[kappa + off + 1] sh
@@ -33,8 +33,8 @@
   0, 0, 0, 1023, 0, 0, 547, 0, 0, 372, 0, 0, 0, 0, 273, 0, 0, 215, 0, 0, 178, 0, 0, 151, 0, 0, 132, 0, 0, 116, 0, 0, \
   102, 0, 0, 0, 90, 0, 0, 80, 0, 0, 71, 0, 0, 64, 0, 0, 57, 0, 0, 51, 0, 0, 45, 0, 0, 0, 40, 0, 0, 35, 0, 0, \
   31, 0, 0, 27, 0, 0, 23, 0, 0, 19, 0, 0, 15, 0, 0, 0, 0, 11, 0, 0, 7, 0, 0, 3, 0, 0, 0 }
-// magic[angle] = floor(2^22 / Dr_Intra_Derivative[angle]) + 1: (64 k * magic) >> 22 == floor(64 k / derivative) for k = 1 .. 32, and the product
-// fits 32 bits (both checked exhaustively by tests/test_intra_pieces.py)
+// magic[angle] = floor(2^22 / Dr_Intra_Derivative[angle]) + 1: (64 k * magic) >> 22 == floor(64 k / derivative) for k = 1 .. 64 in 64-bit
+// arithmetic (checked exhaustively by tests/test_intra_pieces.py)
 #define AV1MI_DR_MAGIC_INIT { \
   0, 0, 0, 4101, 0, 0, 7668, 0, 0, 11276, 0, 0, 0, 0, 15364, 0, 0, 19509, 0, 0, 23564, 0, 0, 27777, 0, 0, 31776, 0, 0, 36158, 0, 0, 41121, 0, 0, 0, 46604, \
   0, 0, 52429, 0, 0, 59075, 0, 0, 65537, 0, 0, 73585, 0, 0, 82242, 0, 0, 93207, 0, 0, 0, 104858, 0, 0, 119838, 0, 0, 135301, 0, 0, 155345, 0, 0, 182362, \
@@ -167,7 +167,7 @@ AV1MI_PIECE_FN uint32_t pass_t(int sl, int mode, int ang, int dy, uint32_t magic
     } else {
       const pu4 sv = *reinterpret_cast<const pu4 *>(&tsrc[rho * N + k0]);
       pu4 inv = { 0, 0, 0, 0 };
-      if (ang < 180) inv = prefix_mask((int)(((uint32_t)(rho + 1) * 64u * magic) >> 22) - k0);   // rows above floor(64 (c + 1) / dx) take the above form
+      if (ang < 180) inv = prefix_mask((int)(((uint64_t)((uint32_t)(rho + 1) * 64u) * magic) >> 22) - k0);   // rows above floor(64 (c + 1) / dx) take the above form
       const pu4 mv = merge(inv, sv, pv);
       acc = sad2(sv[0], mv[0], acc); acc = sad2(sv[1], mv[1], acc); acc = sad2(sv[2], mv[2], acc); acc = sad2(sv[3], mv[3], acc);
     }

@@ -99,8 +99,11 @@ struct alignas(16) SbLds {
   uint16_t blkpix[MAXN * MAXN];     // prediction, then reconstruction, of the current transform block
   uint16_t srcblk[MAXN * MAXN];     // source pixels of the block; reused for the quantised levels
   int16_t scratch[MAXN * (MAXN + 1)];     // 2-D transform staging (every intermediate fits 16 bits)
-  uint16_t edge_a[2 * 72 + 8];  // element i of a lane group's edge at [group * 72 + 8 + i] (i >= -1): element 0 is 16-byte aligned
-  uint16_t edge_l[2 * 72 + 8];
+  // element i of a lane group's edge at [group * EDGS + 8 + i] (i >= -1; padded up to 3 N + 8 for the piece-wise predictors): element 0 is
+  // 16-byte aligned.  Two groups of blocks up to MAXN / 2, or one block of MAXN.
+#define AV1MI_EDGS (MAXN > 32 ? 120 : 72)
+  uint16_t edge_a[2 * AV1MI_EDGS + 8];
+  uint16_t edge_l[2 * AV1MI_EDGS + 8];
   uint8_t blkdec[2][19][19];    // luma, chroma (U and V decode together)
   uint8_t smw[64];              // smooth weights of the current block size
   int eobs[4];                  // eob of the current block's Y, U, V transform blocks
@@ -521,11 +524,11 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   constexpr int G = 64 / NPL;              // lanes per group
   constexpr int PIXO = NPL == 1 ? 0 : (N > 16 ? 1024 : 512); // per-group offset inside srcblk / blkpix (NPL == 2: N <= 16, or 32 in the 64x64 build)
   constexpr int SCRO = NPL == 1 ? 0 : (N > 16 ? 32 * 33 : 16 * 24);   // (16 rows of stride 24: see STR)
-  constexpr int EDGO = NPL == 1 ? 0 : 72;
+  constexpr int EDGO = NPL == 1 ? 0 : AV1MI_EDGS;
+  static_assert(NPL == 1 ? 8 + 3 * N + 9 <= 2 * AV1MI_EDGS + 8 : 8 + 3 * N + 9 <= AV1MI_EDGS, "padded edge does not fit its array");
   constexpr int EB = 8;   // index of element 0 inside a group's edge array
-  // PVOK: block classes with the piece-wise intra predictors (eight samples of a row per lane and step; below).  Not in the 64x64 build:
-  // the edge arrays there have no room for the padding of a 64-sample edge.
-  constexpr bool PVOK = !AV1MI_RECON_BIG && N >= 8;
+  // PVOK: block classes with the piece-wise intra predictors (eight samples of a row per lane and step; below)
+  constexpr bool PVOK = N >= 8;
   const Av1miDevParams *P = cx.P;
   const int lane = cx.lane;
   const int grp = NPL == 1 ? 0 : lane >> 5, sl = NPL == 1 ? lane : lane & 31;
@@ -1231,6 +1234,9 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     // the classes this size has pruned networks for (64 = the full network)
     auto cls = [](int v) { return LOG2N >= 5 ? (v <= 8 ? 8 : (v <= 16 ? 16 : 64)) : (LOG2N == 4 ? (v <= 4 ? 4 : (v <= 8 ? 8 : 64)) : (LOG2N == 3 && v <= 4 ? 4 : 64)); };
     nzc = cls(ec); nzr = cls(er);
+#ifdef AV1MI_NO_PRUNE
+    nzc = nzr = 64;
+#endif
   }
   // row pass of one class: [matrix-core path: the row's levels back from LDS through the normative dequantiser (spec 7.12.3),] inverse rows
   auto row_pass = [&](auto tag) {
@@ -1263,10 +1269,13 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     for (int j = 0; j < N; j++) S->scratch[so + sl * ST + j] = (int16_t)clamp_bits(rshift_round(x[j], RS), bd + 6 > 16 ? bd + 6 : 16);
   };
   if (row_lane && eob && sl < nzr) {   // (rows beyond the extent are all zero: the column pass does not read them)
+#ifndef AV1MI_NO_PRUNE   /* (A/B switch: the build without the pruned networks) */
     if (LOG2N >= 4 && nzc == 8) row_pass(NzTag<8>{});
     else if (LOG2N >= 5 && nzc == 16) row_pass(NzTag<16>{});
     else if ((LOG2N == 3 || LOG2N == 4) && nzc == 4) row_pass(NzTag<4>{});
-    else row_pass(NzTag<64>{});
+    else
+#endif
+    row_pass(NzTag<64>{});
   }
   wave_sync();
   STAMP(4);   // forward rows, quantiser, dequantiser, eob, inverse rows
@@ -1283,10 +1292,13 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
   };
   if (tx_lane && eob) {
+#ifndef AV1MI_NO_PRUNE
     if (LOG2N >= 4 && nzr == 8) col_pass(NzTag<8>{});
     else if (LOG2N >= 5 && nzr == 16) col_pass(NzTag<16>{});
     else if ((LOG2N == 3 || LOG2N == 4) && nzr == 4) col_pass(NzTag<4>{});
-    else col_pass(NzTag<64>{});
+    else
+#endif
+    col_pass(NzTag<64>{});
   }
   if (eob) {  // levels out (32-bit words, coalesced inside the group)
     // (16 bytes = 8 levels per store: the block's area of the level buffer is 32-byte aligned, av1mi_levels_off)

@@ -41,6 +41,8 @@ extern "C" long pieces_run(int n, int lanes, int mode, int ang, int dcv, const u
     case 1664: return run<16, 64>(mode, ang, dcv, above, left, smw, src, pix, write);
     case 1632: return run<16, 32>(mode, ang, dcv, above, left, smw, src, pix, write);
     case 3264: return run<32, 64>(mode, ang, dcv, above, left, smw, src, pix, write);
+    case 3232: return run<32, 32>(mode, ang, dcv, above, left, smw, src, pix, write);
+    case 6464: return run<64, 64>(mode, ang, dcv, above, left, smw, src, pix, write);
   }
   return -1;
 }

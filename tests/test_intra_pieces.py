@@ -13,7 +13,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "host", "intra_pieces_host.cpp")
 MODE_ANGLE = {1: 90, 2: 180, 3: 45, 4: 135, 5: 113, 6: 157, 7: 203, 8: 67}
-SM_WEIGHTS = {8: [255, 197, 146, 105, 73, 50, 37, 32], 16: [255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16],
+SM_WEIGHTS = {64: [255, 248, 240, 233, 225, 218, 210, 203, 196, 189, 182, 176, 169, 163, 156, 150, 144, 138, 133, 127, 121, 116, 111, 106, 101, 96, 91, 86, 82, 77, 73, 69,
+                   65, 61, 57, 54, 50, 47, 44, 41, 38, 35, 32, 29, 27, 25, 22, 20, 18, 16, 15, 13, 12, 10, 9, 8, 7, 6, 6, 5, 5, 4, 4, 4],
+              8: [255, 197, 146, 105, 73, 50, 37, 32], 16: [255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16],
               32: [255, 240, 225, 210, 196, 182, 169, 157, 145, 133, 122, 111, 101, 92, 83, 74, 66, 59, 52, 45, 39, 34, 29, 25, 21, 17, 14, 12, 10, 9, 8, 8]}
 
 
@@ -40,17 +42,17 @@ def test_division_magic_is_exact(pieces):
             assert pieces.pieces_magic(ang) == 0
             continue
         m = pieces.pieces_magic(ang)
-        for k in range(1, 33):
-            assert 64 * k * m < 1 << 32 and (64 * k * m) >> 22 == (64 * k) // d
+        for k in range(1, 65):
+            assert (64 * k * m) >> 22 == (64 * k) // d
         n += 1
     assert n == 27
 
 
-@pytest.mark.parametrize("n,lanes,bd", [(8, 64, 8), (8, 32, 10), (16, 64, 10), (16, 32, 8), (32, 64, 10), (32, 64, 8)])
+@pytest.mark.parametrize("n,lanes,bd", [(8, 64, 8), (8, 32, 10), (16, 64, 10), (16, 32, 8), (32, 64, 10), (32, 64, 8), (32, 32, 10), (64, 64, 10)])
 def test_pieces_equal_the_oracle_predictor(pieces, oracle, n, lanes, bd):
     L = oracle.lib()
     rng = np.random.default_rng(n * 100 + lanes + bd)
-    log2n = {8: 3, 16: 4, 32: 5}[n]
+    log2n = {8: 3, 16: 4, 32: 5, 64: 6}[n]
     maxv = (1 << bd) - 1
     smw = np.zeros(64, np.uint8)
     smw[:n] = SM_WEIGHTS[n]
