@@ -554,26 +554,30 @@ __global__ void __launch_bounds__(256) quarter_luma_kernel(Av1miDevParams P, con
   }
 }
 
-// presearch_kernel: one wave per superblock of an inter frame.  The superblock's 16x16 quarter-resolution block and the 48x48 window of the
-// previous frame around it (coordinates clamped to the plane) are staged in LDS; per dqy lane = dqx + 16 takes the SAD of its candidate (the
-// block's sample is a broadcast read, the window's consecutive), cost = SAD + 16 (|dqx| + |dqy|); a candidate whose centre would push the
-// superblock more than 16 samples out of the frame is skipped; minimum over (cost, raster index).  Writes the centre code of the winner
-// rounded to whole multiples of 8 luma samples (av1mi_dev.h: motion search keys).
-__global__ void __launch_bounds__(64) presearch_kernel(Av1miDevParams P, const uint16_t *__restrict__ quarter, uint32_t *__restrict__ centre, int frame0) {
-  __shared__ uint16_t cur[16][16];
-  __shared__ uint16_t win[48][50];
+// presearch_kernel: one workgroup of two waves per superblock of an inter frame.  The superblock's 16x16 quarter-resolution block and the
+// 48x48 window of the previous frame around it (coordinates clamped to the plane) are staged in LDS; lane = dqx + 16, each wave takes half
+// of the dqy range; a candidate's SAD two samples per instruction (the block's pair is a broadcast read, the window's pair an unaligned
+// 4-byte read), cost = SAD + 16 (|dqx| + |dqy|); a candidate whose centre would push the superblock more than 16 samples out of the frame is
+// skipped; minimum over (cost, raster index).  Writes the centre code of the winner rounded to whole multiples of 8 luma samples
+// (av1mi_dev.h: motion search keys).  (As one wave with one sample per instruction it took as long as a frame's chain step, and the chain
+// waited for it: 1080p IPPP 5.36 -> 4.89 k frames/s.)
+__global__ void __launch_bounds__(128) presearch_kernel(Av1miDevParams P, const uint16_t *__restrict__ quarter, uint32_t *__restrict__ centre, int frame0) {
+  __shared__ __attribute__((aligned(16))) uint16_t cur[16][16];
+  __shared__ __attribute__((aligned(16))) uint16_t win[48][50];
+  __shared__ uint32_t wbest[2];
+  typedef uint32_t u32_any __attribute__((aligned(2)));
   const int f = frame0 + blockIdx.y;
   if (!av1mi_frame_is_inter(P, f)) return;
-  const int sb = blockIdx.x, lane = threadIdx.x;
+  const int sb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sx = (sb % P.sb_cols) * 64, sy = (sb / P.sb_cols) * 64;
   const int W = P.width, H = P.height, qw = W >> 2, qh = H >> 2;
   const uint16_t *qc = quarter + (size_t)f * qw * qh, *qp = qc - (size_t)qw * qh;
-  for (int i = lane; i < 256; i += 64) {
+  for (int i = tid; i < 256; i += 128) {
     int y = (sy >> 2) + (i >> 4), x = (sx >> 2) + (i & 15);
     y = y > qh - 1 ? qh - 1 : y; x = x > qw - 1 ? qw - 1 : x;
     cur[i >> 4][i & 15] = qc[(size_t)y * qw + x];
   }
-  for (int i = lane; i < 48 * 48; i += 64) {
+  for (int i = tid; i < 48 * 48; i += 128) {
     const int r = i / 48, c = i - r * 48;
     // window sample (r, c) = previous plane at (block row - 16 + r, block column - 16 + c), coordinates clamped to the plane
     int y = (sy >> 2) - 16 + r, x = (sx >> 2) - 16 + c;
@@ -584,22 +588,28 @@ __global__ void __launch_bounds__(64) presearch_kernel(Av1miDevParams P, const u
   const int sbw = W - sx < 64 ? W - sx : 64, sbh = H - sy < 64 ? H - sy : 64;
   uint32_t best = 0xFFFFFFFFu;
   const int dqx = lane - 16;
-  for (int dqy = -16; dqy <= 16; dqy++) {
+  // wave 0: dqy -16 .. 0, wave 1: 1 .. 16
+  for (int dqy = wave ? 1 : -16; dqy <= (wave ? 16 : 0); dqy++) {
     if (lane > 32) continue;
     const int ccx = ((dqx + 1) >> 1) * 8, ccy = ((dqy + 1) >> 1) * 8;
     if (sx + ccx < -16 || sx + ccx + sbw > W + 16 || sy + ccy < -16 || sy + ccy + sbh > H + 16) continue;
     uint32_t sad = 0;
     for (int i = 0; i < 16; i++) {
+      const uint32_t *cr = reinterpret_cast<const uint32_t *>(&cur[i][0]);
+      const uint16_t *wr = &win[i + dqy + 16][dqx + 16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) sad = __builtin_amdgcn_sad_u16((uint32_t)cur[i][j], (uint32_t)win[i + dqy + 16][j + dqx + 16], sad);
+      for (int k = 0; k < 8; k++) sad = __builtin_amdgcn_sad_u16(cr[k], *reinterpret_cast<const u32_any *>(wr + 2 * k), sad);
     }
     const uint32_t cost = sad + 16u * (uint32_t)(iabs(dqx) + iabs(dqy));
     const uint32_t key = (cost << 11) | (uint32_t)((dqy + 16) * 33 + lane);
     best = key < best ? key : best;
   }
   for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t < best ? t : best; }
-  if (lane == 0) {
-    const int idx = (int)(best & 0x7FF), bqy = idx / 33 - 16, bqx = idx % 33 - 16;
+  if (lane == 0) wbest[wave] = best;
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t bb = wbest[0] < wbest[1] ? wbest[0] : wbest[1];
+    const int idx = (int)(bb & 0x7FF), bqy = idx / 33 - 16, bqx = idx % 33 - 16;
     const int c8y = (bqy + 1) >> 1, c8x = (bqx + 1) >> 1;   // centre / 8
     centre[(size_t)f * P.sb_rows * P.sb_cols + sb] = ((uint32_t)(c8y & 0xFFF) << 12) | (uint32_t)(c8x & 0xFFF);
   }
@@ -616,7 +626,7 @@ extern "C" hipError_t av1mi_launch_quarter_luma(const Av1miDevParams *P, const v
 }
 // search centres of frames [frame0, frame0 + count) (key frames are skipped)
 extern "C" hipError_t av1mi_launch_presearch(const Av1miDevParams *P, const uint16_t *quarter, uint32_t *centre, int frame0, int count, hipStream_t stream) {
-  hipLaunchKernelGGL(presearch_kernel, dim3(P->sb_rows * P->sb_cols, count), dim3(64), 0, stream, *P, quarter, centre, frame0);
+  hipLaunchKernelGGL(presearch_kernel, dim3(P->sb_rows * P->sb_cols, count), dim3(128), 0, stream, *P, quarter, centre, frame0);
   return hipGetLastError();
 }
 
