@@ -120,6 +120,20 @@ template <> struct SbSel<2> { static __device__ __forceinline__ SbLds *get() { r
 // block is finished (the chroma wave writes the block-info entry, which holds both)
 struct SplitQueue { int dec[4 * 64]; int e0[4 * 64]; };
 __shared__ SplitQueue g_q;
+// P-frame tile walk: everything a block of the superblock would fetch from HBM on the walk's serial chain, staged once per superblock
+// with all loads in flight together (referenced - and allocated - by the inter instantiations only).  A decision used to pay four
+// dependent HBM round trips (search key, provisional block info, source block, the inter version's bottom row / right column):
+// ~ 4 of its ~ 7 us.  Samples as 16-bit whatever the bit depth; coordinates beyond the frame repeat the last row / column.
+struct WalkStage {
+  uint16_t src_y[64 * 64];        // source luma of the superblock
+  uint16_t row_y[8][64];          // provisional reconstruction (every block as an inter block): luma rows 8 k + 7 ...
+  uint16_t col_y[8][64];          // ... and columns 8 k + 7 - the bottom row / right column of any leaf is one of them
+  uint16_t row_c[2][8][32];       // U, V: rows 4 k + 3
+  uint16_t col_c[2][8][32];       //       columns 4 k + 3
+  unsigned long long key[64];     // motion search result per 8x8 unit
+  uint16_t pre_eob[64][4];        // the inter version's eobs per 8x8 unit (Y, U, V)
+};
+__shared__ __attribute__((aligned(16))) WalkStage g_ws;
 #define Q_VALID 0x40000000
 __device__ __forceinline__ int q_wait(const int *slot) {
   int v;
@@ -555,18 +569,19 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // the line buffers, the decoded-block map and the eob are set, nothing else happens
   auto inter_done = [&]() {
     if constexpr (PH == 2) {
-      const PIX *pl = rec_frame + poff;
-      // (positions of an overhanging block that lie outside the plane are never read back - intra edges stop at the frame
-      // limit - they only have to be loaded from inside the buffer)
+      // the block's bottom row and right column come from the superblock's staged rows / columns (g_ws; the row index of a leaf's last
+      // row inside the frame is 7 mod 8 - 3 mod 4 in chroma - whatever its size, block sizes and coded frame sizes being multiples of 8)
       const int rb = N - 1 < ph_lim ? N - 1 : ph_lim - 1, cb = N - 1 < pw_lim ? N - 1 : pw_lim - 1;   // last row / column inside
+      const uint16_t *srow = plane == 0 ? g_ws.row_y[(y0 + rb) >> 3] + x0 : g_ws.row_c[plane - 1][(y0 + rb) >> 2] + x0;
+      const uint16_t *scol = plane == 0 ? g_ws.col_y[(x0 + cb) >> 3] + y0 : g_ws.col_c[plane - 1][(x0 + cb) >> 2] + y0;
       if (sl < N) {
-        LN.above[plane][lx + sl] = (uint16_t)pl[(size_t)(gy + rb) * gs + gx + (sl < pw_lim ? sl : pw_lim - 1)];
-        LN.left[plane][ly + sl] = (uint16_t)pl[(size_t)(gy + (sl < ph_lim ? sl : ph_lim - 1)) * gs + gx + cb];
+        LN.above[plane][lx + sl] = srow[sl < pw_lim ? sl : pw_lim - 1];
+        LN.left[plane][ly + sl] = scol[sl < ph_lim ? sl : ph_lim - 1];
       }
       if (sl < step) {
         const int j = sl + 1, q = 4 * j - 1;
-        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = (uint16_t)pl[(size_t)(gy + rb) * gs + gx + (q < pw_lim ? q : pw_lim - 1)];
-        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = (uint16_t)pl[(size_t)(gy + (q < ph_lim ? q : ph_lim - 1)) * gs + gx + cb];
+        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = srow[q < pw_lim ? q : pw_lim - 1];
+        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = scol[q < ph_lim ? q : ph_lim - 1];
       }
       for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
       if (EXT && lane < (plane0 ? N >> 2 : N >> 3)) { LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = 0; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = 0; }
@@ -612,7 +627,20 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // ---- source block -> LDS.  16-bit samples of a block inside the frame go as 16-byte pieces of a row (8 samples: two loads per
   // lane for a 32x32 block instead of sixteen 2-byte ones, full cache lines; the stamps build had the sixteen at 25 - 30 % of a
   // block pass); 8-bit samples, 4-wide blocks and blocks that overhang the frame edge (clamped coordinates) sample by sample.
-  {
+  bool staged_src = false;
+  if constexpr (PH == 2 && NPL == 1 && N >= 8) {
+    if (plane0 == 0) {   // the walk's luma item: the superblock's source is staged (g_ws), edge samples already replicated
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      constexpr int CPR = N / 8;
+#pragma unroll
+      for (int q = sl; q < N * CPR; q += G) {
+        const int r = q / CPR, c8 = q - r * CPR;
+        *reinterpret_cast<u4 *>(&S->srcblk[r * N + 8 * c8]) = *reinterpret_cast<const u4 *>(&g_ws.src_y[(y0 + r) * 64 + x0 + 8 * c8]);
+      }
+      staged_src = true;
+    }
+  }
+  if (!staged_src) {
     const PIX *pl = frame + poff;
     bool wide = false;
     if constexpr (sizeof(PIX) == 2 && N >= 8) {
@@ -1425,9 +1453,9 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
     int mode = 3 << 4;   // (mode | (angle delta + 3) << 4)
     InterInfo ii;
     ii.ref = ref_frame; ii.is_inter = 0; ii.mv_row = ii.mv_col = 0; ii.sad_inter = 0;
-    if (INTER) {
+    if constexpr (INTER) {
       // motion search result of this leaf: (cost << 16) | candidate index, cost = SAD + n * (|dx| + |dy|)
-      const unsigned long long key = me_best[(by >> 3) * b8_stride + (bx >> 3)];
+      const unsigned long long key = g_ws.key[(by >> 3) * 8 + (bx >> 3)];   // (staged per superblock: recon_sb_kernel)
       if (P.subpel) {  // refined (me_kernel.hip): (SAD << 36) | (u16 mv.row << 16) | u16 mv.col, 1/8 samples
         ii.mv_row = (int16_t)(key >> 16); ii.mv_col = (int16_t)key;
         ii.sad_inter = (int)(key >> 36);
@@ -1438,8 +1466,8 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
         ii.sad_inter = cost - n * ((dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv));
       }
       // the block's inter version is done (recon_inter_pre_kernel): its eobs, in case motion compensation wins
-      const Av1miBlkInfo &pre = info[(by >> 3) * b8_stride + (bx >> 3)];
-      ii.pre_eob[0] = pre.eob[0]; ii.pre_eob[1] = pre.eob[1]; ii.pre_eob[2] = pre.eob[2];
+      const uint16_t *pre = g_ws.pre_eob[(by >> 3) * 8 + (bx >> 3)];
+      ii.pre_eob[0] = pre[0]; ii.pre_eob[1] = pre[1]; ii.pre_eob[2] = pre[2];
     }
     int16_t *lv_y = sb_levels + av1mi_levels_off(0, bx, by);
     int16_t *lv_u = sb_levels + av1mi_levels_off(1, bx, by), *lv_v = sb_levels + av1mi_levels_off(2, bx, by);
@@ -1560,6 +1588,49 @@ __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribut
           if (y == sz && x == -1) v = 0;
         }
         sbl->blkdec[pl][y + 1][x + 1] = (uint8_t)v;
+      }
+    }
+    if constexpr (INTER) {
+      // stage what the walk's blocks would fetch from HBM one after the other (WalkStage): every load of the superblock in flight at once
+      const int t = threadIdx.x, W = P.width, H = P.height, Wc = W >> 1, Hc = H >> 1;
+      const int sx = sbc * 64, sy = sbr * 64, gsy = P.stride_y, gsc = P.stride_c;
+      const PIX *recf = rec + (size_t)f * P.frame_samples;
+      for (int q = t; q < 64 * 8; q += 128) {   // source luma, 8 samples per piece
+        const int r = q >> 3, c8 = q & 7, y = sy + r < H ? sy + r : H - 1, x = sx + 8 * c8;
+        const PIX *row = frame + (size_t)y * gsy;
+        uint16_t *dst = &g_ws.src_y[r * 64 + 8 * c8];
+        if (sizeof(PIX) == 2 && x + 8 <= W && ((gsy | x) & 7) == 0) {
+          typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<u4 *>(dst) = *reinterpret_cast<const u4 *>(row + x);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) dst[j] = (uint16_t)row[x + j < W ? x + j : W - 1];
+        }
+      }
+      for (int q = t; q < 8 * 64; q += 128) {   // provisional reconstruction: luma rows / columns 8 k + 7
+        const int k = q >> 6, i = q & 63;
+        const int yr = sy + 8 * k + 7 < H ? sy + 8 * k + 7 : H - 1, xr = sx + i < W ? sx + i : W - 1;
+        const int yc = sy + i < H ? sy + i : H - 1, xc = sx + 8 * k + 7 < W ? sx + 8 * k + 7 : W - 1;
+        g_ws.row_y[k][i] = (uint16_t)recf[(size_t)yr * gsy + xr];
+        g_ws.col_y[k][i] = (uint16_t)recf[(size_t)yc * gsy + xc];
+      }
+      for (int q = t; q < 2 * 8 * 32; q += 128) {   // U, V: rows / columns 4 k + 3
+        const int pl = q >> 8, k = (q >> 5) & 7, i = q & 31;
+        const PIX *pc = recf + (pl ? P.plane_off_v : P.plane_off_u);
+        const int cx0 = sx >> 1, cy0 = sy >> 1;
+        const int yr = cy0 + 4 * k + 3 < Hc ? cy0 + 4 * k + 3 : Hc - 1, xr = cx0 + i < Wc ? cx0 + i : Wc - 1;
+        const int yc = cy0 + i < Hc ? cy0 + i : Hc - 1, xc = cx0 + 4 * k + 3 < Wc ? cx0 + 4 * k + 3 : Wc - 1;
+        g_ws.row_c[pl][k][i] = (uint16_t)pc[(size_t)yr * gsc + xr];
+        g_ws.col_c[pl][k][i] = (uint16_t)pc[(size_t)yc * gsc + xc];
+      }
+      if (t < 64) {   // search keys and the inter version's eobs of the superblock's 8x8 units (units outside the frame are never asked for)
+        const int uy = sbr * 8 + (t >> 3), ux = sbc * 8 + (t & 7);
+        if (uy < P.b8_rows && ux < P.b8_cols) {
+          const size_t u = (size_t)uy * P.b8_cols + ux;
+          g_ws.key[t] = me_best[u];
+          const Av1miBlkInfo bi = blk[(size_t)f * P.b8_rows * P.b8_cols + u];
+          g_ws.pre_eob[t][0] = bi.eob[0]; g_ws.pre_eob[t][1] = bi.eob[1]; g_ws.pre_eob[t][2] = bi.eob[2];
+        }
       }
     }
     __syncthreads();
