@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 _VARIANT = os.environ.get("AV1MI_BUILD_VARIANT", "")
 OUT = os.path.join(HERE, "ab", "libav1mi_%s.so" % _VARIANT) if _VARIANT else os.path.join(HERE, "libav1mi.so")
 OBJDIR = os.path.join(HERE, "build_" + _VARIANT if _VARIANT else "build")
-SOURCES = ["recon_kernel.hip", "recon64_kernel.hip", "entropy_kernel.hip", "cdef_pack_kernels.hip", "scene_kernels.hip", "me_kernel.hip", "lr_kernel.hip", "deblock_kernel.hip", "av1mi_host.cpp", "av1mi_file.cpp", "av1mi_exec.cpp"]
+SOURCES = ["recon64_kernel.hip", "recon64_8_kernel.hip", "recon_kernel.hip", "recon8_kernel.hip", "entropy_kernel.hip", "cdef_pack_kernels.hip", "scene_kernels.hip", "me_kernel.hip", "lr_kernel.hip", "deblock_kernel.hip", "av1mi_host.cpp", "av1mi_file.cpp", "av1mi_exec.cpp"]
 # -fno-optimize-sibling-calls: keeps LLVM from marking the calls of the `noinline` transform items `tail`.  With the marker the
 # backend's interprocedural register allocation treats the items as ordinary ABI functions that save and restore every
 # callee-saved VGPR they touch - 33 stores + 29 loads of 256 B per call, 60 % of the reconstruction kernel's HBM traffic
@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("AV1MI_BUILD_JOBS", "6"))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or not os.path.exists(OUT):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"])

@@ -27,10 +27,13 @@
 
 extern "C" {
 hipError_t av1mi_launch_partition(const Av1miDevParams *P, const void *frames, uint32_t *part, hipStream_t stream);
-hipError_t av1mi_launch_recon(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
-                              const unsigned long long *me_best, const uint32_t *part, hipStream_t s);
-hipError_t av1mi_launch_recon64(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, Av1miBlkInfo *blk, const void *ref,
-                                const unsigned long long *me_best, const uint32_t *part, hipStream_t s);
+// one translation unit per (largest leaf, sample type): recon_kernel.hip, recon8_kernel.hip, recon64_kernel.hip, recon64_8_kernel.hip
+#define AV1MI_RECON_PROTO(name) hipError_t name(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels, \
+                                               Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, const uint32_t *part, hipStream_t s)
+AV1MI_RECON_PROTO(av1mi_launch_recon_u16);
+AV1MI_RECON_PROTO(av1mi_launch_recon_u8);
+AV1MI_RECON_PROTO(av1mi_launch_recon64_u16);
+AV1MI_RECON_PROTO(av1mi_launch_recon64_u8);
 hipError_t av1mi_launch_subpel_refine(const Av1miDevParams *P, const void *frames, const unsigned long long *best, unsigned long long *refined,
                                       int me_range, int frame0, int count, hipStream_t stream);
 hipError_t av1mi_launch_motion_search(const Av1miDevParams *P, const void *frames, unsigned long long *best, int me_range, int frame0,
@@ -992,7 +995,8 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   const bool inter_chunk = P.keyint > 1 && n_frames > 1;
   // 64x64 leaf blocks run the kernels of recon64_kernel.hip (64-point transforms, larger LDS tiles)
-  auto launch_recon = P.max_bs_log2 >= 6 ? av1mi_launch_recon64 : av1mi_launch_recon;
+  auto launch_recon = P.max_bs_log2 >= 6 ? (P.bit_depth == 8 ? av1mi_launch_recon64_u8 : av1mi_launch_recon64_u16)
+                                         : (P.bit_depth == 8 ? av1mi_launch_recon_u8 : av1mi_launch_recon_u16);
   const bool lr = P.enable_lr != 0;
   uint32_t entropy_from = 0;      // inter chunks: frames before this one are entropy-coded on the third stream, beside the chain
   bool sym_groups = false;        // ... or only symbolized there (AV1MI_SYM_GROUP)

@@ -1,6 +1,5 @@
-// recon64_kernel.hip - the reconstruction kernels for block_log2 = 6: 64x64 luma blocks coded with the 64-point DCT (only the
-// 32x32 low-frequency corner of the coefficients exists in AV1: spec §7.13.3), 32x32 chroma blocks - north_star's "4x4-64x64
-// DCT/ADST"; SURVEY.md §8a row a10.  Same source as recon_kernel.hip, compiled with the larger LDS tiles and the 64-point
-// networks (av1mi_launch_recon64); kept in a translation unit of its own so that the 32x32 kernels' occupancy stays what it is.
+// recon64_kernel.hip - the reconstruction kernels for leaf blocks up to 64x64 (block_log2 = 6), 16-bit samples: the same source as
+// recon_kernel.hip compiled with AV1MI_RECON_BIG (64-point transforms, 64x64 LDS tiles, 2 waves per SIMD) in a translation unit of its
+// own, so that the 32x32 kernels keep their LDS footprint and occupancy.
 #define AV1MI_RECON_BIG 1
 #include "recon_kernel.hip"

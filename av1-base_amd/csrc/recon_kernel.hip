@@ -32,6 +32,11 @@
 #ifndef AV1MI_RECON_BIG
 #define AV1MI_RECON_BIG 0
 #endif
+// ... and once per sample type: as is for 16-bit samples (10-bit video), through recon8_kernel.hip / recon64_8_kernel.hip with
+// AV1MI_RECON_PIX8 = 1 for 8-bit samples - four translation units that compile side by side (one unit took 13 minutes).
+#ifndef AV1MI_RECON_PIX8
+#define AV1MI_RECON_PIX8 0
+#endif
 #define MAXN (AV1MI_RECON_BIG ? 64 : 32)   /* largest transform block side */
 #define AV1_TXFM_FN static __device__ __forceinline__
 // Round2(w0 * a + w1 * b, 12) of the butterfly rotations with 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24: full rate; the
@@ -1719,7 +1724,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_R
 }
 }  // namespace
 
-#if defined(AV1MI_STAMPS) && !AV1MI_RECON_BIG
+#if defined(AV1MI_STAMPS) && !AV1MI_RECON_BIG && !AV1MI_RECON_PIX8
 // diagnostic build: read (and clear) the phase sums.  out[class * 8 + phase] cycles, then total wave cycles, then waves
 extern "C" int av1mi_debug_stamps(unsigned long long *out, int reset) {
   unsigned long long z[STAMP_CLASSES * STAMP_PHASES + 3] = {};
@@ -1732,10 +1737,19 @@ extern "C" int av1mi_debug_stamps(unsigned long long *out, int reset) {
 // ref == nullptr: P->n_frames key frames in one launch.  ref != nullptr: ONE inter frame (P->n_frames must be 1),
 // predicted from `ref` with the motion search results `me_best` of that frame.
 // dP: the same parameters in device memory (what the kernel reads; n_frames and the loop-filter levels are not used by it).
-#if AV1MI_RECON_BIG
-#define AV1MI_LAUNCH_RECON av1mi_launch_recon64   /* leaf blocks up to 64x64 (P->max_bs_log2 == 6) */
+#if AV1MI_RECON_BIG && AV1MI_RECON_PIX8
+#define AV1MI_LAUNCH_RECON av1mi_launch_recon64_u8   /* leaf blocks up to 64x64 (P->max_bs_log2 == 6), 8-bit samples */
+#elif AV1MI_RECON_BIG
+#define AV1MI_LAUNCH_RECON av1mi_launch_recon64_u16
+#elif AV1MI_RECON_PIX8
+#define AV1MI_LAUNCH_RECON av1mi_launch_recon_u8     /* leaf blocks up to 32x32 */
 #else
-#define AV1MI_LAUNCH_RECON av1mi_launch_recon     /* leaf blocks up to 32x32 */
+#define AV1MI_LAUNCH_RECON av1mi_launch_recon_u16
+#endif
+#if AV1MI_RECON_PIX8
+typedef uint8_t ReconPix;
+#else
+typedef uint16_t ReconPix;
 #endif
 extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDevParams *dP, const void *src, void *rec, int16_t *levels,
                                          Av1miBlkInfo *blk, const void *ref, const unsigned long long *me_best, const uint32_t *part, hipStream_t stream) {
@@ -1752,7 +1766,7 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
                               levels, blk, (const PIXT *)ref, me_best, g, part);                                                             \
     } while (0)
 #define PRE_LAUNCH(PIXT) do { if (P->subpel) PRE_LAUNCH2(PIXT, true); else PRE_LAUNCH2(PIXT, false); } while (0)
-    if (P->bit_depth == 8) PRE_LAUNCH(uint8_t); else PRE_LAUNCH(uint16_t);
+    PRE_LAUNCH(ReconPix);
 #undef PRE_LAUNCH
 #undef PRE_LAUNCH2
   }
@@ -1767,13 +1781,8 @@ extern "C" hipError_t AV1MI_LAUNCH_RECON(const Av1miDevParams *P, const Av1miDev
   // the optional intra tools (edge filter, chroma from luma) live in instantiations of their own (EXT)
 #define RECON_LAUNCH(PIXT, INTERV, TSBV)                                                                                                    \
   do { if (P->edge_filter || P->cfl || P->tx_search) RECON_LAUNCH2(PIXT, INTERV, TSBV, true); else RECON_LAUNCH2(PIXT, INTERV, TSBV, false); } while (0)
-  if (P->bit_depth == 8) {
-    if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(uint8_t, true, 1); else RECON_LAUNCH(uint8_t, false, 1); }
-    else { if (inter) RECON_LAUNCH(uint8_t, true, 2); else RECON_LAUNCH(uint8_t, false, 2); }
-  } else {
-    if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(uint16_t, true, 1); else RECON_LAUNCH(uint16_t, false, 1); }
-    else { if (inter) RECON_LAUNCH(uint16_t, true, 2); else RECON_LAUNCH(uint16_t, false, 2); }
-  }
+  if (P->tile_sb == 1) { if (inter) RECON_LAUNCH(ReconPix, true, 1); else RECON_LAUNCH(ReconPix, false, 1); }
+  else { if (inter) RECON_LAUNCH(ReconPix, true, 2); else RECON_LAUNCH(ReconPix, false, 2); }
 #undef RECON_LAUNCH
 #undef RECON_LAUNCH2
   return hipGetLastError();
