@@ -15,7 +15,7 @@
 //        cooperatively, lane j = CDF entry j).  Output: a flat stream of 32-bit entries per tile,
 //        either RESOLVED (fl>>6, fh>>6, N-s: nothing left but range coding; literals are this kind
 //        too) or NARROW (slot, symbol) for the 4-symbol coefficient CDFs that still must adapt.
-//   K4 rangecode_tiles_kernel  one LANE per tile, 64 tiles per wave.  Each lane keeps its tile's
+//   K4 rangecode{2,4}_tiles_kernel  one LANE per tile, 64 tiles per wave.  Each lane keeps its tile's
 //        adaptive coeff_base / coeff_br rows (2 x 63 rows x 8 B) in LDS laid out [slot][lane] -
 //        bank = 2*lane mod 64 whatever the slot, i.e. conflict-free across lanes - plus its own
 //        range coder in VGPRs, and walks its stream.  The serial chain now runs 64-wide on the
@@ -804,20 +804,252 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles, const uin
 }
 
 // ================================================================================= K4
+// One lane per tile, 64 tiles per workgroup, FOUR waves per workgroup - one per SIMD of the CU - working as a pipeline over batches of
+// RC_BATCH entries (batch k is at stage j in trip k + j; double-buffered LDS rings between the stages, one barrier per trip):
+//   wave 0 (adapt):   walks the tile's stream and adapts the tile's narrow CDF rows (LDS, [slot][lane] x 8 bytes {c0, c1, c2, counter});
+//                     passes on every entry's row as it was BEFORE the entry;
+//   wave 1 (resolve): turns (entry, row) into a RESOLVED entry {fl, fh, N - s};
+//   wave 2 (range):   the range recurrence alone: rng -> (what the entry adds to `low`, the normalisation shift);
+//   wave 3 (output):  accumulates `low` and writes the tile's bytes.
+// The kernel's duration is the serial chain of its longest tile (~4.8 k symbols at 1080p) times the instructions per entry of the
+// slowest stage: a wave alone on its SIMD issues one vector instruction per ~4.4 cycles, so the two-wave form (resolver 61, coder 45
+// instructions per entry) was bound at 61; the stages here are 34 / 25 / 20 / 34.
+#define RC_BATCH 16
+#define RC_DUMMY (MAX_COMBOS * SLOTS_PER_COMBO)
+struct RcLds {
+  uint64_t row[RC_DUMMY + 1][64];   // + one dummy row: entries that need no resolving go through it, branch-free
+  uint64_t ring_row[2][RC_BATCH][64];
+  uint32_t ring_ent[2][RC_BATCH][64];
+  uint32_t ring_upd[2][RC_BATCH][64];
+};
+__shared__ RcLds g_rc;
+
+__global__ void __launch_bounds__(256) rangecode4_tiles_kernel(Av1miDevParams P, int n_tiles, const uint16_t *__restrict__ cdf_init,
+                                                             const uint32_t *__restrict__ streams, const uint32_t *__restrict__ stream_len,
+                                                             const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
+                                                             uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ order,
+                                                             int tile0 /* chunk-wide index of the launch's first tile; n_tiles and `order` are launch-local */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // order != nullptr (more workgroups than the chip holds at once): a permutation of the launch's tiles, see the launcher
+  const bool live = (int)(blockIdx.x * 64 + lane) < n_tiles;
+  const int tile = live ? tile0 + (order ? (int)order[blockIdx.x * 64 + lane] : (int)(blockIdx.x * 64 + lane)) : 0;
+  const int count_raw = live ? (int)stream_len[tile] : 0;
+  const bool overflow = count_raw > P.stream_cap;
+  const int count = overflow ? 0 : count_raw;
+  int maxcount = count;
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(maxcount, o, 64); maxcount = t > maxcount ? t : maxcount; }
+  const int nb = (maxcount + RC_BATCH - 1) / RC_BATCH;
+  const uint32_t *st = streams + (size_t)(live ? tile : 0) * P.stream_cap;
+  const int adapt = !P.disable_cdf_update;
+
+  // ---- adapt stage: per-lane CDF rows from the defaults of this tile's two (tx size, plane type) classes
+  if (wave == 0) {
+    const uint32_t cm = live ? tile_combos[tile] : 0xFFFFu;
+    for (int k = 0; k < MAX_COMBOS; k++) {
+      const int combo = (cm >> (8 * k)) & 0xFF;
+      if (combo == 0xFF) continue;
+      const int txs = combo >> 1, ptype = combo & 1;
+      const uint16_t *b = cdf_init + CL::COEFF_BASE + (txs * 2 + ptype) * 42 * 5;
+      const uint16_t *r = cdf_init + CL::COEFF_BR + ((txs > 3 ? 3 : txs) * 2 + ptype) * 21 * 5;
+      for (int j = 0; j < 42; j++) g_rc.row[k * SLOTS_PER_COMBO + j][lane] = (uint64_t)b[j * 5] | ((uint64_t)b[j * 5 + 1] << 16) | ((uint64_t)b[j * 5 + 2] << 32);
+      for (int j = 0; j < 21; j++) g_rc.row[k * SLOTS_PER_COMBO + 42 + j][lane] = (uint64_t)r[j * 5] | ((uint64_t)r[j * 5 + 1] << 16) | ((uint64_t)r[j * 5 + 2] << 32);
+    }
+    g_rc.row[RC_DUMMY][lane] = 0;
+  }
+  // ---- range stage / output stage state
+  uint32_t low = 0, rng = 0x8000;
+  int cnt = -9, out_pos = 0;
+  // Output: "pre-carry" entries, one 16-bit value per output byte holding the byte and, in bit 8, a carry that still
+  // has to be added to the bytes before it (od_ec's precarry buffer).  Nothing already written is ever touched here;
+  // pack_tiles_kernel resolves the carries of a whole tile with a wave-parallel carry-lookahead when it copies the
+  // tile to its final place.
+  // (the tile's slot is a per-lane 64-bit base - chunks whose slots exceed 4 GB are legal: 4K x 140 frames at capacity scale 2 -
+  // and the entry's position inside it a 32-bit offset, one v_lshl_add_u64 per store; an entry beyond the slot's capacity goes to
+  // the last one: the overflow is reported through tile_bytes, what the slot then holds does not matter)
+  uint16_t *const out_tile = reinterpret_cast<uint16_t *>(slots) + (size_t)(live ? tile : 0) * (size_t)P.tile_slot_bytes;
+  const int out_cap = P.tile_slot_bytes;  // entries
+#define PUT(pos_, v_)                                                                                                    \
+  do {                                                                                                                   \
+    out_tile[(uint32_t)((pos_) < out_cap ? (pos_) : out_cap - 1)] = (uint16_t)((v_) & 0x1FFu);                           \
+  } while (0)
+#define EMIT(v_) do { PUT(out_pos, v_); out_pos++; } while (0)
+
+  __syncthreads();
+  // The stream reads of waves 0 and 1 are one 16-byte request per lane into 64 different streams (an HBM / L2 round trip each):
+  // the next batch is loaded while the current one is worked on (handing the entries from wave 0 to wave 1 through LDS instead was
+  // measured: no faster).  What lies beyond a tile's count inside the last 16 bytes is whatever an earlier chunk left there: wave 0
+  // may adapt rows with it (the tile is over), wave 1 replaces it by an entry that codes nothing.
+  uint4 qn[RC_BATCH / 4];
+  auto load_batch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < RC_BATCH; j += 4) {
+      const int i1 = kb * RC_BATCH + j;
+      qn[j / 4] = i1 < count ? *reinterpret_cast<const uint4 *>(st + i1) : make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u);
+    }
+  };
+  if (wave <= 1 && nb > 0) load_batch(0);
+  for (int k = 0; k < nb + 3; k++) {
+    if (wave == 0) {
+      if (k < nb) {
+        uint32_t ev[RC_BATCH];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = qn[j / 4].x; ev[j + 1] = qn[j / 4].y; ev[j + 2] = qn[j / 4].z; ev[j + 3] = qn[j / 4].w; }
+        if (k + 1 < nb) load_batch(k + 1);
+        // The 16 entries of the batch, one after the other.  An entry that is already resolved runs the same instructions against the
+        // dummy row: no divergent branch.  The row of entry i + 1 is read BEFORE entry i's row is written back, and replaced by that
+        // new row if both entries name the same slot - otherwise every entry waited for an LDS round trip behind the previous
+        // entry's write (read -> adapt -> write -> read ...).
+        auto slot_of = [&](uint32_t e) { const uint32_t t = e >> 2; return (int)(t < (uint32_t)RC_DUMMY ? t : (uint32_t)RC_DUMMY); };
+        int slot = slot_of(ev[0]);
+        uint64_t rw = g_rc.row[slot][lane];
+#pragma unroll
+        for (int jj = 0; jj < RC_BATCH; jj++) {
+          const int s = ev[jj] & 3;
+          int slot_nx = 0;
+          uint64_t rw_nx = 0;
+          if (jj + 1 < RC_BATCH) { slot_nx = slot_of(ev[jj + 1]); rw_nx = g_rc.row[slot_nx][lane]; }
+          g_rc.ring_row[k & 1][jj][lane] = rw;
+          uint64_t nrow = rw;
+          if (adapt) {
+            // the three values move towards 32768 (index < s) or 0 by their distance >> rate: packed 16-bit arithmetic on {c0, c1}
+            // and on {c2, counter} (the counter half is replaced afterwards)
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
+            const uint32_t cn = c2n >> 16;
+            const unsigned short rate = (unsigned short)(5 + (cn >> 4));   // counter <= 32: 5 + (cn > 15) + (cn > 31)
+            const us2 rv = { rate, rate }, top = { 0x8000, 0x8000 };
+            const us2 a = __builtin_bit_cast(us2, c01), b = __builtin_bit_cast(us2, c2n);
+            const uint32_t up01 = __builtin_bit_cast(uint32_t, (us2)(a + ((top - a) >> rv))), dn01 = __builtin_bit_cast(uint32_t, (us2)(a - (a >> rv)));
+            const uint32_t up2 = __builtin_bit_cast(uint32_t, (us2)(b + ((top - b) >> rv))), dn2 = __builtin_bit_cast(uint32_t, (us2)(b - (b >> rv)));
+            const uint32_t m01 = s >= 2 ? 0xFFFFFFFFu : (s ? 0xFFFFu : 0u);   // halves with index < s
+            const uint32_t n01 = (up01 & m01) | (dn01 & ~m01);
+            const uint32_t cn1 = cn + 1 < 32u ? cn + 1 : 32u;
+            const uint32_t n2 = ((s > 2 ? up2 : dn2) & 0xFFFFu) | (cn1 << 16);
+            nrow = (uint64_t)n01 | ((uint64_t)n2 << 32);
+            g_rc.row[slot][lane] = nrow;
+          }
+          if (jj + 1 < RC_BATCH) { rw = slot_nx == slot ? nrow : rw_nx; slot = slot_nx; }
+        }
+      }
+    } else if (wave == 1) {
+      if (k >= 1 && k - 1 < nb) {
+        const int kb = k - 1;
+        uint32_t ev[RC_BATCH];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = qn[j / 4].x; ev[j + 1] = qn[j / 4].y; ev[j + 2] = qn[j / 4].z; ev[j + 3] = qn[j / 4].w; }
+        if (kb + 1 < nb) load_batch(kb + 1);
+        uint64_t rws[RC_BATCH];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH; j++) rws[j] = g_rc.ring_row[kb & 1][j][lane];
+#pragma unroll
+        for (int jj = 0; jj < RC_BATCH; jj++) {
+          uint32_t ent = ev[jj];
+          const int s = ent & 3;
+          const uint32_t c01 = (uint32_t)rws[jj], c2 = (uint32_t)(rws[jj] >> 32) & 0xFFFFu;
+          // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): one 64-bit shift each of {32768, c0, c1, c2} / {c0, c1, c2, 0}
+          const uint64_t vals = ((uint64_t)c2 << 32) | c01;
+          const uint32_t fh = (uint32_t)(vals >> (16 * s)) & 0xFFFFu;
+          const uint32_t fl = (uint32_t)(((vals << 16) | 0x8000u) >> (16 * s)) & 0xFFFFu;
+          ent = (ent & 0x80000000u) ? ent : ENT_RESOLVED(fl >> 6, fh >> 6, 3 - s);
+          // beyond this tile's count: "the whole range" (fl = 32768, fh = 0 of a one-symbol alphabet) changes nothing and emits nothing
+          ent = kb * RC_BATCH + jj < count ? ent : ENT_RESOLVED(512, 0, 0);
+          g_rc.ring_ent[kb & 1][jj][lane] = ent;
+        }
+      }
+    } else if (wave == 2) {
+      if (k >= 2 && k - 2 < nb) {
+        const int kb = k - 2;
+        uint32_t ce[RC_BATCH];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH; j++) ce[j] = g_rc.ring_ent[kb & 1][j][lane];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH; j++) {
+          const uint32_t ent = ce[j];
+          const uint32_t fl6 = (ent >> 14) & 0x3FF, fh6 = (ent >> 4) & 0x3FF, ns = ent & 15;
+          // range update (od_ec_encode_q15, the mirror of spec §8.2.6), branch-free: fl6 == 512 <=> s == 0
+          const uint32_t r = rng, r8 = r >> 8;
+          // (r8 < 2^8, fl6 / fh6 <= 512: 24-bit multiplies, full rate)
+          const uint32_t v = (__umul24(r8, fh6) >> 1) + 4u * ns;
+          const uint32_t u = fl6 >= 512 ? r : (__umul24(r8, fl6) >> 1) + 4u * ns + 4u;
+          const uint32_t nr = u - v;
+          const int d = __builtin_clz(nr) - 16;
+          rng = nr << d;
+          g_rc.ring_upd[kb & 1][j][lane] = (r - u) | ((uint32_t)d << 16);
+        }
+      }
+    } else {
+      if (k >= 3) {
+        const int kb = k - 3;
+        uint32_t cu[RC_BATCH];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH; j++) cu[j] = g_rc.ring_upd[kb & 1][j][lane];
+#pragma unroll
+        for (int j = 0; j < RC_BATCH; j++) {
+          const int d = (int)(cu[j] >> 16);
+          uint32_t l = low + (cu[j] & 0xFFFFu);
+          int s2 = cnt + d;
+          if (s2 >= 0) {   // one byte, or two when at least 8 bits are ready (od_ec_enc_normalize)
+            int c = cnt + 16;
+            const bool two = s2 >= 8;
+            // no inner branch: the first byte is stored in any case and, if it was not due, overwritten by the second at the same position
+            PUT(out_pos, l >> c);
+            out_pos += two;
+            l = two ? l & ((1u << c) - 1) : l;
+            c = two ? c - 8 : c;
+            EMIT(l >> c);
+            l &= (1u << c) - 1;
+            s2 = c + d - 24;
+          }
+          low = l << d;
+          cnt = s2;
+        }
+      }
+    }
+    // (the fences name the LDS address space only: __syncthreads() also waits for the wave's global memory traffic - the stream loads
+    // just issued for the NEXT trip and the output stores - which put an HBM round trip into every trip)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+  // ---- finish (od_ec_enc_done), output wave
+  if (wave == 3) {
+    if (live && !overflow) {
+      uint32_t l = low;
+      int c = cnt, s = 10;
+      const uint32_t m = 0x3FFF;
+      uint32_t v = ((l + m) & ~m) | (m + 1);
+      s += c;
+      if (s > 0) {
+        uint32_t n = (1u << (c + 16)) - 1;
+        do {
+          EMIT(v >> (c + 16));
+          v &= n;
+          s -= 8;
+          c -= 8;
+          n >>= 8;
+        } while (s > 0);
+      }
+    }
+    if (live) tile_bytes[tile] = overflow ? 0xFFFFFFFFu : (uint32_t)out_pos;
+  }
+}
+#undef EMIT
+#undef PUT
+
+// ---- K4, two-stage form (more than 256 workgroups: see the launcher)
 // One lane per tile, 64 tiles per workgroup, TWO waves per workgroup working as a pipeline:
 //   wave 0 (resolver): walks the tile's stream, adapts the tile's narrow CDF rows (LDS, [slot][lane] x
 //           8 bytes {c0, c1, c2, counter}) and turns every entry into a RESOLVED one in an LDS ring;
 //   wave 1 (coder):    runs the range coder over the ring and writes the tile's bytes.
 // The kernel's duration is the serial chain of its longest tile (~4.8 k symbols at 1080p), so halving
 // the instructions per link of that chain matters more than anything else here.
-#define RC_BATCH 16
-struct RcLds {
+struct Rc2Lds {
   uint64_t row[MAX_COMBOS * SLOTS_PER_COMBO + 1][64];   // + one dummy row: entries that need no resolving go through it, branch-free
   uint32_t ring[2][RC_BATCH][64];
 };
-__shared__ RcLds g_rc;
+__shared__ Rc2Lds g_rc2;
 
-__global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, int n_tiles, const uint16_t *__restrict__ cdf_init,
+__global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P, int n_tiles, const uint16_t *__restrict__ cdf_init,
                                                              const uint32_t *__restrict__ streams, const uint32_t *__restrict__ stream_len,
                                                              const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
                                                              uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ order,
@@ -847,8 +1079,8 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
       const int txs = combo >> 1, ptype = combo & 1;
       const uint16_t *b = cdf_init + CL::COEFF_BASE + (txs * 2 + ptype) * 42 * 5;
       const uint16_t *r = cdf_init + CL::COEFF_BR + ((txs > 3 ? 3 : txs) * 2 + ptype) * 21 * 5;
-      for (int j = 0; j < 42; j++) g_rc.row[k * SLOTS_PER_COMBO + j][lane] = (uint64_t)b[j * 5] | ((uint64_t)b[j * 5 + 1] << 16) | ((uint64_t)b[j * 5 + 2] << 32);
-      for (int j = 0; j < 21; j++) g_rc.row[k * SLOTS_PER_COMBO + 42 + j][lane] = (uint64_t)r[j * 5] | ((uint64_t)r[j * 5 + 1] << 16) | ((uint64_t)r[j * 5 + 2] << 32);
+      for (int j = 0; j < 42; j++) g_rc2.row[k * SLOTS_PER_COMBO + j][lane] = (uint64_t)b[j * 5] | ((uint64_t)b[j * 5 + 1] << 16) | ((uint64_t)b[j * 5 + 2] << 32);
+      for (int j = 0; j < 21; j++) g_rc2.row[k * SLOTS_PER_COMBO + 42 + j][lane] = (uint64_t)r[j * 5] | ((uint64_t)r[j * 5 + 1] << 16) | ((uint64_t)r[j * 5 + 2] << 32);
     }
   }
   // ---- coder state
@@ -901,7 +1133,7 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
         const int i0 = k * RC_BATCH;
         auto slot_of = [&](int idx, uint32_t e) { return (i0 + idx < count && !(e & 0x80000000u)) ? (int)((e >> 2) & 0x1FF) : MAX_COMBOS * SLOTS_PER_COMBO; };
         int slot = slot_of(0, ev[0]);
-        uint64_t rw = g_rc.row[slot][lane];
+        uint64_t rw = g_rc2.row[slot][lane];
 #pragma unroll
         for (int jj = 0; jj < RC_BATCH; jj++) {
           uint32_t ent = ev[jj];
@@ -909,7 +1141,7 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
           const int s = ent & 3;
           int slot_nx = 0;
           uint64_t rw_nx = 0;
-          if (jj + 1 < RC_BATCH) { slot_nx = slot_of(jj + 1, ev[jj + 1]); rw_nx = g_rc.row[slot_nx][lane]; }
+          if (jj + 1 < RC_BATCH) { slot_nx = slot_of(jj + 1, ev[jj + 1]); rw_nx = g_rc2.row[slot_nx][lane]; }
           const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
           // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): one 64-bit shift each of {32768, c0, c1, c2} / {c0, c1, c2, 0}
           const uint64_t vals = ((uint64_t)(c2n & 0xFFFFu) << 32) | c01;
@@ -931,9 +1163,9 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
             const uint32_t n01 = (up01 & m01) | (dn01 & ~m01);
             const uint32_t n2 = ((s > 2 ? up2 : dn2) & 0xFFFFu) | ((cn + (cn < 32)) << 16);
             nrow = (uint64_t)n01 | ((uint64_t)n2 << 32);
-            g_rc.row[slot][lane] = nrow;
+            g_rc2.row[slot][lane] = nrow;
           }
-          g_rc.ring[k & 1][jj][lane] = ent;
+          g_rc2.ring[k & 1][jj][lane] = ent;
           if (jj + 1 < RC_BATCH) { rw = slot_nx == slot ? nrow : rw_nx; slot = slot_nx; }
         }
       }
@@ -943,7 +1175,7 @@ __global__ void __launch_bounds__(128) rangecode_tiles_kernel(Av1miDevParams P, 
       // count is coded as "the whole range" (fl = 32768, fh = 0 of a one-symbol alphabet): it changes nothing and emits nothing
       uint32_t ce[RC_BATCH];
 #pragma unroll
-      for (int j = 0; j < RC_BATCH; j++) ce[j] = g_rc.ring[(k - 1) & 1][j][lane];
+      for (int j = 0; j < RC_BATCH; j++) ce[j] = g_rc2.ring[(k - 1) & 1][j][lane];
 #pragma unroll
       for (int j = 0; j < RC_BATCH; j++) {
         {
@@ -1045,17 +1277,30 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   }
   if (mid) (void)hipEventRecord(mid, stream);
   if (!(phase & 2)) return hipGetLastError();
-  // The range coder holds 2 workgroups (of 64 tiles) per CU.  Up to that many workgroups all run at once and the kernel lasts
-  // as long as its longest tile: the natural order is best (a workgroup of 64 long tiles would be slower per symbol than
-  // one long tile among short ones - measured 1.1 -> 2.1 ms).  Beyond it the workgroups run in rounds, and what counts is
-  // the sum over workgroups of their longest tile: sorted order (4K, 30 frames: 3.9 -> 2.9 ms).
-  // experiment knob AV1MI_RC_LDS_PAD=<bytes>: dynamic LDS on top of the kernel's 73 KB - 16384 leaves room for ONE workgroup per CU, i.e. half
-  // of every CU's LDS for another chunk's kernels while the range coder takes two rounds
-  static const int lds_pad = [] { const char *e = getenv("AV1MI_RC_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 65536 ? v : 0; }();
-  const int per_cu = lds_pad >= 8192 ? 1 : 2;
-  const bool sorted = (n_tiles + 63) / 64 > per_cu * 256;
+  // Two forms of the range coder.  A wave of either wants a SIMD to itself (two workgroups' waves on one SIMD: twice as long,
+  // measured), so a CU runs four waves at full speed: ONE workgroup of the four-stage form (112 ns per entry of the longest tile) or
+  // TWO of the two-stage form (177 ns).  Measured range-coder times, two-stage / four-stage form, ms (tools/rc_probe.sh):
+  //   1080p all-key x 30 (239 workgroups) 0.94 / 0.64     x 60 (478) 0.91 / 1.12     x 120 (956) 1.91 / 1.75     x 60 at CQ 8 2.45 / 2.75
+  //   1080p IPPP x 60 (470)  0.80 / 0.60    at CQ 8  2.03 / 2.38    production point  1.43 / 1.59
+  //   4K x 30 (957) all-key  1.81 / 1.64    IPPP  1.01 / 0.84
+  // Up to 256 workgroups the four-stage form runs them all at once and wins; up to 512 the two-stage form still has everything
+  // resident while the four-stage form runs two rounds (it wins only where few tiles are long: IPPP at CQ 30); beyond that both run in
+  // rounds and the faster workgroup wins again.  AV1MI_RC_STAGES = 2 / 4 forces a form.
+  // Order of the tiles: while all workgroups run at once the kernel lasts as long as its longest tile and the natural order is best
+  // (a workgroup of 64 long tiles is slower per symbol than one long tile among short ones: 64 cache lines per store / stream
+  // load - measured 1.1 -> 2.1 ms).  In rounds what counts is the sum over a CU's workgroups of their longest tile: tiles sorted by
+  // decreasing length (4K, 30 frames: 3.9 -> 2.9 ms).
+  const char *const stages_str = getenv("AV1MI_RC_STAGES");   // (read per launch: the parity tests run both forms in one process)
+  const int stages_env = stages_str ? atoi(stages_str) : 0;
+  const int n_groups = (n_tiles + 63) / 64;
+  const int stages = stages_env == 2 || stages_env == 4 ? stages_env : (n_groups <= 256 || n_groups > 512 ? 4 : 2);
+  const bool sorted = n_groups > (stages == 4 ? 256 : 512);
   if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len + tile0, tile_order + tile0);
-  hipLaunchKernelGGL(rangecode_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(128), (size_t)lds_pad, stream, *P, n_tiles, cdf_init, streams, stream_len,
-                     tile_combos, slots, tile_bytes, sorted ? tile_order + tile0 : (uint32_t *)nullptr, tile0);
+  if (stages == 4)
+    hipLaunchKernelGGL(rangecode4_tiles_kernel, dim3(n_groups), dim3(256), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
+                       tile_combos, slots, tile_bytes, sorted ? tile_order + tile0 : (uint32_t *)nullptr, tile0);
+  else
+    hipLaunchKernelGGL(rangecode2_tiles_kernel, dim3(n_groups), dim3(128), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
+                       tile_combos, slots, tile_bytes, sorted ? tile_order + tile0 : (uint32_t *)nullptr, tile0);
   return hipGetLastError();
 }

@@ -127,10 +127,10 @@ def test_edge_cases_flat_and_extreme_inputs(av1mi, ctx, oracle):
         assert data == tu and recon.tobytes() == raw_of(rec, 8)
 
 
-def test_full_size_properties_1080p(av1mi, ctx, oracle):
+def test_full_size_properties_1080p(av1mi, ctx, oracle, monkeypatch):
     """At BASELINE's full frame size the oracle is still used for one frame (seconds), plus
     size-independent properties on a 6-frame chunk: per-frame independence (chunk == concatenation of
-    single-frame encodes), determinism, and the checksum of the frame sizes."""
+    single-frame encodes), determinism, the checksum of the frame sizes, and the same bytes from either form of the range coder."""
     w, h, bd = 1920, 1080, 10
     frames = [oracle.synthclip_frame(w, h, bd, seed=1080, t=t) for t in range(6)]
     raws = [raw_of(f, bd) for f in frames]
@@ -138,7 +138,11 @@ def test_full_size_properties_1080p(av1mi, ctx, oracle):
     data, sizes, rep, _ = ctx.encode_chunk(p, b"".join(raws), 6)
     data2, sizes2, _, _ = ctx.encode_chunk(p, b"".join(raws), 6)
     assert data == data2 and sizes == sizes2 and sum(sizes) == len(data)
-    off = 0
+    for form in ("2", "4"):
+        monkeypatch.setenv("AV1MI_RC_STAGES", form)
+        data3, sizes3, _, _ = ctx.encode_chunk(p, b"".join(raws), 6)
+        assert data == data3 and sizes == sizes3, form
+    monkeypatch.delenv("AV1MI_RC_STAGES")
     for i in (0, 5):
         one, s1, _, _ = ctx.encode_chunk(p, raws[i], 1)
         start = sum(sizes[:i])
@@ -436,8 +440,10 @@ def test_alternative_schedules_give_the_same_bytes(av1mi, oracle, monkeypatch):
     raw = b"".join(raw_of(f, bd) for f in frames)
     p = av1mi.default_params(w, h, bd, deblock=1, cdef_y_sec=1, cdef_uv_sec=2)
     outs = []
-    for env in ({}, {"AV1MI_INTRA_GROUPS": "3"}, {"AV1MI_CDEF_SPLIT": "1"}, {"AV1MI_INTRA_GROUPS": "4", "AV1MI_CDEF_SPLIT": "1"}):
-        for k in ("AV1MI_INTRA_GROUPS", "AV1MI_CDEF_SPLIT"):
+    # (AV1MI_RC_STAGES: the range coder's two-stage and four-stage forms - the launcher picks by the number of workgroups)
+    for env in ({}, {"AV1MI_INTRA_GROUPS": "3"}, {"AV1MI_CDEF_SPLIT": "1"}, {"AV1MI_INTRA_GROUPS": "4", "AV1MI_CDEF_SPLIT": "1"},
+                {"AV1MI_RC_STAGES": "2"}, {"AV1MI_RC_STAGES": "4"}):
+        for k in ("AV1MI_INTRA_GROUPS", "AV1MI_CDEF_SPLIT", "AV1MI_RC_STAGES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
