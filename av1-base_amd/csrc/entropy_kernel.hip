@@ -829,7 +829,7 @@ __global__ void __launch_bounds__(256) rangecode4_tiles_kernel(Av1miDevParams P,
                                                              const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
                                                              uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ order,
                                                              int tile0 /* chunk-wide index of the launch's first tile; n_tiles and `order` are launch-local */) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // order != nullptr (more workgroups than the chip holds at once): a permutation of the launch's tiles, see the launcher
   const bool live = (int)(blockIdx.x * 64 + lane) < n_tiles;
   const int tile = live ? tile0 + (order ? (int)order[blockIdx.x * 64 + lane] : (int)(blockIdx.x * 64 + lane)) : 0;
@@ -879,22 +879,35 @@ __global__ void __launch_bounds__(256) rangecode4_tiles_kernel(Av1miDevParams P,
   // the next batch is loaded while the current one is worked on (handing the entries from wave 0 to wave 1 through LDS instead was
   // measured: no faster).  What lies beyond a tile's count inside the last 16 bytes is whatever an earlier chunk left there: wave 0
   // may adapt rows with it (the tile is over), wave 1 replaces it by an entry that codes nothing.
-  uint4 qn[RC_BATCH / 4];
-  auto load_batch = [&](int kb) {
+  // Three register buffers (batch mod 3): a buffer is refilled with batch + 3 at the END of the trip that used it - when its registers
+  // are dead, so that the loaded registers ARE the loop-carried ones and nothing is copied (a copy waits for the load just issued) -
+  // which gives a load two whole trips to arrive.  The loads are unconditional (a load under `i < count` costs a select per register
+  // and makes the compiler wait for ALL loads in flight wherever one is used): a lane whose tile is shorter than the wave's longest
+  // reads what an earlier chunk left in its slot - batch kb < nb lies inside the slot, whose capacity is a multiple of the batch -
+  // and nothing uses it.
+  typedef uint4 QBuf[RC_BATCH / 4];
+  QBuf qa, qb, qc;
+  auto load_batch = [&](QBuf &q, int kb) __attribute__((always_inline)) {
+    kb = kb < nb ? kb : (nb > 0 ? nb - 1 : 0);
 #pragma unroll
-    for (int j = 0; j < RC_BATCH; j += 4) {
-      const int i1 = kb * RC_BATCH + j;
-      qn[j / 4] = i1 < count ? *reinterpret_cast<const uint4 *>(st + i1) : make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u);
-    }
+    for (int j = 0; j < RC_BATCH; j += 4) q[j / 4] = *reinterpret_cast<const uint4 *>(st + kb * RC_BATCH + j);
   };
-  if (wave <= 1 && nb > 0) load_batch(0);
-  for (int k = 0; k < nb + 3; k++) {
-    if (wave == 0) {
+  if (wave <= 1) { load_batch(qa, 0); load_batch(qb, 1); load_batch(qc, 2); }
+  // Every wave runs a loop of its own with the same number of barriers (nb + 3): in one loop with a branch per wave the compiler's
+  // wait-count pass loses track of the loads in flight at the joins and waits for all of them.
+  auto trip_end = [&]() __attribute__((always_inline)) {
+    // (the fences name the LDS address space only: the stream loads in flight and the output stores must not be waited for here)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  const int n_trips = (nb + 3 + 2) / 3 * 3;   // (a multiple of 3: the loops of waves 0 and 1 are unrolled by the three buffers)
+  auto stage0 = [&](const int k, QBuf &q0) __attribute__((always_inline)) {
+    {
       if (k < nb) {
         uint32_t ev[RC_BATCH];
 #pragma unroll
-        for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = qn[j / 4].x; ev[j + 1] = qn[j / 4].y; ev[j + 2] = qn[j / 4].z; ev[j + 3] = qn[j / 4].w; }
-        if (k + 1 < nb) load_batch(k + 1);
+        for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = q0[j / 4].x; ev[j + 1] = q0[j / 4].y; ev[j + 2] = q0[j / 4].z; ev[j + 3] = q0[j / 4].w; }
         // The 16 entries of the batch, one after the other.  An entry that is already resolved runs the same instructions against the
         // dummy row: no divergent branch.  The row of entry i + 1 is read BEFORE entry i's row is written back, and replaced by that
         // new row if both entries name the same slot - otherwise every entry waited for an LDS round trip behind the previous
@@ -931,13 +944,17 @@ __global__ void __launch_bounds__(256) rangecode4_tiles_kernel(Av1miDevParams P,
           if (jj + 1 < RC_BATCH) { rw = slot_nx == slot ? nrow : rw_nx; slot = slot_nx; }
         }
       }
-    } else if (wave == 1) {
+    }
+    load_batch(q0, k + 3);
+    trip_end();
+  };
+  auto stage1 = [&](const int k, QBuf &q1) __attribute__((always_inline)) {
+    {
       if (k >= 1 && k - 1 < nb) {
         const int kb = k - 1;
         uint32_t ev[RC_BATCH];
 #pragma unroll
-        for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = qn[j / 4].x; ev[j + 1] = qn[j / 4].y; ev[j + 2] = qn[j / 4].z; ev[j + 3] = qn[j / 4].w; }
-        if (kb + 1 < nb) load_batch(kb + 1);
+        for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = q1[j / 4].x; ev[j + 1] = q1[j / 4].y; ev[j + 2] = q1[j / 4].z; ev[j + 3] = q1[j / 4].w; }
         uint64_t rws[RC_BATCH];
 #pragma unroll
         for (int j = 0; j < RC_BATCH; j++) rws[j] = g_rc.ring_row[kb & 1][j][lane];
@@ -956,7 +973,12 @@ __global__ void __launch_bounds__(256) rangecode4_tiles_kernel(Av1miDevParams P,
           g_rc.ring_ent[kb & 1][jj][lane] = ent;
         }
       }
-    } else if (wave == 2) {
+    }
+    if (k >= 1) load_batch(q1, k - 1 + 3);
+    trip_end();
+  };
+  auto stage2 = [&](const int k) __attribute__((always_inline)) {
+    {
       if (k >= 2 && k - 2 < nb) {
         const int kb = k - 2;
         uint32_t ce[RC_BATCH];
@@ -977,8 +999,12 @@ __global__ void __launch_bounds__(256) rangecode4_tiles_kernel(Av1miDevParams P,
           g_rc.ring_upd[kb & 1][j][lane] = (r - u) | ((uint32_t)d << 16);
         }
       }
-    } else {
-      if (k >= 3) {
+    }
+    trip_end();
+  };
+  auto stage3 = [&](const int k) __attribute__((always_inline)) {
+    {
+      if (k >= 3 && k - 3 < nb) {
         const int kb = k - 3;
         uint32_t cu[RC_BATCH];
 #pragma unroll
@@ -1005,11 +1031,16 @@ __global__ void __launch_bounds__(256) rangecode4_tiles_kernel(Av1miDevParams P,
         }
       }
     }
-    // (the fences name the LDS address space only: __syncthreads() also waits for the wave's global memory traffic - the stream loads
-    // just issued for the NEXT trip and the output stores - which put an HBM round trip into every trip)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    trip_end();
+  };
+  if (wave == 0) {
+    for (int k = 0; k < n_trips; k += 3) { stage0(k, qa); stage0(k + 1, qb); stage0(k + 2, qc); }
+  } else if (wave == 1) {   // (its batch is k - 1)
+    for (int k = 0; k < n_trips; k += 3) { stage1(k, qc); stage1(k + 1, qa); stage1(k + 2, qb); }
+  } else if (wave == 2) {
+    for (int k = 0; k < n_trips; k++) stage2(k);
+  } else {
+    for (int k = 0; k < n_trips; k++) stage3(k);
   }
   // ---- finish (od_ec_enc_done), output wave
   if (wave == 3) {
@@ -1054,7 +1085,7 @@ __global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P,
                                                              const uint32_t *__restrict__ tile_combos, uint8_t *__restrict__ slots,
                                                              uint32_t *__restrict__ tile_bytes, const uint32_t *__restrict__ order,
                                                              int tile0 /* chunk-wide index of the launch's first tile; n_tiles and `order` are launch-local */) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // order != nullptr (more tiles than the chip holds workgroups for at once): the 64 tiles of a workgroup are neighbours in
   // the order of decreasing stream length (tile_order_kernel) - a wave lasts as long as its longest tile, so similar lengths
   // waste the fewest lane-cycles, and the long ones start first
@@ -1105,24 +1136,29 @@ __global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P,
   // batch k is resolved by wave 0 in trip k and coded by wave 1 in trip k + 1.  The resolver's stream reads are one
   // 16-byte request per lane into 64 different streams (an HBM round trip each): batch k + 1 is loaded while batch k is
   // being resolved, otherwise every trip would start with that latency.
-  uint4 qn[RC_BATCH / 4];
-  if (wave == 0) {
+  // (three register buffers refilled with batch + 3 at the end of the trip that used them, unconditional loads, a loop per wave with the
+  // same number of barriers: see the four-stage form)
+  typedef uint4 QBuf[RC_BATCH / 4];
+  QBuf qa, qb, qd;
+  auto load_batch = [&](QBuf &q, int kb) __attribute__((always_inline)) {
+    kb = kb < nb ? kb : (nb > 0 ? nb - 1 : 0);
 #pragma unroll
-    for (int j = 0; j < RC_BATCH; j += 4) qn[j / 4] = j < count ? *reinterpret_cast<const uint4 *>(st + j) : make_uint4(0, 0, 0, 0);
-  }
-  for (int k = 0; k <= nb; k++) {
-    if (wave == 0) {
+    for (int j = 0; j < RC_BATCH; j += 4) q[j / 4] = *reinterpret_cast<const uint4 *>(st + kb * RC_BATCH + j);
+  };
+  if (wave == 0) { load_batch(qa, 0); load_batch(qb, 1); load_batch(qd, 2); }
+  auto trip_end = [&]() __attribute__((always_inline)) {
+    // (the fences name the LDS address space only: the stream loads in flight and the output stores must not be waited for here)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  const int n_trips = (nb + 1 + 2) / 3 * 3;
+  auto resolve_trip = [&](const int k, QBuf &q0) __attribute__((always_inline)) {
+    {
       if (k < nb) {
         uint4 qc[RC_BATCH / 4];
 #pragma unroll
-        for (int j = 0; j < RC_BATCH / 4; j++) qc[j] = qn[j];
-        if (k + 1 < nb) {
-#pragma unroll
-          for (int j = 0; j < RC_BATCH; j += 4) {
-            const int i1 = (k + 1) * RC_BATCH + j;
-            qn[j / 4] = i1 < count ? *reinterpret_cast<const uint4 *>(st + i1) : make_uint4(0, 0, 0, 0);
-          }
-        }
+        for (int j = 0; j < RC_BATCH / 4; j++) qc[j] = q0[j];
         // The 16 entries of the batch, one after the other.  An entry that is already resolved (or lies beyond this tile's count) runs
         // the same instructions against a dummy row and keeps its value: no divergent branch.  The row of entry i + 1 is read BEFORE
         // entry i's row is written back, and replaced by that new row if both entries name the same slot - otherwise every entry
@@ -1169,7 +1205,12 @@ __global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P,
           if (jj + 1 < RC_BATCH) { rw = slot_nx == slot ? nrow : rw_nx; slot = slot_nx; }
         }
       }
-    } else if (k > 0) {
+    }
+    load_batch(q0, k + 3);
+    trip_end();
+  };
+  auto code_trip = [&](const int k) __attribute__((always_inline)) {
+    if (k > 0 && k <= nb) {
       const int base = (k - 1) * RC_BATCH;
       // the batch's 16 entries into registers at once (the reads are independent of the coder's state); an entry beyond this tile's
       // count is coded as "the whole range" (fl = 32768, fh = 0 of a one-symbol alphabet): it changes nothing and emits nothing
@@ -1209,7 +1250,12 @@ __global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P,
         }
       }
     }
-    __syncthreads();
+    trip_end();
+  };
+  if (wave == 0) {
+    for (int k = 0; k < n_trips; k += 3) { resolve_trip(k, qa); resolve_trip(k + 1, qb); resolve_trip(k + 2, qd); }
+  } else {
+    for (int k = 0; k < n_trips; k++) code_trip(k);
   }
   // ---- finish (od_ec_enc_done), coder wave
   if (wave == 1) {
@@ -1278,14 +1324,15 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   if (mid) (void)hipEventRecord(mid, stream);
   if (!(phase & 2)) return hipGetLastError();
   // Two forms of the range coder.  A wave of either wants a SIMD to itself (two workgroups' waves on one SIMD: twice as long,
-  // measured), so a CU runs four waves at full speed: ONE workgroup of the four-stage form (112 ns per entry of the longest tile) or
-  // TWO of the two-stage form (177 ns).  Measured range-coder times, two-stage / four-stage form, ms (tools/rc_probe.sh):
-  //   1080p all-key x 30 (239 workgroups) 0.94 / 0.64     x 60 (478) 0.91 / 1.12     x 120 (956) 1.91 / 1.75     x 60 at CQ 8 2.45 / 2.75
-  //   1080p IPPP x 60 (470)  0.80 / 0.60    at CQ 8  2.03 / 2.38    production point  1.43 / 1.59
-  //   4K x 30 (957) all-key  1.81 / 1.64    IPPP  1.01 / 0.84
+  // measured), so a CU runs four waves at full speed: ONE workgroup of the four-stage form (~100 ns per entry of the longest tile) or
+  // TWO of the two-stage form (~160 ns).  Measured range-coder times, two-stage / four-stage form, ms (tools/rc_probe.sh):
+  //   1080p all-key x 30 (239 workgroups) 0.88 / 0.56     x 60 (478) 0.85 / 1.06     x 120 (956) 1.86 / 1.69     x 60 at CQ 8 2.32 / 2.62
+  //   1080p IPPP x 60 (470)  0.76 / 0.58    at CQ 8  2.05 / 2.12    production point  1.46 / 1.43    8K IPPP x 16 (510)  2.0 / 1.6
+  //   4K x 30 (957) all-key  1.75 / 1.59    IPPP  0.96 / 0.77
   // Up to 256 workgroups the four-stage form runs them all at once and wins; up to 512 the two-stage form still has everything
-  // resident while the four-stage form runs two rounds (it wins only where few tiles are long: IPPP at CQ 30); beyond that both run in
-  // rounds and the faster workgroup wins again.  AV1MI_RC_STAGES = 2 / 4 forces a form.
+  // resident while the four-stage form runs two rounds - that costs more than it gains where every frame has its long tiles (all-key
+  // chunks) and less where few tiles are long (chunks with inter frames); beyond 512 both run in rounds and the faster workgroup
+  // wins again.  AV1MI_RC_STAGES = 2 / 4 forces a form.
   // Order of the tiles: while all workgroups run at once the kernel lasts as long as its longest tile and the natural order is best
   // (a workgroup of 64 long tiles is slower per symbol than one long tile among short ones: 64 cache lines per store / stream
   // load - measured 1.1 -> 2.1 ms).  In rounds what counts is the sum over a CU's workgroups of their longest tile: tiles sorted by
@@ -1293,7 +1340,7 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   const char *const stages_str = getenv("AV1MI_RC_STAGES");   // (read per launch: the parity tests run both forms in one process)
   const int stages_env = stages_str ? atoi(stages_str) : 0;
   const int n_groups = (n_tiles + 63) / 64;
-  const int stages = stages_env == 2 || stages_env == 4 ? stages_env : (n_groups <= 256 || n_groups > 512 ? 4 : 2);
+  const int stages = stages_env == 2 || stages_env == 4 ? stages_env : (n_groups <= 256 || n_groups > 512 || has_inter ? 4 : 2);
   const bool sorted = n_groups > (stages == 4 ? 256 : 512);
   if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len + tile0, tile_order + tile0);
   if (stages == 4)
