@@ -616,6 +616,7 @@ def main():
                          "a step then processes chunks-per-gpu x frames frames")
     ap.add_argument("--bit-depth", type=int, default=10)
     ap.add_argument("--block-log2", type=int, default=5)
+    ap.add_argument("--partition-min", type=int, default=0, help="content-driven partition with leaves from 2^k (3..) up to --block-log2")
     ap.add_argument("--static-cdf", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode-mask", type=lambda s: int(s, 0), default=0x1FFF,
@@ -649,12 +650,12 @@ def main():
     base = dict(name="cfg2_1080p_intra", width=args.width, height=args.height, frames=args.frames, keyint=args.keyint, me_range=args.me_range,
                 cq=args.cq, film_grain=args.film_grain, sgr=args.sgr, subpel=args.subpel, qm=args.qm, deblock=args.deblock, lr=args.lr,
                 chunks_per_gpu=args.chunks_per_gpu, bit_depth=args.bit_depth, block_log2=args.block_log2, static_cdf=args.static_cdf,
-                mode_mask=args.mode_mask, seed=1080)
+                mode_mask=args.mode_mask, seed=1080, partition_min=args.partition_min)
     if args.workload == "cfg4":   # BASELINE config 4: "4K30 10-bit, 8 scene-chunks sharded across 8xMI355X (one chunk/GPU, independent HIP streams)"
         base.update(name="cfg4_4k_job8", width=3840, height=2160, frames=30, keyint=240, seed=2160, bit_depth=10, job_chunks=8, mode_mask=0x7)
     default_flags = args.workload == "cfg2" and all(getattr(args, k) == ap.get_default(k) for k in (
         "width", "height", "frames", "keyint", "me_range", "cq", "film_grain", "sgr", "subpel", "qm", "deblock", "lr", "chunks_per_gpu",
-        "bit_depth", "block_log2", "static_cdf", "mode_mask"))
+        "bit_depth", "block_log2", "static_cdf", "mode_mask", "partition_min"))
     if not default_flags:
         base["name"] = "custom"
     with_configs = args.configs == "all" or (args.configs == "auto" and world == 1 and default_flags)
