@@ -778,28 +778,48 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
 }
 #undef S
 
-// Tiles in the order of decreasing symbol-stream length, to batches of 16 entries: a counting sort in one workgroup
-// (histogram over length / 16 in LDS, exclusive scan, scatter).  Which tile of a bucket comes first does not matter -
+// Tiles in the order of decreasing symbol-stream length: a counting sort in one workgroup (histogram over the length in LDS,
+// exclusive scan, scatter).  Which tile of a bucket comes first does not matter -
 // every tile writes only its own slot.
 __global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles, const uint32_t *__restrict__ stream_len, uint32_t *__restrict__ order) {
-  __shared__ uint32_t hist[1024];
-  __shared__ uint32_t base[1024];
+  // One bucket per length (8192; longer streams share the first): with one per 16 entries most tiles of a chunk met in a few dozen
+  // buckets and the LDS atomics of a wave serialised on them - 161 us for the 30 600 tiles of a 1080p x 60 chunk, a third of what the
+  // four-stage range coder then takes.  The lengths are read eight per thread with all loads in flight before the first atomic; the
+  // bucket bases come from a scan over eight buckets per thread, wave shuffles, and the 16 waves' sums.
+  constexpr int NB = 8192, PER = NB / 1024, U = 8;
+  __shared__ uint32_t hist[NB];
+  __shared__ uint32_t wsum[16];
   const int t = threadIdx.x;
-  hist[t] = 0;
+  auto bucket = [](uint32_t len) { return (uint32_t)(NB - 1) - (len > (uint32_t)(NB - 1) ? (uint32_t)(NB - 1) : len); };
+  for (int k = 0; k < PER; k++) hist[k * 1024 + t] = 0;
   __syncthreads();
-  for (int i = t; i < n_tiles; i += 1024) {
-    const uint32_t b = stream_len[i] >> 4;
-    atomicAdd(&hist[1023 - (b > 1023 ? 1023 : b)], 1u);
+  for (int i0 = 0; i0 < n_tiles; i0 += 1024 * U) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = i0 + u * 1024 + t; v[u] = stream_len[i < n_tiles ? i : n_tiles - 1]; }   // (a load under a condition is waited for on the spot)
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = i0 + u * 1024 + t; if (i < n_tiles) atomicAdd(&hist[bucket(v[u])], 1u); }
   }
   __syncthreads();
-  if (t == 0) {
-    uint32_t acc = 0;
-    for (int k = 0; k < 1024; k++) { base[k] = acc; acc += hist[k]; }
-  }
+  // exclusive scan: thread t owns buckets PER t .. PER t + PER - 1
+  uint32_t own[PER], tot = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { own[k] = hist[t * PER + k]; tot += own[k]; }
+  uint32_t inc = tot;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += y; }
+  if ((t & 63) == 63) wsum[t >> 6] = inc;
   __syncthreads();
-  for (int i = t; i < n_tiles; i += 1024) {
-    const uint32_t b = stream_len[i] >> 4;
-    order[atomicAdd(&base[1023 - (b > 1023 ? 1023 : b)], 1u)] = (uint32_t)i;
+  uint32_t base = inc - tot;
+  for (int w = 0; w < (t >> 6); w++) base += wsum[w];
+#pragma unroll
+  for (int k = 0; k < PER; k++) { hist[t * PER + k] = base; base += own[k]; }
+  __syncthreads();
+  for (int i0 = 0; i0 < n_tiles; i0 += 1024 * U) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = i0 + u * 1024 + t; v[u] = stream_len[i < n_tiles ? i : n_tiles - 1]; }   // (a load under a condition is waited for on the spot)
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = i0 + u * 1024 + t; if (i < n_tiles) order[atomicAdd(&hist[bucket(v[u])], 1u)] = (uint32_t)i; }
   }
 }
 

@@ -71,12 +71,10 @@ __constant__ uint8_t c_sm_weights[4 + 8 + 16 + 32 + 64] = {
 __constant__ int16_t c_dr_deriv[91] = AV1MI_DR_DERIV_INIT;
 // floor(64 k / Dr_Intra_Derivative[angle]) for k = 1 .. 32 as (64 k * magic) >> 22 (the row where a 90 < angle < 180 prediction switches edges)
 __constant__ uint32_t c_dr_magic[91] = AV1MI_DR_MAGIC_INIT;
-__constant__ int16_t c_mode_angle[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
 // Mode_To_Txfm (spec §6.10.x): 0 DCT_DCT 1 ADST_DCT 2 DCT_ADST 3 ADST_ADST
 // luma 32x32 forward transform on the matrix cores: per lane the operand fragments of fdct32_matrix.h (stage-1 B low / high bytes,
 // stage-2 A low / high bytes)
 __device__ const uint32_t c_fdct32_frag[64][16] = AV1_FDCT32_FRAG_INIT;
-__constant__ uint8_t c_mode_txfm[14] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3, 0 };   // [13] = UV_CFL_PRED
 
 // LDS per superblock-wave (~9 KB, so ~4 waves fit a SIMD): decoder-style line buffers instead of the
 // whole reconstructed superblock.  above[p][x] = bottom row of the last block reconstructed over column
@@ -750,10 +748,14 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   // mode_io: bits 0-3 the mode, bits 4-6 the angle delta + 3 (chroma passes follow the luma decision; luma passes decide)
   int best_mode = mode_io & 15, best_delta = ((mode_io >> 4) & 7) - 3, best_sad = 0x7FFFFFFF, sad_dc = -1;
   // direction parameters of a directional mode at an angle delta (§7.11.2.4)
+  // (mode and delta are the same in every lane; saying so turns the table reads into scalar loads from the constant cache - as
+  // per-lane loads each was a global round trip the wave waited for on the spot, two or three per candidate - and the mode's base
+  // angle comes out of a 64-bit literal: 90, 180, 45, 135, 113, 157, 203, 67 for V_PRED .. D67_PRED)
   auto dir_params = [&](int mode, int delta, int &ang, int &dx, int &dy) {
     ang = 0; dx = 0; dy = 0;
+    mode = uniform_i(mode); delta = uniform_i(delta);
     if (mode >= V_PRED && mode <= D67_PRED) {
-      ang = c_mode_angle[mode] + 3 * delta;
+      ang = (int)((0x43CB9D71872DB45Aull >> (8 * (mode - V_PRED))) & 255u) + 3 * delta;
       if (ang < 90) dx = c_dr_deriv[ang];
       else if (ang > 90 && ang < 180) { dx = c_dr_deriv[180 - ang]; dy = c_dr_deriv[ang - 90]; }
       else if (ang > 180) dy = c_dr_deriv[270 - ang];
@@ -1060,7 +1062,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   wave_sync();
   STAMP(2);   // other candidates, decision, prediction + residual
   // ---- transform: fwd columns | fwd rows + quant + dequant + inv rows | inv columns
-  const int txt = (LOG2N <= 4 && !(INTER && ii.is_inter)) ? c_mode_txfm[best_mode] : 0;  // inter blocks: DCT_DCT
+  // (Mode_To_Txfm, two bits per mode, out of a literal: the table read was a per-lane global load waited for on the spot)
+  const int txt = (LOG2N <= 4 && !(INTER && ii.is_inter)) ? (int)((0x39DA724u >> (2 * best_mode)) & 3u) : 0;  // inter blocks: DCT_DCT
   // transform type search (tx_search; EXT instantiations): an intra luma block of up to 16x16 whose residual
   // is sparse - at most one sample in eight nonzero - takes the identity transform (IDTX) both ways
   int idtx = 0;

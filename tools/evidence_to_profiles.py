@@ -16,10 +16,10 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OURS = ("recon_", "cdef_", "symbolize_", "rangecode_", "motion_search", "subpel_refine", "me64_", "pack_", "sse_", "lr_", "deblock_",
+OURS = ("recon_", "cdef_", "symbolize_", "rangecode", "motion_search", "subpel_refine", "me64_", "pack_", "sse_", "lr_", "deblock_",
         "luma_sad", "tile_order", "carry_", "scene_")
 STAGE_OF = (("recon_sb_kernel", "recon"), ("recon_inter_pre_kernel", "recon_pre"), ("cdef_sb_kernel", "cdef"), ("symbolize_tile_kernel", "symbolize"),
-            ("rangecode_tiles_kernel", "rangecode"), ("motion_search_kernel", "motion_search"))
+            ("rangecode2_tiles_kernel", "rangecode"), ("rangecode4_tiles_kernel", "rangecode"), ("motion_search_kernel", "motion_search"))
 
 
 def short(name):
