@@ -68,7 +68,7 @@ __constant__ uint8_t c_sm_weights[4 + 8 + 16 + 32 + 64] = {
   255, 248, 240, 233, 225, 218, 210, 203, 196, 189, 182, 176, 169, 163, 156, 150, 144, 138, 133, 127, 121, 116, 111, 106, 101, 96, 91, 86, 82, 77, 73, 69,
   65, 61, 57, 54, 50, 47, 44, 41, 38, 35, 32, 29, 27, 25, 22, 20, 18, 16, 15, 13, 12, 10, 9, 8, 7, 6, 6, 5, 5, 4, 4, 4 };
 // Dr_Intra_Derivative indexed by angle/3 rounded down is not injective, so index by angle (values: intra_pieces.h)
-__constant__ int16_t c_dr_deriv[91] = AV1MI_DR_DERIV_INIT;
+__constant__ int c_dr_deriv[91] = AV1MI_DR_DERIV_INIT;   // (32-bit: the scalar unit has no 16-bit loads, and the angle is the same in every lane)
 // floor(64 k / Dr_Intra_Derivative[angle]) for k = 1 .. 32 as (64 k * magic) >> 22 (the row where a 90 < angle < 180 prediction switches edges)
 __constant__ uint32_t c_dr_magic[91] = AV1MI_DR_MAGIC_INIT;
 // Mode_To_Txfm (spec §6.10.x): 0 DCT_DCT 1 ADST_DCT 2 DCT_ADST 3 ADST_ADST
@@ -511,10 +511,27 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
 // tile walk carried 348 B of scratch per lane for it).  The wave-uniform arguments are laundered through readfirstlane so that
 // the compiler keeps them - and everything derived from them: addresses, edge availability, loop bounds - on the scalar unit.
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// (the pointers are rebuilt as pointers into GLOBAL memory: a pointer that arrives through a `noinline` function's arguments is a
+// generic one, its accesses FLAT instructions - slower, and counted on the LDS counter too, so that a wait for an LDS read also waits
+// for every global store in flight)
 template <typename T>
 __device__ __forceinline__ T *uniform_p(T *p) {
+  typedef T __attribute__((address_space(1))) *G;
   const unsigned long long a = (unsigned long long)p;
-  return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+  return (T *)(G)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+}
+// (a pointer into LDS: the low 32 bits of its generic form are the LDS offset)
+template <typename T>
+__device__ __forceinline__ T *uniform_lds_p(T *p) {
+  typedef T __attribute__((address_space(3))) *L;
+  return (T *)(L)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)p);
+}
+// the parameter block: constant address space - its fields become scalar loads through the constant cache instead of per-lane FLAT
+// loads the wave waits for on the spot (nothing writes the block while a kernel runs)
+__device__ __forceinline__ const Av1miDevParams *uniform_params(const Av1miDevParams *p) {
+  typedef const Av1miDevParams __attribute__((address_space(4))) *C;
+  const unsigned long long a = (unsigned long long)p;
+  return (const Av1miDevParams *)(C)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
 // EXT: the instantiation contains the optional intra tools (edge filter / upsampling, chroma from luma); the default operating
 // point runs the instantiations without them - their code alone cost 5 % (the items are larger than the instruction cache).
@@ -522,9 +539,9 @@ template <typename PIX, int LOG2N, int NPL, bool INTER, int TSB, bool QM, int PH
 __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX *rec_frame, int plane0, int x0, int y0,
                                                  int mode_io, InterInfo ii, int16_t *lv_out0, int16_t *lv_out1, int *eob_out, int post_idx) {
   post_idx = uniform_i(post_idx);
-  cx.P = uniform_p(cx.P); cx.sb_x = uniform_i(cx.sb_x); cx.sb_y = uniform_i(cx.sb_y); cx.tox = uniform_i(cx.tox); cx.toy = uniform_i(cx.toy);
+  cx.P = uniform_params(cx.P); cx.sb_x = uniform_i(cx.sb_x); cx.sb_y = uniform_i(cx.sb_y); cx.tox = uniform_i(cx.tox); cx.toy = uniform_i(cx.toy);
   frame = uniform_p(frame); rec_frame = uniform_p(rec_frame); plane0 = uniform_i(plane0); x0 = uniform_i(x0); y0 = uniform_i(y0);
-  mode_io = uniform_i(mode_io); lv_out0 = uniform_p(lv_out0); lv_out1 = uniform_p(lv_out1); eob_out = uniform_p(eob_out);
+  mode_io = uniform_i(mode_io); lv_out0 = uniform_p(lv_out0); lv_out1 = uniform_p(lv_out1); eob_out = uniform_lds_p(eob_out);
   if (INTER) {
     ii.ref = uniform_p(ii.ref); ii.mv_row = uniform_i(ii.mv_row); ii.mv_col = uniform_i(ii.mv_col); ii.sad_inter = uniform_i(ii.sad_inter);
     ii.is_inter = uniform_i(ii.is_inter); ii.pre_eob[0] = uniform_i(ii.pre_eob[0]); ii.pre_eob[1] = uniform_i(ii.pre_eob[1]); ii.pre_eob[2] = uniform_i(ii.pre_eob[2]);
