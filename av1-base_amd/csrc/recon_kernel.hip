@@ -526,6 +526,9 @@ __device__ __forceinline__ T *uniform_lds_p(T *p) {
   typedef T __attribute__((address_space(3))) *L;
   return (T *)(L)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)p);
 }
+// the quantiser-matrix table (its address is a field of the parameter block): a pointer into global memory
+typedef const Av1miQmEntry __attribute__((address_space(1))) *QmTab;
+__device__ __forceinline__ QmTab qm_table(const Av1miDevParams *P) { return (QmTab)(unsigned long long)P->qm_tab; }
 // the parameter block: constant address space - its fields become scalar loads through the constant cache instead of per-lane FLAT
 // loads the wave waits for on the spot (nothing writes the block while a kernel runs)
 __device__ __forceinline__ const Av1miDevParams *uniform_params(const Av1miDevParams *p) {
@@ -1150,7 +1153,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     {
       const int col = mr;
       const uint32_t acq = (uint32_t)P->ac_q, acr = P->ac_recip;
-      const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + AV1MI_QM_32X32 + col : nullptr;
+      const QmTab tab = QM ? qm_table(P) + (pc ? AV1MI_QM_PLANE : 0) + AV1MI_QM_32X32 + col : (QmTab)0;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * mh;
@@ -1228,16 +1231,18 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         if (lastj >= 0) { const int d0 = row + lastj; my_key = (d0 << 6) | ((d0 & 1) ? row : lastj); my_ext = ((uint32_t)(row + 1) << 16) | (uint32_t)(lastj + 1); }
       } else {
       constexpr int QM_OFF = LOG2N == 2 ? AV1MI_QM_4X4 : (LOG2N == 3 ? AV1MI_QM_8X8 : (LOG2N == 4 ? AV1MI_QM_16X16 : AV1MI_QM_32X32));
-      const Av1miQmEntry *tab = P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row;
+      const QmTab tab = qm_table(P) + (pc ? AV1MI_QM_PLANE : 0) + QM_OFF + row;
+      // (the flat quantiser's four values as scalars first: selecting between a field of the parameter block and a table entry made the
+      // compiler select between two ADDRESSES in different address spaces - FLAT loads)
+      const uint32_t dcq = (uint32_t)P->dc_q, acq = (uint32_t)P->ac_q, dcr = P->dc_recip, acr = P->ac_recip;
   #pragma unroll
       for (int j = 0; j < CW; j++) {
         const int v = rshift_round(x[j], SH2);
-        Av1miQmEntry e = tab[j * CW];
+        uint32_t q = tab[j * CW].q, recip = tab[j * CW].recip;
         if (idtx) {   // the matrices apply to the 2-D DCT / ADST types only (spec 7.12.3: PlaneTxType < IDTX)
           const bool dc = (row | j) == 0;
-          e.q = dc ? (uint32_t)P->dc_q : (uint32_t)P->ac_q; e.recip = dc ? P->dc_recip : P->ac_recip;
+          q = dc ? dcq : acq; recip = dc ? dcr : acr;
         }
-        const uint32_t q = e.q, recip = e.recip;
         // frequency-dependent dead zone: 3q/8 for row+col < n/4, q/4 below n/2, q/8 above (n = the coded width)
         const int d0 = row + j;
         const uint32_t rnd = d0 < (CW >> 2) ? (3 * q) >> 3 : (d0 < (CW >> 1) ? (q >> 2) : (q >> 3));
@@ -1296,7 +1301,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     constexpr int NZT = decltype(tag)::value, NZ = NZT < CW ? NZT : CW;
     if constexpr (MM) {
       const int row = sl, lim = 1 << (7 + bd);
-      const Av1miQmEntry *tab = QM ? P->qm_tab + (pc ? AV1MI_QM_PLANE : 0) + AV1MI_QM_32X32 + row : nullptr;
+      const QmTab tab = QM ? qm_table(P) + (pc ? AV1MI_QM_PLANE : 0) + AV1MI_QM_32X32 + row : (QmTab)0;
       const uint32_t *lw = reinterpret_cast<const uint32_t *>(lvl + row * 32);
 #pragma unroll
       for (int j2 = 0; j2 < NZ / 2; j2++) {
