@@ -157,12 +157,14 @@ __device__ __forceinline__ int scan_pos(int c, int log2n) {
   return c_scan_tab.v[off + c];
 }
 
-__constant__ uint8_t c_base_ctx_off[5][5] = { { 0, 1, 6, 6, 21 }, { 1, 6, 6, 21, 21 }, { 6, 6, 21, 21, 21 }, { 6, 21, 21, 21, 21 }, { 21, 21, 21, 21, 21 } };
-__constant__ uint8_t c_intra_mode_ctx[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };
-__constant__ uint8_t c_mode_txfm[13] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3 };
+// Small per-block tables as literals (four / two bits per entry): as `__constant__` byte arrays each read was a per-lane global load
+// the wave waited for on the spot (the scalar unit has no byte loads) - a cache round trip per block and table on a serial chain.
+// Intra_Mode_Context { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 }, Mode_To_Txfm { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3, 1, 2, 3 }
+__device__ __forceinline__ int intra_mode_ctx(int mode) { return (int)((0x210344443210ull >> (4 * mode)) & 15u); }
+__device__ __forceinline__ int mode_txfm(int mode) { return (int)((0x39da724u >> (2 * mode)) & 3u); }
 // symbol of {DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST} in intra set 1 (7 symbols) / set 2 (5 symbols)
-__constant__ uint8_t c_txsym_set1[4] = { 1, 5, 6, 4 };
-__constant__ uint8_t c_txsym_set2[4] = { 1, 3, 4, 2 };
+__device__ __forceinline__ int txsym_set1(int tt) { return (0x4651 >> (4 * tt)) & 15; }   // { 1, 5, 6, 4 }
+__device__ __forceinline__ int txsym_set2(int tt) { return (0x2431 >> (4 * tt)) & 15; }   // { 1, 3, 4, 2 }
 
 struct TileGeo {
   int tox, toy;     // origin of the current superblock inside the tile, luma pixels (0 or 64)
@@ -235,9 +237,9 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       // (TX_64X64: the transform set is DCT only, nothing is coded)
     } else if (plane == 0 && log2n <= 4) {
       // intra_tx_type: the mode's default type, or IDTX (symbol 0 of both intra sets) when the reconstruction chose it
-      const int tt = c_mode_txfm[ymode];
-      if (log2n <= 3) sym_wide(y, lane, adapt, idtx ? 0 : c_txsym_set1[tt], CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
-      else sym_wide(y, lane, adapt, idtx ? 0 : c_txsym_set2[tt], CL::TX_SET2 + ((log2n - 2) * 13 + ymode) * 6, 5);
+      const int tt = mode_txfm(ymode);
+      if (log2n <= 3) sym_wide(y, lane, adapt, idtx ? 0 : txsym_set1(tt), CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
+      else sym_wide(y, lane, adapt, idtx ? 0 : txsym_set2(tt), CL::TX_SET2 + ((log2n - 2) * 13 + ymode) * 6, 5);
     }
     {
       const int eob_pt = eob <= 2 ? eob : floor_log2((unsigned)(eob - 1)) + 2;
@@ -266,10 +268,14 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
     }
     const int base_off0 = CL::COEFF_BASE + (txs * 2 + ptype) * 42 * 5;
     const int br_off0 = CL::COEFF_BR + ((txs > 3 ? 3 : txs) * 2 + ptype) * 21 * 5;
+    // Scan positions come from a table in device memory: the load for the NEXT 64 coefficients is issued before the current ones are
+    // worked on, with a clamped index instead of a condition (a load under `if (c >= 0)` is waited for on the spot, and on this serial
+    // chain that was a cache round trip per 64 coefficients and pass).
+    int pos_nx = scan(imax(eob - 1 - lane, 0));
     // ---- last coefficient: coeff_base_eob (3 symbols, resolved here)
     {
       const int cc = eob - 1;
-      const int lvl_last = uni(iabs((int)S->lv[scan(cc)]));
+      const int lvl_last = uni(iabs((int)S->lv[__builtin_amdgcn_readfirstlane(pos_nx)]));   // (lane 0 holds scan index eob - 1)
       const int cctx = cc == 0 ? 0 : (cc <= (n * n) / 8 ? 1 : (cc <= (n * n) / 4 ? 2 : 3));
       sym_wide(y, lane, adapt, imin(lvl_last, 3) - 1, CL::COEFF_BASE_EOB + ((txs * 2 + ptype) * 4 + cctx) * 4, 3);
     }
@@ -277,8 +283,9 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
     for (int c_hi = eob - 1; c_hi >= 0; c_hi -= 64) {
       const int c = c_hi - lane;
       int level = 0, cb = 0, cbr = 0, cnt = 0;
+      const int pos = pos_nx;
+      pos_nx = scan(imax(c - 64, 0));
       if (c >= 0) {
-        const int pos = scan(c);
         const int row = pos >> bwl, col = pos & (n - 1);
 #define LVA(r_, c_) (((r_) < n && (c_) < n) ? iabs((int)S->lv[((r_) << bwl) + (c_)]) : 0)
         const int a01 = LVA(row, col + 1), a10 = LVA(row + 1, col), a11 = LVA(row + 1, col + 1), a02 = LVA(row, col + 2), a20 = LVA(row + 2, col);
@@ -327,10 +334,13 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       }
     }
     // ---- signs / golomb in forward scan order (all literals except the DC sign)
+    int fpos_nx = scan(imin(lane, eob - 1));
     for (int c0 = 0; c0 < eob; c0 += 64) {
       const int c = c0 + lane;
       int v = 0;
-      if (c < eob) v = S->lv[scan(c)];
+      const int fpos = fpos_nx;
+      fpos_nx = scan(imin(c + 64, eob - 1));
+      if (c < eob) v = S->lv[fpos];
       const int level = iabs(v);
       { int lsum; (void)wave_excl_scan(level, lane, &lsum); cul += lsum; }   // (the DPP prefix sum's total)
       if (c0 == 0) {
@@ -731,8 +741,8 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
             // intra_block_mode_info (§5.11.22): y_mode by block-size group
             sym_wide<1>(y, lane, adapt, ymode, CL::IF_Y_MODE + (bsl <= 3 ? 1 : (bsl == 4 ? 2 : 3)) * 14, 13);
           } else {
-            const int am = uni(c_intra_mode_ctx[avail_u ? INFO(b8x, b8y - 1).ymode : 0]);
-            const int lm = uni(c_intra_mode_ctx[avail_l ? INFO(b8x - 1, b8y).ymode : 0]);
+            const int am = intra_mode_ctx(uni(avail_u ? INFO(b8x, b8y - 1).ymode : 0));
+            const int lm = intra_mode_ctx(uni(avail_l ? INFO(b8x - 1, b8y).ymode : 0));
             sym_wide(y, lane, adapt, ymode, CL::KF_Y_MODE + (am * 5 + lm) * 14, 13);
           }
           // chroma: the luma mode at luma's angle delta, or chroma from luma (`angle` bits 4-9 / 10-15: the alphas, not both zero)

@@ -524,7 +524,7 @@ __device__ __forceinline__ T *uniform_p(T *p) {
 template <typename T>
 __device__ __forceinline__ T *uniform_lds_p(T *p) {
   typedef T __attribute__((address_space(3))) *L;
-  return (T *)(L)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)p);
+  return (T *)(L)(unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)p);
 }
 // the quantiser-matrix table (its address is a field of the parameter block): a pointer into global memory
 typedef const Av1miQmEntry __attribute__((address_space(1))) *QmTab;
@@ -1159,7 +1159,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * mh;
         const int v = ((hh2[reg] << 16) + (mid2[reg] << 8) + ll2[reg] + 2048) >> 12;
         uint32_t q, recip;
-        if constexpr (QM) { const Av1miQmEntry e = tab[row * 32]; q = e.q; recip = e.recip; }
+        if constexpr (QM) { q = tab[row * 32].q; recip = tab[row * 32].recip; }
         else if (reg == 0) { const bool dc = (row | col) == 0; q = dc ? (uint32_t)P->dc_q : acq; recip = dc ? P->dc_recip : acr; }
         else { q = acq; recip = acr; }
         const int d0 = row + col;
