@@ -40,6 +40,7 @@ typedef Av1miCdfLayout CL;
 // The coefficient (narrow) rows are 57 % of the CDF set; a regular tile in adaptive mode never
 // touches them here (they adapt per lane in K4), so only the FULL kernel variant holds them in LDS.
 __shared__ uint16_t g_cdf_narrow[CL::INTRA_TOTAL - CL::COEFF_BASE + 64];
+__shared__ uint16_t g_full_list[5 * 64];   // FULL variant: the (row, symbol) pairs of 64 coefficients in coding order
 // inter-frame CDFs and the motion vector candidate list: only the INTER instantiations reference (and allocate) them
 __shared__ uint16_t g_cdf_inter[CL::TOTAL - CL::INTER_BASE + 64];
 struct InterLds {
@@ -318,17 +319,59 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
         }
         y.pos += total;
       } else if (FULL) {
-        // resolved path (static CDFs, or a third size class in an edge tile): walk the items
-        const int top = imin(c_hi, 63);
-        for (int i = 0; i <= top; i++) {
-          const int lv_i = __builtin_amdgcn_readlane(level, i), cb_i = __builtin_amdgcn_readlane(cb, i), cbr_i = __builtin_amdgcn_readlane(cbr, i);
-          if (c_hi - i != eob - 1) sym_narrow_resolved(y, lane, adapt, imin(lv_i, 3), base_off0 + cb_i * 5);
-          if (lv_i > 2) {
-            for (int idx = 0; idx < 4; idx++) {
-              const int k3 = imin(lv_i - 3 - idx * 3, 3);
-              sym_narrow_resolved(y, lane, adapt, k3, br_off0 + cbr_i * 5);
-              if (k3 < 3) break;
+        // Resolved path (static CDFs, or a third size class in an edge tile): the symbols adapt here, one after the other - a few
+        // waves with a long serial chain, which last as long as the regular variant's thousands beside them.  So the chain is kept short:
+        // the batch's (row, symbol) pairs go to an LDS list in coding order, lane-parallel like the slot path above; the serial loop
+        // then takes 64 of them into a register, reads the NEXT pair's CDF row before it writes the current one back (forwarded when both
+        // name the same row), builds the entries in a register and stores the 64 with one instruction.
+        if constexpr (FULL) {
+          int total;
+          const int off = wave_excl_scan(cnt, lane, &total);
+          if (c >= 0) {
+            uint16_t *o = g_full_list + off;
+            if (c != eob - 1) *o++ = (uint16_t)((cb << 2) | imin(level, 3));
+            if (level > 2) {
+              for (int idx = 0; idx < 4; idx++) {
+                const int k3 = imin(level - 3 - idx * 3, 3);
+                *o++ = (uint16_t)(((42 + cbr) << 2) | k3);
+                if (k3 < 3) break;
+              }
             }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+          const int row0 = base_off0 - CL::COEFF_BASE, row1 = br_off0 - CL::COEFF_BASE - 42 * 5;   // g_cdf_narrow offset of row r: r < 42 ? row0 + 5 r : row1 + 5 r
+          const int l5 = lane < 5 ? lane : 4;
+          for (int k0 = 0; k0 < total; k0 += 64) {
+            const int n_k = imin(64, total - k0);
+            const int ents = k0 + lane < total ? (int)g_full_list[k0 + lane] : 0;
+            int e = __builtin_amdgcn_readlane(ents, 0);
+            int roff = ((e >> 2) < 42 ? row0 : row1) + (e >> 2) * 5;
+            int v = g_cdf_narrow[roff + l5];
+            uint32_t outv = 0;
+            for (int k = 0; k < n_k; k++) {
+              const int sy = e & 3;
+              // the next pair and its row (k + 1 == n_k: lane 63's or a stale pair - a valid row either way, and unused)
+              const int e_nx = __builtin_amdgcn_readlane(ents, (k + 1) & 63);
+              const int roff_nx = ((e_nx >> 2) < 42 ? row0 : row1) + (e_nx >> 2) * 5;
+              const int v_nx = g_cdf_narrow[roff_nx + l5];
+              const uint32_t fl = sy > 0 ? (uint32_t)__builtin_amdgcn_readlane(v, sy - 1) : 32768u;
+              const uint32_t fh = (uint32_t)__builtin_amdgcn_readlane(v, sy);
+              int nv = v;
+              if (adapt) {
+                const int cntr = __builtin_amdgcn_readlane(v, 4);
+                const int rate = 5 + (cntr > 15) + (cntr > 31);
+                nv = lane < sy ? v + ((32768 - v) >> rate) : v - (v >> rate);
+                nv = lane == 4 ? cntr + (cntr < 32) : nv;
+                if (lane <= 4) g_cdf_narrow[roff + lane] = (uint16_t)nv;
+              }
+              outv = lane == k ? ENT_RESOLVED(fl >> 6, fh >> 6, 3 - sy) : outv;
+              v = roff_nx == roff ? nv : v_nx;
+              roff = roff_nx; e = e_nx;
+            }
+            if (lane < n_k && y.pos + lane < y.cap) y.out[y.pos + lane] = outv;
+            y.pos += n_k;
           }
         }
       }
