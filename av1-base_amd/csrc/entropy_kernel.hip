@@ -206,6 +206,17 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
 #define a_dc (TI.above_dc[plane] + aoff)
 #define l_lvl S->left_lvl[plane]
 #define l_dc S->left_dc[plane]
+  // the block's levels, 16 bytes (8 levels) per lane and step: requested here, needed only after the block's first symbols (by then
+  // they have arrived - issued where they are copied to LDS the wave waited a memory round trip per transform block); unconditional,
+  // index clamped (a load under a condition is waited for on the spot)
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 lv_pre[2];
+  {
+    const u4 *g128 = reinterpret_cast<const u4 *>(lv_global);
+    const int last = n * n / 8 - 1;
+    lv_pre[0] = g128[imin(lane, last)];
+    lv_pre[1] = g128[imin(lane + 64, last)];
+  }
   int nb_or = 0, dsum = 0;
   if (lane < w4) {
     if (x4 + lane < max_x4) { nb_or |= (a_lvl[x4 + lane] | a_dc[x4 + lane]) ? 1 : 0; int sg = a_dc[x4 + lane]; dsum += sg == 1 ? -1 : (sg == 2 ? 1 : 0); }
@@ -223,11 +234,10 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
   int cul = 0, dc_cat = 0;
   if (eob != 0) {
     {
-      // the block's levels, 16 bytes (8 levels) per lane and step, straight into the LDS copy (same row-major layout)
-      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-      const u4 *g128 = reinterpret_cast<const u4 *>(lv_global);
+      // ... into the LDS copy (same row-major layout)
       u4 *l128 = reinterpret_cast<u4 *>(S->lv);
-      for (int i = lane; i < n * n / 8; i += 64) l128[i] = g128[i];
+      if (lane < n * n / 8) l128[lane] = lv_pre[0];
+      if (lane + 64 < n * n / 8) l128[lane + 64] = lv_pre[1];
       __syncthreads();
     }
     if (plane == 0 && is_inter) {
