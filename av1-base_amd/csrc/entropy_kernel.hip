@@ -1196,6 +1196,7 @@ __global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P,
       for (int j = 0; j < 42; j++) g_rc2.row[k * SLOTS_PER_COMBO + j][lane] = (uint64_t)b[j * 5] | ((uint64_t)b[j * 5 + 1] << 16) | ((uint64_t)b[j * 5 + 2] << 32);
       for (int j = 0; j < 21; j++) g_rc2.row[k * SLOTS_PER_COMBO + 42 + j][lane] = (uint64_t)r[j * 5] | ((uint64_t)r[j * 5 + 1] << 16) | ((uint64_t)r[j * 5 + 2] << 32);
     }
+    g_rc2.row[RC_DUMMY][lane] = 0;
   }
   // ---- coder state
   uint32_t low = 0, rng = 0x8000;
@@ -1249,18 +1250,18 @@ __global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P,
         uint32_t ev[RC_BATCH];
 #pragma unroll
         for (int j = 0; j < RC_BATCH; j += 4) { ev[j] = qc[j / 4].x; ev[j + 1] = qc[j / 4].y; ev[j + 2] = qc[j / 4].z; ev[j + 3] = qc[j / 4].w; }
-        const int i0 = k * RC_BATCH;
-        auto slot_of = [&](int idx, uint32_t e) { return (i0 + idx < count && !(e & 0x80000000u)) ? (int)((e >> 2) & 0x1FF) : MAX_COMBOS * SLOTS_PER_COMBO; };
-        int slot = slot_of(0, ev[0]);
+        // (no test against the tile's count here: what lies beyond it may adapt rows - the tile is over - and the coder replaces it)
+        auto slot_of = [&](uint32_t e) { const uint32_t t = e >> 2; return (int)(t < (uint32_t)RC_DUMMY ? t : (uint32_t)RC_DUMMY); };
+        int slot = slot_of(ev[0]);
         uint64_t rw = g_rc2.row[slot][lane];
 #pragma unroll
         for (int jj = 0; jj < RC_BATCH; jj++) {
           uint32_t ent = ev[jj];
-          const bool nar = i0 + jj < count && !(ent & 0x80000000u);
+          const bool nar = !(ent & 0x80000000u);
           const int s = ent & 3;
           int slot_nx = 0;
           uint64_t rw_nx = 0;
-          if (jj + 1 < RC_BATCH) { slot_nx = slot_of(jj + 1, ev[jj + 1]); rw_nx = g_rc2.row[slot_nx][lane]; }
+          if (jj + 1 < RC_BATCH) { slot_nx = slot_of(ev[jj + 1]); rw_nx = g_rc2.row[slot_nx][lane]; }
           const uint32_t c01 = (uint32_t)rw, c2n = (uint32_t)(rw >> 32);  // {c0, c1}, {c2, counter}
           // fl = icdf[s-1] (32768 for s == 0), fh = icdf[s] (0 for s == 3): one 64-bit shift each of {32768, c0, c1, c2} / {c0, c1, c2, 0}
           const uint64_t vals = ((uint64_t)(c2n & 0xFFFFu) << 32) | c01;
@@ -1273,14 +1274,15 @@ __global__ void __launch_bounds__(128) rangecode2_tiles_kernel(Av1miDevParams P,
             // and on {c2, counter} (the counter half is replaced afterwards)
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
             const uint32_t cn = c2n >> 16;
-            const unsigned short rate = (unsigned short)(5 + (cn > 15) + (cn > 31));
+            const unsigned short rate = (unsigned short)(5 + (cn >> 4));   // counter <= 32: 5 + (cn > 15) + (cn > 31)
             const us2 rv = { rate, rate }, top = { 0x8000, 0x8000 };
             const us2 a = __builtin_bit_cast(us2, c01), b = __builtin_bit_cast(us2, c2n);
             const uint32_t up01 = __builtin_bit_cast(uint32_t, (us2)(a + ((top - a) >> rv))), dn01 = __builtin_bit_cast(uint32_t, (us2)(a - (a >> rv)));
             const uint32_t up2 = __builtin_bit_cast(uint32_t, (us2)(b + ((top - b) >> rv))), dn2 = __builtin_bit_cast(uint32_t, (us2)(b - (b >> rv)));
             const uint32_t m01 = s >= 2 ? 0xFFFFFFFFu : (s ? 0xFFFFu : 0u);   // halves with index < s
             const uint32_t n01 = (up01 & m01) | (dn01 & ~m01);
-            const uint32_t n2 = ((s > 2 ? up2 : dn2) & 0xFFFFu) | ((cn + (cn < 32)) << 16);
+            const uint32_t cn1 = cn + 1 < 32u ? cn + 1 : 32u;
+            const uint32_t n2 = ((s > 2 ? up2 : dn2) & 0xFFFFu) | (cn1 << 16);
             nrow = (uint64_t)n01 | ((uint64_t)n2 << 32);
             g_rc2.row[slot][lane] = nrow;
           }
@@ -1408,22 +1410,23 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   if (!(phase & 2)) return hipGetLastError();
   // Two forms of the range coder.  A wave of either wants a SIMD to itself (two workgroups' waves on one SIMD: twice as long,
   // measured), so a CU runs four waves at full speed: ONE workgroup of the four-stage form (~100 ns per entry of the longest tile) or
-  // TWO of the two-stage form (~160 ns).  Measured range-coder times, two-stage / four-stage form, ms (tools/rc_probe.sh):
-  //   1080p all-key x 30 (239 workgroups) 0.88 / 0.56     x 60 (478) 0.85 / 1.06     x 120 (956) 1.86 / 1.69     x 60 at CQ 8 2.32 / 2.62
-  //   1080p IPPP x 60 (470)  0.76 / 0.58    at CQ 8  2.05 / 2.12    production point  1.46 / 1.43    8K IPPP x 16 (510)  2.0 / 1.6
-  //   4K x 30 (957) all-key  1.75 / 1.59    IPPP  0.96 / 0.77
-  // Up to 256 workgroups the four-stage form runs them all at once and wins; up to 512 the two-stage form still has everything
-  // resident while the four-stage form runs two rounds - that costs more than it gains where every frame has its long tiles (all-key
-  // chunks) and less where few tiles are long (chunks with inter frames); beyond 512 both run in rounds and the faster workgroup
-  // wins again.  AV1MI_RC_STAGES = 2 / 4 forces a form.
+  // TWO of the two-stage form (~140 ns).  Measured range-coder times, two-stage / four-stage form, ms (tools/rc_probe.sh):
+  //   1080p all-key x 30 (239 workgroups) 0.79 / 0.55     x 60 (478) 0.75 / 1.04     x 120 (956) 1.78 / 1.64     x 60 at CQ 8 2.57 / 2.88
+  //   1080p IPPP x 60 (470)  0.68 / 0.53    at CQ 8  1.76 / 2.27    production point (CQ 8)  1.26 / 1.46    8K IPPP x 16 (510)  2.0 / 1.6
+  //   4K x 30 (957) all-key  1.68 / 1.58    IPPP  0.84 / 0.74
+  // Up to 256 workgroups the four-stage form runs them all at once and wins; beyond 512 both run in rounds and the faster workgroup
+  // wins again.  Between the two the two-stage form still has everything resident while the four-stage form runs two rounds of
+  // length-sorted workgroups, whose 64 equally long tiles cost more per entry (64 cache lines per stream load): that pays only where
+  // few tiles are long - chunks with inter frames at a coarse quantiser (the P frames' tiles are short next to the key frame's).  The
+  // quantiser index stands in for "few long tiles" here (the lengths themselves are on the device): >= 64.  AV1MI_RC_STAGES = 2 / 4
+  // forces a form.
   // Order of the tiles: while all workgroups run at once the kernel lasts as long as its longest tile and the natural order is best
-  // (a workgroup of 64 long tiles is slower per symbol than one long tile among short ones: 64 cache lines per store / stream
-  // load - measured 1.1 -> 2.1 ms).  In rounds what counts is the sum over a CU's workgroups of their longest tile: tiles sorted by
-  // decreasing length (4K, 30 frames: 3.9 -> 2.9 ms).
+  // (a workgroup of 64 long tiles is slower per symbol than one long tile among short ones - measured 1.1 -> 2.1 ms).  In rounds
+  // what counts is the sum over a CU's workgroups of their longest tile: tiles sorted by decreasing length (4K, 30 frames: 3.9 -> 2.9 ms).
   const char *const stages_str = getenv("AV1MI_RC_STAGES");   // (read per launch: the parity tests run both forms in one process)
   const int stages_env = stages_str ? atoi(stages_str) : 0;
   const int n_groups = (n_tiles + 63) / 64;
-  const int stages = stages_env == 2 || stages_env == 4 ? stages_env : (n_groups <= 256 || n_groups > 512 || has_inter ? 4 : 2);
+  const int stages = stages_env == 2 || stages_env == 4 ? stages_env : (n_groups <= 256 || n_groups > 512 || (has_inter && P->base_q_idx >= 64) ? 4 : 2);
   const bool sorted = n_groups > (stages == 4 ? 256 : 512);
   if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len + tile0, tile_order + tile0);
   if (stages == 4)
