@@ -1427,7 +1427,8 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   const int stages_env = stages_str ? atoi(stages_str) : 0;
   const int n_groups = (n_tiles + 63) / 64;
   const int stages = stages_env == 2 || stages_env == 4 ? stages_env : (n_groups <= 256 || n_groups > 512 || (has_inter && P->base_q_idx >= 64) ? 4 : 2);
-  const bool sorted = n_groups > (stages == 4 ? 256 : 512);
+  bool sorted = n_groups > (stages == 4 ? 256 : 512);
+  if (const char *so = getenv("AV1MI_RC_SORT")) sorted = atoi(so) != 0;   // experiment knob: force the tile order on / off
   if (sorted) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, stream_len + tile0, tile_order + tile0);
   if (stages == 4)
     hipLaunchKernelGGL(rangecode4_tiles_kernel, dim3(n_groups), dim3(256), 0, stream, *P, n_tiles, cdf_init, streams, stream_len,
