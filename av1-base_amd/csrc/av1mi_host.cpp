@@ -49,7 +49,8 @@ hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16_t *cdf_ini
                                 uint32_t *streams, uint32_t *stream_len, uint32_t *tile_combos, uint8_t *slots, uint32_t *tile_bytes,
                                 const uint8_t *lr_choice, uint32_t *tile_order, int frame0, int count, int phase,
                                 hipStream_t s, hipEvent_t mid, hipStream_t aux, hipEvent_t fork, hipEvent_t join);
-hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, const uint16_t *dirtab, hipStream_t s);
+hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, const uint16_t *dirtab, const void *src,
+                             unsigned long long *sse, hipStream_t s);
 hipError_t av1mi_launch_cdef_dir(const Av1miDevParams *P, const void *rec, const Av1miBlkInfo *blk, uint16_t *dirtab, hipStream_t s);
 hipError_t av1mi_launch_sse(const Av1miDevParams *P, const void *a, const void *b, unsigned long long *sse, hipStream_t s);
 hipError_t av1mi_launch_pack(const Av1miDevParams *P, const uint8_t *slots, const uint32_t *tile_bytes, uint32_t *tile_off,
@@ -1006,7 +1007,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
     // the unit decisions are part of the tile syntax: CDEF and restoration must precede entropy coding
     HIPCHK(c, launch_recon(&P, c->d_params, d_src, c->d_rec, c->d_levels, c->d_blk, nullptr, nullptr, P.part_map, s));
     if (P.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P, c->d_rec, c->d_blk, s));
-    HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, nullptr, s));
+    HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_cd, c->d_blk, nullptr, nullptr, nullptr, s));
     HIPCHK(c, av1mi_launch_lr(&P, c->d_rec, c->d_cd, d_src, c->d_fin, c->d_lrc, c->d_lrsse, 1, s));
   } else if (!inter_chunk) {
     // All-key-frame chunk: the frames are independent, so the chunk CAN run as a software pipeline over groups of frames
@@ -1122,7 +1123,7 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
       if (!av1mi_frame_is_inter(P, (int)f)) { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level[i]; }
       else { for (int i = 0; i < 4; i++) P1.lf_level[i] = P.lf_level_inter[i]; }
       if (P1.lf_level[0]) HIPCHK(c, av1mi_launch_deblock(&P1, recf, blkf, s));
-      HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, nullptr, s));
+      HIPCHK(c, av1mi_launch_cdef(&P1, recf, cdf_, blkf, nullptr, nullptr, nullptr, s));
       if (lr) {
         const int upf = ((P.true_h + 32) / 64 > 0 ? (P.true_h + 32) / 64 : 1) * ((P.true_w + 32) / 64 > 0 ? (P.true_w + 32) / 64 : 1);
         HIPCHK(c, av1mi_launch_lr(&P1, recf, cdf_, srcf, finf, c->d_lrc + (size_t)f * upf, c->d_lrsse + (size_t)f * upf * 8, 0, s));
@@ -1172,8 +1173,12 @@ static int encode_chunk_once(av1mi_ctx *c, const av1mi_params *params, const voi
   HIPCHK(c, hipStreamWaitEvent(s2, c->ev[7], 0));  // ev[7]: recorded between symbolize and range-code (measured: starting CDEF
                                                    // right after the reconstruction, beside symbolize, costs 8 % overall)
   HIPCHK(c, hipEventRecord(c->ev[8], s2));
-  if (!inter_chunk && !lr) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, split_cdef ? c->d_cdefdir : nullptr, s2));
-  HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s2));
+  // (an all-key chunk's CDEF is one launch over the chunk: it sums the squared error itself - a second pass over the frames, 0.19 ms at
+  // 1080p x 60, would end after the range coder CDEF runs beside; a one-frame chunk's CDEF runs in strips without the sum)
+  const bool sse_in_cdef = !inter_chunk && !lr && n_frames > 1 && !getenv("AV1MI_CDEF_STRIPS");
+  if (!inter_chunk && !lr) HIPCHK(c, av1mi_launch_cdef(&P, c->d_rec, c->d_fin, c->d_blk, split_cdef ? c->d_cdefdir : nullptr, sse_in_cdef ? d_src : nullptr,
+                                                       sse_in_cdef ? c->d_sse : nullptr, s2));
+  if (!sse_in_cdef) HIPCHK(c, av1mi_launch_sse(&P, d_src, c->d_fin, c->d_sse, s2));
   HIPCHK(c, hipEventRecord(c->ev[9], s2));
   // packing and the download of the bitstream need nothing from the second stream: they run beside the tail of CDEF / SSE;
   // the join comes before the reconstruction and the SSE are read (below)

@@ -75,7 +75,7 @@ __device__ __forceinline__ void st_px(PIX *pl, int idx, int v) {
 }
 template <typename PIX, bool EDGE, bool SEC, int BR>
 __device__ __forceinline__ void cdef_rows(const PIX *pl, PIX *out, int stride, int w, int h, int gx, int gy0, int pri, int sec, int pri_shift,
-                                          int sec_shift, int dir, int coeff_shift) {
+                                          int sec_shift, int dir, int coeff_shift, const PIX *srcp = nullptr, unsigned *acc = nullptr) {
   int oy[2], ox[2], sy[2][2], sx[2][2];
   cdef_dir_offsets(dir, oy[0], ox[0], oy[1], ox[1]);
   if (SEC) {
@@ -138,19 +138,26 @@ __device__ __forceinline__ void cdef_rows(const PIX *pl, PIX *out, int stride, i
     }
     int v = x + ((8 + sum - (sum < 0)) >> 4);
     v = v < mn ? mn : (v > mx ? mx : v);
-    if (!EDGE || gy0 + r < h) st_px(out, (gy0 + r) * stride + gx, v);
+    if (!EDGE || gy0 + r < h) {
+      st_px(out, (gy0 + r) * stride + gx, v);
+      // (chunk-wide launches: the squared error against the source is summed here - sse_kernel's second pass over the frames would
+      // end after the range coder that CDEF runs beside)
+      if (acc) { const int d = v - ld_px(srcp, (gy0 + r) * stride + gx); *acc += (unsigned)(d * d); }
+    }
   }
 }
 
-template <typename PIX, bool EDGE, bool SEC>
+template <typename PIX, bool EDGE, bool SEC, bool SSEV>
 __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PIX *fr, PIX *fo, int x0, int y0, int w, int h, int lane,
-                                               int row0, int row1 /* luma rows [row0, row1) of the superblock, multiples of 8 */) {
+                                               int row0, int row1 /* luma rows [row0, row1) of the superblock, multiples of 8 */,
+                                               const PIX *sf /* SSEV: the source frame */, unsigned long long *sse_f /* SSEV: the frame's three sums */) {
   const int coeff_shift = P.bit_depth - 8;
   // ---- luma: lane = column, batches of the 8 rows of a block row (row-contiguous HBM loads and stores)
   {
     const int sec = (P.cdef_y_sec == 3 ? 4 : P.cdef_y_sec) << coeff_shift;
     const int damping = P.cdef_damping + coeff_shift;
     const int sec_shift = damp_shift(sec, damping);
+    unsigned acc = 0, *const accp = SSEV ? &acc : nullptr;
     if (lane < w) {
       for (int r = row0; r < (row1 < h ? row1 : h); r += 8) {
         const int b = (r >> 3) * 8 + (lane >> 3);
@@ -159,15 +166,20 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
         const int dir = P.cdef_y_pri == 0 ? 0 : g_cdef.dir[b];
         // batches: 8 rows with primary taps only in interior superblocks; 4 rows with the secondary taps or the frame-edge tests
         if (SEC && sec) {
-          cdef_rows<PIX, EDGE, true, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, sec_b, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
-          cdef_rows<PIX, EDGE, true, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r + 4, pri, sec_b, damp_shift(pri, damping), sec_shift, dir, coeff_shift);
+          cdef_rows<PIX, EDGE, true, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, sec_b, damp_shift(pri, damping), sec_shift, dir, coeff_shift, sf, accp);
+          cdef_rows<PIX, EDGE, true, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r + 4, pri, sec_b, damp_shift(pri, damping), sec_shift, dir, coeff_shift, sf, accp);
         } else if (EDGE) {
-          cdef_rows<PIX, true, false, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift);
-          cdef_rows<PIX, true, false, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r + 4, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift);
+          cdef_rows<PIX, true, false, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift, sf, accp);
+          cdef_rows<PIX, true, false, 4>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r + 4, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift, sf, accp);
         } else {
-          cdef_rows<PIX, false, false, 8>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift);
+          cdef_rows<PIX, false, false, 8>(fr, fo, P.stride_y, P.width, P.height, x0 + lane, y0 + r, pri, 0, damp_shift(pri, damping), 0, dir, coeff_shift, sf, accp);
         }
       }
+    }
+    if constexpr (SSEV) {
+      unsigned long long t = acc;
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (lane == 0 && t) atomicAdd(&sse_f[0], t);
     }
   }
   // ---- chroma: lanes 0-31 = columns of U, lanes 32-63 = columns of V; batches of the 4 rows of a block row
@@ -180,15 +192,22 @@ __device__ __forceinline__ void cdef_filter_sb(const Av1miDevParams &P, const PI
     const int damping = P.cdef_damping + coeff_shift - 1;
     const int pri_shift = damp_shift(pri0, damping), sec_shift = damp_shift(sec0, damping);
     const int wc = w >> 1, hc = h >> 1;
+    const PIX *sp = SSEV ? sf + (pl ? P.plane_off_v : P.plane_off_u) : nullptr;
+    unsigned acc = 0, *const accp = SSEV ? &acc : nullptr;
     if (col < wc) {
       for (int r = row0 >> 1; r < ((row1 >> 1) < hc ? (row1 >> 1) : hc); r += 4) {
         const int b = (r >> 2) * 8 + (col >> 2);
         const bool on = g_cdef.on[b] != 0;
         const int pri = on ? pri0 : 0, sec = on ? sec0 : 0;
         const int dir = pri0 == 0 ? 0 : (int)g_cdef.dir[b];
-        if (SEC && sec0) cdef_rows<PIX, EDGE, true, 4>(cp, op, P.stride_c, P.width >> 1, P.height >> 1, (x0 >> 1) + col, (y0 >> 1) + r, pri, sec, pri_shift, sec_shift, dir, coeff_shift);
-        else cdef_rows<PIX, EDGE, false, 4>(cp, op, P.stride_c, P.width >> 1, P.height >> 1, (x0 >> 1) + col, (y0 >> 1) + r, pri, 0, pri_shift, 0, dir, coeff_shift);
+        if (SEC && sec0) cdef_rows<PIX, EDGE, true, 4>(cp, op, P.stride_c, P.width >> 1, P.height >> 1, (x0 >> 1) + col, (y0 >> 1) + r, pri, sec, pri_shift, sec_shift, dir, coeff_shift, sp, accp);
+        else cdef_rows<PIX, EDGE, false, 4>(cp, op, P.stride_c, P.width >> 1, P.height >> 1, (x0 >> 1) + col, (y0 >> 1) + r, pri, 0, pri_shift, 0, dir, coeff_shift, sp, accp);
       }
+    }
+    if constexpr (SSEV) {   // the two halves of the wave: U, V
+      unsigned long long t = acc;
+      for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if ((lane & 31) == 0 && t) atomicAdd(&sse_f[1 + pl], t);
     }
   }
 }
@@ -334,9 +353,11 @@ __global__ void __launch_bounds__(64) cdef_dir_kernel(Av1miDevParams P, const PI
 // (one-frame launches of inter chunks: 4x the waves and a quarter of the serial work per wave: latency).
 // TAB: directions and adjusted strengths come from cdef_dir_kernel's table instead of being searched here.
 // SEC: some secondary strength is non-zero (the default strengths have none: the instantiation without carries no secondary-tap code).
-template <typename PIX, int NS, bool TAB, bool SEC>
+// SSEV: the squared error of the output against the source `src` is added to sse[frame][plane] (chunk-wide launches only).
+template <typename PIX, int NS, bool TAB, bool SEC, bool SSEV = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) cdef_sb_kernel(Av1miDevParams P, const PIX *__restrict__ rec, PIX *__restrict__ fin,
-                                                    const Av1miBlkInfo *__restrict__ blk, const uint16_t *__restrict__ dirtab) {
+                                                    const Av1miBlkInfo *__restrict__ blk, const uint16_t *__restrict__ dirtab,
+                                                    const PIX *__restrict__ src = nullptr, unsigned long long *__restrict__ sse = nullptr) {
   const int sbs_per_frame = P.sb_rows * P.sb_cols;
   const int strip = NS == 1 ? 0 : (int)(blockIdx.x % NS);
   const int item = blockIdx.x / NS;
@@ -385,8 +406,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // taps reach 2 samples beyond the superblock (1 in chroma): interior superblocks need no tests
   const bool edge = x0 < 2 || y0 < 2 || x0 + 66 > P.width || y0 + 66 > P.height;
   const int row0 = NS == 1 ? 0 : strip * 16, row1 = NS == 1 ? 64 : strip * 16 + 16;
-  if (edge) cdef_filter_sb<PIX, true, SEC>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
-  else cdef_filter_sb<PIX, false, SEC>(P, fr, fo, x0, y0, w, h, lane, row0, row1);
+  const PIX *sf = SSEV ? src + (size_t)f * P.frame_samples : nullptr;
+  unsigned long long *sse_f = SSEV ? sse + (size_t)f * 3 : nullptr;
+  if (edge) cdef_filter_sb<PIX, true, SEC, SSEV>(P, fr, fo, x0, y0, w, h, lane, row0, row1, sf, sse_f);
+  else cdef_filter_sb<PIX, false, SEC, SSEV>(P, fr, fo, x0, y0, w, h, lane, row0, row1, sf, sse_f);
 }
 
 // ------------------------------------------------------------------------------ SSE (PSNR)
@@ -543,16 +566,20 @@ __global__ void __launch_bounds__(64) pack_tiles_kernel(Av1miDevParams P, const 
 
 // dirtab == nullptr: one kernel (direction search + filter); else the filter reads cdef_dir_kernel's table (av1mi_launch_cdef_dir before)
 extern "C" hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec, void *fin, const Av1miBlkInfo *blk, const uint16_t *dirtab,
+                                        const void *src, unsigned long long *sse /* both or neither: the chunk-wide launch also sums the squared error */,
                                         hipStream_t stream) {
   const int grid = P->n_frames * P->sb_rows * P->sb_cols;
   const bool strips = P->n_frames == 1;  // a one-frame launch sits on an inter chunk's serial chain
   static const bool exp_strips = getenv("AV1MI_CDEF_STRIPS") != nullptr;   // experiment: 16-row strips for chunk-wide launches too
   const bool sec = P->cdef_y_sec != 0 || P->cdef_uv_sec != 0;
+  const bool sse_here = src && sse && !strips && !exp_strips;
 #define CDEF_LAUNCH2(PIXT, SECV)                                                                                                           \
   do {                                                                                                                                     \
     if (exp_strips && dirtab) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 4, true, SECV>), dim3(grid * 4), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
     else if (strips || exp_strips) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 4, false, SECV>), dim3(grid * 4), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
+    else if (dirtab && sse_here) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, true, SECV, true>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab, (const PIXT *)src, sse); \
     else if (dirtab) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, true, SECV>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
+    else if (sse_here) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, false, SECV, true>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab, (const PIXT *)src, sse); \
     else hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, false, SECV>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
   } while (0)
 #define CDEF_LAUNCH(PIXT) do { if (sec) CDEF_LAUNCH2(PIXT, true); else CDEF_LAUNCH2(PIXT, false); } while (0)

@@ -604,9 +604,25 @@ __device__ __forceinline__ bool sb_unsplit(const Av1miDevParams &P, int f, int s
   return P.max_bs_log2 >= 6 ? !(m & 1u) : (P.max_bs_log2 == 5 ? !(m & 0x1Eu) : !(m & 0x1FFFE0u));
 }
 
-// FULL = false: regular tiles (superblock entirely inside the frame) in adaptive mode - exactly two
-// (tx size, plane type) classes, no narrow rows in LDS (10.4 KB -> ~4 waves per SIMD).
-// FULL = true: frame-edge tiles and static-CDF mode.  Each variant skips the other's tiles.
+// ... and does the frame edge leave it alone?  A node of the leaf size whose origin lies inside the frame must not be forced to split
+// (has_rows / has_cols of av1mi_node_split: a leaf may overhang the edge by less than half its size - the bottom superblock row of a
+// 1080-row frame, 56 rows, keeps its four 32x32 leaves; a row of 40 would not).
+__device__ __forceinline__ bool sb_uniform(const Av1miDevParams &P, int f, int sbr, int sbc) {
+  if (!sb_unsplit(P, f, sbr, sbc)) return false;
+  const int L = P.max_bs_log2, n = 1 << L;
+  if (L <= 3) return true;
+  for (int oy = 0; oy < 64; oy += n)
+    for (int ox = 0; ox < 64; ox += n) {
+      const int x = sbc * 64 + ox, yy = sbr * 64 + oy;
+      if (x < P.width && yy < P.height && (yy + (n >> 1) >= P.height || x + (n >> 1) >= P.width)) return false;
+    }
+  return true;
+}
+
+// FULL = false: regular tiles in adaptive mode - every leaf of the tile has one size, i.e. exactly two (tx size, plane type)
+// classes, no narrow rows in LDS (10.4 KB -> ~4 waves per SIMD).
+// FULL = true: tiles that mix sizes (content-driven partition, forced splits at the frame edge) and static-CDF mode.  Each variant
+// skips the other's tiles.
 template <bool FULL, bool INTER, int TSB>
 __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, const uint16_t *__restrict__ cdf_init,
                                                            const int16_t *__restrict__ levels, const Av1miBlkInfo *__restrict__ blk,
@@ -620,9 +636,12 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   const int tr = tile / P.tile_cols, tc = tile % P.tile_cols;
   const int lane = threadIdx.x;
   {
-    bool regular = !P.disable_cdf_update && (tc + 1) * 64 * TSB <= P.width && (tr + 1) * 64 * TSB <= P.height;
+    bool regular = !P.disable_cdf_update;
     if (regular)   // (a tile whose superblocks mix block sizes holds more than two classes: the full variant's)
-      for (int si = 0; si < TSB * TSB; si++) regular = regular && sb_unsplit(P, f, tr * TSB + si / TSB, tc * TSB + si % TSB);
+      for (int si = 0; si < TSB * TSB; si++) {
+        const int sbr = tr * TSB + si / TSB, sbc = tc * TSB + si % TSB;
+        if (sbr < P.sb_rows && sbc < P.sb_cols) regular = regular && sb_uniform(P, f, sbr, sbc);
+      }
     if (regular == FULL) return;
   }
   for (int i = lane; i < CL::COEFF_BASE; i += 64) S->cdf[i] = cdf_init[i];
@@ -1380,7 +1399,7 @@ extern "C" hipError_t av1mi_launch_entropy(const Av1miDevParams *P, const uint16
   const int n_tiles = count * tpf, tile0 = frame0 * tpf;
   bool has_inter = false, has_key = false;
   for (int f = frame0; f < frame0 + count; f++) { if (av1mi_frame_is_inter(*P, f)) has_inter = true; else has_key = true; }
-  // The two variants touch disjoint tiles.  The FULL one has few working waves (1080p: the bottom tile row, 30 of 510 tiles per frame)
+  // The two variants touch disjoint tiles.  The FULL one has few working waves (frame-edge tiles whose leaves the edge forces smaller)
   // with a long serial chain each - 0.14 ms per 60-frame chunk when it ran after the regular one; on a stream of its own it runs
   // beside it.
   hipStream_t fs = stream;
