@@ -349,8 +349,8 @@ __global__ void __launch_bounds__(64) cdef_dir_kernel(Av1miDevParams P, const PI
   dirtab[(size_t)blockIdx.x * 64 + lane] = (uint16_t)((cdef_adjusted_pri(P.cdef_y_pri, var, coeff_shift) << 3) | ydir);
 }
 
-// NS = 1: one wave per superblock (chunk-wide launches: throughput).  NS = 4: one wave per 16-row strip of a superblock
-// (one-frame launches of inter chunks: 4x the waves and a quarter of the serial work per wave: latency).
+// NS = 1: one wave per superblock (chunk-wide launches: throughput).  NS = 4 / 8: one wave per 16- / 8-row strip of a superblock
+// (one-frame launches of inter chunks: NS x the waves and 1 / NS of the filter work per wave: latency).
 // TAB: directions and adjusted strengths come from cdef_dir_kernel's table instead of being searched here.
 // SEC: some secondary strength is non-zero (the default strengths have none: the instantiation without carries no secondary-tap code).
 // SSEV: the squared error of the output against the source `src` is added to sse[frame][plane] (chunk-wide launches only).
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // cdef_idx of the superblock is coded (== 0) iff some block in it is not skipped (§5.11.56)
   const bool sb_on = __ballot(inside && !skip) != 0ull;
   const bool do_filter = P.enable_cdef && sb_on && inside && !skip;
-  const bool mine = NS == 1 || (b8r >> 1) == strip;   // this wave decides (and filters) only the blocks of its strip
+  const bool mine = NS == 1 || b8r / (8 / NS) == strip;   // this wave decides (and filters) only the blocks of its strip
   {
     int ydir = 0, pri = 0;
     if constexpr (TAB) {
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   __syncthreads();
   // taps reach 2 samples beyond the superblock (1 in chroma): interior superblocks need no tests
   const bool edge = x0 < 2 || y0 < 2 || x0 + 66 > P.width || y0 + 66 > P.height;
-  const int row0 = NS == 1 ? 0 : strip * 16, row1 = NS == 1 ? 64 : strip * 16 + 16;
+  const int row0 = NS == 1 ? 0 : strip * (64 / NS), row1 = NS == 1 ? 64 : (strip + 1) * (64 / NS);
   const PIX *sf = SSEV ? src + (size_t)f * P.frame_samples : nullptr;
   unsigned long long *sse_f = SSEV ? sse + (size_t)f * 3 : nullptr;
   if (edge) cdef_filter_sb<PIX, true, SEC, SSEV>(P, fr, fo, x0, y0, w, h, lane, row0, row1, sf, sse_f);
@@ -573,9 +573,13 @@ extern "C" hipError_t av1mi_launch_cdef(const Av1miDevParams *P, const void *rec
   static const bool exp_strips = getenv("AV1MI_CDEF_STRIPS") != nullptr;   // experiment: 16-row strips for chunk-wide launches too
   const bool sec = P->cdef_y_sec != 0 || P->cdef_uv_sec != 0;
   const bool sse_here = src && sse && !strips && !exp_strips;
+  // one-frame launches: 8-row strips (4 080 waves at 1080p, still one round of the chip) - 16-row strips were 2.5 us per frame slower
+  // (AV1MI_CDEF_NS4 brings them back: same-box A/B of the chain)
+  static const bool ns8 = getenv("AV1MI_CDEF_NS4") == nullptr;
 #define CDEF_LAUNCH2(PIXT, SECV)                                                                                                           \
   do {                                                                                                                                     \
     if (exp_strips && dirtab) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 4, true, SECV>), dim3(grid * 4), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
+    else if (strips && ns8) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 8, false, SECV>), dim3(grid * 8), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
     else if (strips || exp_strips) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 4, false, SECV>), dim3(grid * 4), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
     else if (dirtab && sse_here) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, true, SECV, true>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab, (const PIXT *)src, sse); \
     else if (dirtab) hipLaunchKernelGGL((cdef_sb_kernel<PIXT, 1, true, SECV>), dim3(grid), dim3(64), 0, stream, *P, (const PIXT *)rec, (PIXT *)fin, blk, dirtab); \
