@@ -638,10 +638,19 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         typedef u4 u4_any __attribute__((aligned(2)));
         const PIX *rp = static_cast<const PIX *>(ii.ref) + poff;
+        // (every load of the copy before its first LDS store - in one loop the compiler keeps source order, load -> wait -> store ->
+        // load ...: a memory round trip per piece; unconditional, the index clamped: a load under a condition is waited for on the spot)
+        constexpr int CNT = (N * CPR + G - 1) / G;
+        u4 pv[CNT];
 #pragma unroll
-        for (int q = sl; q < N * CPR; q += G) {
-          const int r = q / CPR, c8 = q - r * CPR;
-          *reinterpret_cast<u4 *>(&S->blkpix[po + r * N + 8 * c8]) = *reinterpret_cast<const u4_any *>(rp + (size_t)(iy + r) * gs + ix + 8 * c8);
+        for (int k = 0; k < CNT; k++) {
+          const int q = sl + k * G < N * CPR ? sl + k * G : 0, r = q / CPR, c8 = q - r * CPR;
+          pv[k] = *reinterpret_cast<const u4_any *>(rp + (size_t)(iy + r) * gs + ix + 8 * c8);
+        }
+#pragma unroll
+        for (int k = 0; k < CNT; k++) {
+          const int q = sl + k * G, r = q / CPR, c8 = q - r * CPR;
+          if (q < N * CPR) *reinterpret_cast<u4 *>(&S->blkpix[po + r * N + 8 * c8]) = pv[k];
         }
         mc_in_lds = true;
       }
@@ -671,11 +680,17 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       if (wide) {
         constexpr int CPR = N / 8;   // 16-byte pieces per row
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        constexpr int CNT = (N * CPR + G - 1) / G;   // (all loads first: see the motion-compensated copy above)
+        u4 sv[CNT];
 #pragma unroll
-        for (int q = sl; q < N * CPR; q += G) {
-          const int r = q / CPR, c8 = q - r * CPR;
-          const u4 v = *reinterpret_cast<const u4 *>(pl + (size_t)(gy + r) * gs + gx + 8 * c8);
-          *reinterpret_cast<u4 *>(&S->srcblk[po + r * N + 8 * c8]) = v;
+        for (int k = 0; k < CNT; k++) {
+          const int q = sl + k * G < N * CPR ? sl + k * G : 0, r = q / CPR, c8 = q - r * CPR;
+          sv[k] = *reinterpret_cast<const u4 *>(pl + (size_t)(gy + r) * gs + gx + 8 * c8);
+        }
+#pragma unroll
+        for (int k = 0; k < CNT; k++) {
+          const int q = sl + k * G, r = q / CPR, c8 = q - r * CPR;
+          if (q < N * CPR) *reinterpret_cast<u4 *>(&S->srcblk[po + r * N + 8 * c8]) = sv[k];
         }
       }
     }
