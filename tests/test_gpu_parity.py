@@ -152,6 +152,31 @@ def test_full_size_properties_1080p(av1mi, ctx, oracle, monkeypatch):
     assert 33.0 < rep.psnr[0] < 37.0
 
 
+def test_range_coder_forms_and_tile_orders_in_rounds(av1mi, ctx, oracle, monkeypatch):
+    """More range-coder workgroups than CUs (1080p x 34 all-key frames = 271 groups of 64 tiles): the four-stage form then runs in rounds
+    over tiles sorted by length (tile_order_kernel), the two-stage form has everything resident - and either form in either order
+    must give the bytes of the default choice; the first frame is checked against the oracle."""
+    w, h, bd, n = 1920, 1080, 8, 34
+    f0 = oracle.synthclip_frame(w, h, bd, seed=77, t=0)
+    frames = [f0] + [oracle.synthclip_frame(w, h, bd, seed=77, t=t) for t in range(1, 4)]
+    raw = b"".join(raw_of(frames[t % 4], bd) for t in range(n))
+    p = av1mi.default_params(w, h, bd)
+    for k in ("AV1MI_RC_STAGES", "AV1MI_RC_SORT"):
+        monkeypatch.delenv(k, raising=False)
+    data, sizes, rep, _ = ctx.encode_chunk(p, raw, n)
+    for env in ({"AV1MI_RC_STAGES": "4"}, {"AV1MI_RC_STAGES": "2", "AV1MI_RC_SORT": "1"}, {"AV1MI_RC_STAGES": "4", "AV1MI_RC_SORT": "0"}):
+        for k in ("AV1MI_RC_STAGES", "AV1MI_RC_SORT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d2, s2, _, _ = ctx.encode_chunk(p, raw, n)
+        assert d2 == data and list(s2) == list(sizes), env
+    for k in ("AV1MI_RC_STAGES", "AV1MI_RC_SORT"):
+        monkeypatch.delenv(k, raising=False)
+    tu, _, _ = oracle.encode_frame(oracle.default_config(w, h, bd, min_bs_log2=5, max_bs_log2=5), f0)
+    assert data[:sizes[0]] == tu and data[sum(sizes[:4]):sum(sizes[:5])] == tu   # (frame 4 repeats frame 0)
+
+
 def test_device_resident_input_matches_host_input(av1mi, ctx, oracle):
     import torch
     w, h, bd, n = 200, 120, 8, 3
