@@ -101,7 +101,10 @@ template <> struct LinesSel<2> { static __device__ __forceinline__ LineLds<2> &g
 struct alignas(16) SbLds {
   uint16_t blkpix[MAXN * MAXN];     // prediction, then reconstruction, of the current transform block
   uint16_t srcblk[MAXN * MAXN];     // source pixels of the block; reused for the quantised levels
-  int16_t scratch[MAXN * (MAXN + 1)];     // 2-D transform staging (every intermediate fits 16 bits)
+  // 2-D transform staging (every intermediate fits 16 bits).  A 64x64 block keeps 32 rows of 64 after its first pass,
+  // and its residual is never stored (the column pass subtracts source and prediction itself): 32 x 65 for it, 2 x 32 x 33 for the
+  // chroma pair of the 64x64 build - half of 64 x 65, which was what held that build at five waves per CU
+  int16_t scratch[MAXN > 32 ? 2 * 32 * 33 : MAXN * (MAXN + 1)];
   // element i of a lane group's edge at [group * EDGS + 8 + i] (i >= -1; padded up to 3 N + 8 for the piece-wise predictors): element 0 is
   // 16-byte aligned.  Two groups of blocks up to MAXN / 2, or one block of MAXN.
 #define AV1MI_EDGS (MAXN > 32 ? 120 : 72)
@@ -452,7 +455,7 @@ __device__ __forceinline__ void mc_block_8tap(const PIX *rp, int stride, int las
   // for the window (5.6 KB: 12 instead of 16 waves per CU in the inter pass).
   constexpr int N = 1 << LOG2N, WN = N + 7, G = 64 / NPL, RS = N < 16 ? N : 16, WR = RS + 7;
   constexpr int WSZ = (WR * WN + 3) & ~3, MSZ = WR * N;
-  static_assert(NPL * (WSZ + MSZ) <= MAXN * MAXN + MAXN * (MAXN + 1), "the strip's window and intermediate must fit srcblk + scratch");
+  static_assert(NPL * (WSZ + MSZ) <= MAXN * MAXN + (MAXN > 32 ? 2 * 32 * 33 : MAXN * (MAXN + 1)), "the strip's window and intermediate must fit srcblk + scratch");
   uint16_t *win = buf + grp * (WSZ + MSZ);
   int16_t *mid = reinterpret_cast<int16_t *>(win + WSZ);
   const int ix0 = (px0 >> 4) - 3, iy0 = (py0 >> 4) - 3;
@@ -1066,12 +1069,12 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       const int sv = S->srcblk[po + p];
       if (final_trip) {
         S->blkpix[po + p] = (uint16_t)pv;
-        if (!fe) S->scratch[so + r * STR + c] = (int16_t)(sv - pv);
+        if (!fe && LOG2N < 6) S->scratch[so + r * STR + c] = (int16_t)(sv - pv);
       } else {
         sad += iabs(sv - pv);
       }
     }
-    if (final_trip && (fe || pv_path)) {
+    if (final_trip && (fe || pv_path) && LOG2N < 6) {
       wave_sync();
       if constexpr (VEC) {   // eight differences per lane and step (the residual rows of these classes are 16-byte aligned)
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -1195,7 +1198,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   } else {
     if (tx_lane) {
   #pragma unroll
-      for (int i = 0; i < N; i++) x[i] = (int)S->scratch[so + i * STR + sl] << SH0;   // (the residual's row stride; the passes' own tile is ST)
+      for (int i = 0; i < N; i++)   // (the residual's row stride; the passes' own tile is ST; 64x64: source minus prediction, straight from their tiles)
+        x[i] = (LOG2N < 6 ? (int)S->scratch[so + i * STR + sl] : (int)S->srcblk[po + i * N + sl] - (int)S->blkpix[po + i * N + sl]) << SH0;
       Tx1d<LOG2N>::fwd(x, vt);
   #pragma unroll
       for (int i = 0; i < CW; i++) S->scratch[so + i * ST + sl] = (int16_t)rshift_round(x[i], SH1);
