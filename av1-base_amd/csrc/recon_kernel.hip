@@ -78,7 +78,7 @@ __device__ const uint32_t c_fdct32_frag[64][16] = AV1_FDCT32_FRAG_INIT;
 
 // LDS per superblock-wave (~9 KB, so ~4 waves fit a SIMD): decoder-style line buffers instead of the
 // whole reconstructed superblock.  above[p][x] = bottom row of the last block reconstructed over column
-// x, left[p][y] = right column of the last block reconstructed over row y, corner[p][y4][x4] = pixel
+// x, left[p][y] = right column of the last block reconstructed over row y, corner[p][yk][xk] = pixel
 // (4*y4-1, 4*x4-1).  Z-order + quadtree alignment guarantee that whenever the decoded-block map says an
 // edge is available these hold exactly the pixels spec §7.11.2 asks for.
 // line buffers of a tile of TSB x TSB superblocks (coordinates tile-local); only the instantiations for two-superblock
@@ -87,7 +87,7 @@ template <int TSB>
 struct LineLds {
   uint16_t above[3][64 * TSB];
   uint16_t left[3][64 * TSB];
-  uint16_t corner[3][16 * TSB + 1][16 * TSB + 1];
+  uint16_t corner[3][8 * TSB + 1][8 * TSB + 1];   // luma: every 8 samples (the smallest luma block), chroma: every 4
   // intra edge filter (get_filter_type, spec 7.11.2.8): [luma | chroma][8x8-luma unit of the tile] = the last block reconstructed over
   // that column / beside that row was predicted with a smooth mode
   uint8_t sm_above[2][8 * TSB], sm_left[2][8 * TSB];
@@ -110,7 +110,7 @@ struct alignas(16) SbLds {
 #define AV1MI_EDGS (MAXN > 32 ? 120 : 72)
   uint16_t edge_a[2 * AV1MI_EDGS + 8];
   uint16_t edge_l[2 * AV1MI_EDGS + 8];
-  uint8_t blkdec[2][19][19];    // luma, chroma (U and V decode together)
+  uint32_t blkdec[2][19];       // luma, chroma (U and V decode together): row y + 1 of the 4x4-unit map, bit x + 1
   uint8_t smw[64];              // smooth weights of the current block size
   int eobs[4];                  // eob of the current block's Y, U, V transform blocks
 };
@@ -577,10 +577,11 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
   const int bd = P->bit_depth;
   // decoded-block map lookups (spec §5.11.35): above-right / below-left availability
   const int pc = plane0 > 0;
+  const int cgs = plane0 > 0 ? 2 : 3;   // log2 of the corner grid's pitch in this plane
   const int r4 = y0 >> 2, c4 = x0 >> 2;
   constexpr int step = (N >> 2) > 0 ? (N >> 2) : 1;
-  const int have_ar = PH == 1 ? 0 : S->blkdec[pc][r4 - 1 + 1][c4 + step + 1];
-  const int have_bl = PH == 1 ? 0 : S->blkdec[pc][r4 + step + 1][c4 - 1 + 1];
+  const int have_ar = PH == 1 ? 0 : (int)((S->blkdec[pc][r4 - 1 + 1] >> (c4 + step + 1)) & 1u);
+  const int have_bl = PH == 1 ? 0 : (int)((S->blkdec[pc][r4 + step + 1] >> (c4 - 1 + 1)) & 1u);
   const long poff = plane == 0 ? 0 : (plane == 1 ? P->plane_off_u : P->plane_off_v);
   const int gs = plane0 ? P->stride_c : P->stride_y;
   const int gx = (plane0 ? cx.sb_x >> 1 : cx.sb_x) + x0, gy = (plane0 ? cx.sb_y >> 1 : cx.sb_y) + y0;
@@ -604,12 +605,12 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         LN.above[plane][lx + sl] = srow[sl < pw_lim ? sl : pw_lim - 1];
         LN.left[plane][ly + sl] = scol[sl < ph_lim ? sl : ph_lim - 1];
       }
-      if (sl < step) {
-        const int j = sl + 1, q = 4 * j - 1;
-        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = srow[q < pw_lim ? q : pw_lim - 1];
-        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = scol[q < ph_lim ? q : ph_lim - 1];
+      if (sl < (N >> cgs)) {
+        const int j = sl + 1, q = (j << cgs) - 1;
+        LN.corner[plane][(ly + N) >> cgs][(lx >> cgs) + j] = srow[q < pw_lim ? q : pw_lim - 1];
+        LN.corner[plane][(ly >> cgs) + j][(lx + N) >> cgs] = scol[q < ph_lim ? q : ph_lim - 1];
       }
-      for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
+      if (lane < step) S->blkdec[pc][r4 + lane + 1] |= ((1u << step) - 1u) << (c4 + 1);   // (a lane per row of the block)
       if (EXT && lane < (plane0 ? N >> 2 : N >> 3)) { LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = 0; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = 0; }
       if (sl == 0) eob_out[grp] = plane == 0 ? ii.pre_eob[0] : (plane == 1 ? ii.pre_eob[1] : ii.pre_eob[2]);   // (no dynamic index: the array stays in registers)
       wave_sync();
@@ -756,7 +757,7 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
     if (sl == 0) {
       int tl;
-      if (have_above && have_left) tl = LN.corner[plane][ly >> 2][lx >> 2];
+      if (have_above && have_left) tl = LN.corner[plane][ly >> cgs][lx >> cgs];
       else if (have_above) tl = LN.above[plane][lx];
       else if (have_left) tl = LN.left[plane][ly];
       else tl = 1 << (bd - 1);
@@ -1431,12 +1432,12 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
         LN.above[plane][lx + sl] = S->blkpix[po + (N - 1) * N + sl];
         LN.left[plane][ly + sl] = S->blkpix[po + sl * N + (N - 1)];
       }
-      if (sl < step) {  // corners at every 4-aligned position of the bottom row and right column
-        const int j = sl + 1;
-        LN.corner[plane][(ly + N) >> 2][(lx >> 2) + j] = S->blkpix[po + (N - 1) * N + 4 * j - 1];
-        LN.corner[plane][(ly >> 2) + j][(lx + N) >> 2] = S->blkpix[po + (4 * j - 1) * N + (N - 1)];
+      if (sl < (N >> cgs)) {  // corners at every 8-aligned (chroma: 4-aligned) position of the bottom row and right column
+        const int j = sl + 1, q = (j << cgs) - 1;
+        LN.corner[plane][(ly + N) >> cgs][(lx >> cgs) + j] = S->blkpix[po + (N - 1) * N + q];
+        LN.corner[plane][(ly >> cgs) + j][(lx + N) >> cgs] = S->blkpix[po + q * N + (N - 1)];
       }
-      for (int t = lane; t < step * step; t += 64) S->blkdec[pc][r4 + t / step + 1][c4 + t % step + 1] = 1;
+      if (lane < step) S->blkdec[pc][r4 + lane + 1] |= ((1u << step) - 1u) << (c4 + 1);   // (a lane per row of the block)
       if (EXT && lane < (plane0 ? N >> 2 : N >> 3)) {
         const uint8_t smf = (uint8_t)(!(INTER && ii.is_inter) && best_mode >= SMOOTH_PRED && best_mode <= SMOOTH_H_PRED);
         LN.sm_above[pc][(lx >> (plane0 ? 2 : 3)) + lane] = smf; LN.sm_left[pc][(ly >> (plane0 ? 2 : 3)) + lane] = smf;
@@ -1626,17 +1627,20 @@ __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribut
     __syncthreads();
     {
       const int w4 = tile_mi_c1 - sbc * 16, h4 = tile_mi_r1 - sbr * 16;
-      for (int t = cx.lane; t < 2 * 19 * 19; t += 64) {
-        int pl = t / 361, y = (t % 361) / 19 - 1, x = t % 19 - 1;
-        int sz = 16 >> pl;
-        int sw = w4 >> pl, sh = h4 >> pl;
-        int v = 0;
-        if (y <= sz && x <= sz) {
-          if (y < 0 && x < sw) v = 1;
-          else if (x < 0 && y < sh) v = 1;
-          if (y == sz && x == -1) v = 0;
+      if (cx.lane < 2 * 19) {   // a lane per row of a plane's map
+        const int pl = cx.lane / 19, y = cx.lane % 19 - 1;
+        const int sz = 16 >> pl, sw = w4 >> pl, sh = h4 >> pl;
+        uint32_t m = 0;
+        for (int x = -1; x < 18; x++) {
+          int v = 0;
+          if (y <= sz && x <= sz) {
+            if (y < 0 && x < sw) v = 1;
+            else if (x < 0 && y < sh) v = 1;
+            if (y == sz && x == -1) v = 0;
+          }
+          m |= (uint32_t)v << (x + 1);
         }
-        sbl->blkdec[pl][y + 1][x + 1] = (uint8_t)v;
+        sbl->blkdec[pl][y + 1] = m;
       }
     }
     if constexpr (INTER) {
