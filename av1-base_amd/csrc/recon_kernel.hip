@@ -1579,14 +1579,14 @@ __device__ __forceinline__ void encode_superblock(const SbCtx &cx, const PIX *fr
 // The tile walk of an inter frame is SPLIT (two waves per tile, see encode_superblock): its duration is the chain of the tile with
 // most intra-coded blocks, and the chroma blocks were 45 % of that chain.
 #ifndef AV1MI_RECON_MIN_WAVES
-#define AV1MI_RECON_MIN_WAVES 4
+#define AV1MI_RECON_MIN_WAVES 5
 #endif
 #ifndef AV1MI_SPLIT_INTRA
 #define AV1MI_SPLIT_INTRA 0
 #endif
 template <bool INTER> struct WalkSplit { static constexpr bool value = INTER || AV1MI_SPLIT_INTRA; };
 template <typename PIX, bool INTER, int TSB, bool QM, bool EXT>
-__global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : 4))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
+__global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES))) recon_sb_kernel(const Av1miDevParams *__restrict__ Pd, const PIX *__restrict__ src, PIX *__restrict__ rec,
                                                      int16_t *__restrict__ levels, Av1miBlkInfo *__restrict__ blk,
                                                      const PIX *__restrict__ ref /* inter frame: previous final reconstruction, one frame */,
                                                      const unsigned long long *__restrict__ me_best,
@@ -1709,7 +1709,7 @@ __global__ void __launch_bounds__(WalkSplit<INTER>::value ? 128 : 64) __attribut
 // that does depend on neighbours - the intra SAD of the decision and the blocks intra prediction wins.
 // (As one kernel a P frame was 510 waves of six serial block passes: 290 us of latency on the chunk's serial chain.)
 template <typename PIX, bool QM, bool SP /* sub-sample motion vectors (P->subpel) */>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : 4))) recon_inter_pre_kernel(const Av1miDevParams *__restrict__ Pd,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES, AV1MI_RECON_BIG ? 2 : AV1MI_RECON_MIN_WAVES))) recon_inter_pre_kernel(const Av1miDevParams *__restrict__ Pd,
                                                      const PIX *__restrict__ src, PIX *__restrict__ rec, int16_t *__restrict__ levels,
                                                      Av1miBlkInfo *__restrict__ blk, const PIX *__restrict__ ref,
                                                      const unsigned long long *__restrict__ me_best, int cell_log2,
