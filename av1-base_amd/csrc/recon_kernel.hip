@@ -85,8 +85,11 @@ __device__ const uint32_t c_fdct32_frag[64][16] = AV1_FDCT32_FRAG_INIT;
 // tiles reference - and therefore allocate - the larger set
 template <int TSB>
 struct LineLds {
-  uint16_t above[3][64 * TSB];
-  uint16_t left[3][64 * TSB];
+  // (one row of 64 TSB luma + two of 32 TSB chroma samples each: with three rows of 64 the 32x32 build's wave held 8 348 B of LDS,
+  // 156 more than lets 20 waves share a CU)
+  uint16_t above_[128 * TSB], left_[128 * TSB];
+  __device__ __forceinline__ uint16_t *above(int plane) { return above_ + (plane ? 32 * TSB * (plane + 1) : 0); }
+  __device__ __forceinline__ uint16_t *left(int plane) { return left_ + (plane ? 32 * TSB * (plane + 1) : 0); }
   uint16_t corner[3][8 * TSB + 1][8 * TSB + 1];   // luma: every 8 samples (the smallest luma block), chroma: every 4
   // intra edge filter (get_filter_type, spec 7.11.2.8): [luma | chroma][8x8-luma unit of the tile] = the last block reconstructed over
   // that column / beside that row was predicted with a smooth mode
@@ -602,8 +605,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
       const uint16_t *srow = plane == 0 ? g_ws.row_y[(y0 + rb) >> 3] + x0 : g_ws.row_c[plane - 1][(y0 + rb) >> 2] + x0;
       const uint16_t *scol = plane == 0 ? g_ws.col_y[(x0 + cb) >> 3] + y0 : g_ws.col_c[plane - 1][(x0 + cb) >> 2] + y0;
       if (sl < N) {
-        LN.above[plane][lx + sl] = srow[sl < pw_lim ? sl : pw_lim - 1];
-        LN.left[plane][ly + sl] = scol[sl < ph_lim ? sl : ph_lim - 1];
+        LN.above(plane)[lx + sl] = srow[sl < pw_lim ? sl : pw_lim - 1];
+        LN.left(plane)[ly + sl] = scol[sl < ph_lim ? sl : ph_lim - 1];
       }
       if (sl < (N >> cgs)) {
         const int j = sl + 1, q = (j << cgs) - 1;
@@ -738,19 +741,19 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     // what a prediction at an angle below 90 degrees takes beyond max_base)
     for (int i = sl; i < (PVOK ? 3 * N + 9 : 2 * N); i += G) {
       int a, l;
-      if (!have_above && have_left) a = LN.left[plane][ly];           // pixel (y0, x0-1)
+      if (!have_above && have_left) a = LN.left(plane)[ly];           // pixel (y0, x0-1)
       else if (!have_above) a = (1 << (bd - 1)) - 1;
       else {
         int lim = lx + (have_ar ? 2 * N : N) - 1;
         if (lim > max_x) lim = max_x;
-        a = LN.above[plane][lx + i < lim ? lx + i : lim];             // pixel (y0-1, .)
+        a = LN.above(plane)[lx + i < lim ? lx + i : lim];             // pixel (y0-1, .)
       }
-      if (!have_left && have_above) l = LN.above[plane][lx];          // pixel (y0-1, x0)
+      if (!have_left && have_above) l = LN.above(plane)[lx];          // pixel (y0-1, x0)
       else if (!have_left) l = (1 << (bd - 1)) + 1;
       else {
         int lim = ly + (have_bl ? 2 * N : N) - 1;
         if (lim > max_y) lim = max_y;
-        l = LN.left[plane][ly + i < lim ? ly + i : lim];              // pixel (., x0-1)
+        l = LN.left(plane)[ly + i < lim ? ly + i : lim];              // pixel (., x0-1)
       }
       S->edge_a[eo + EB + i] = (uint16_t)a;
       S->edge_l[eo + EB + i] = (uint16_t)l;
@@ -758,8 +761,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     if (sl == 0) {
       int tl;
       if (have_above && have_left) tl = LN.corner[plane][ly >> cgs][lx >> cgs];
-      else if (have_above) tl = LN.above[plane][lx];
-      else if (have_left) tl = LN.left[plane][ly];
+      else if (have_above) tl = LN.above(plane)[lx];
+      else if (have_left) tl = LN.left(plane)[ly];
       else tl = 1 << (bd - 1);
       S->edge_a[eo + EB - 1] = (uint16_t)tl;
       S->edge_l[eo + EB - 1] = (uint16_t)tl;
@@ -1429,8 +1432,8 @@ __device__ __attribute__((noinline)) int tx_item(SbCtx cx, const PIX *frame, PIX
     }
     if constexpr (PH != 1) {
       if (sl < N) {
-        LN.above[plane][lx + sl] = S->blkpix[po + (N - 1) * N + sl];
-        LN.left[plane][ly + sl] = S->blkpix[po + sl * N + (N - 1)];
+        LN.above(plane)[lx + sl] = S->blkpix[po + (N - 1) * N + sl];
+        LN.left(plane)[ly + sl] = S->blkpix[po + sl * N + (N - 1)];
       }
       if (sl < (N >> cgs)) {  // corners at every 8-aligned (chroma: 4-aligned) position of the bottom row and right column
         const int j = sl + 1, q = (j << cgs) - 1;
