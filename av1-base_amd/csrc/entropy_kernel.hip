@@ -48,8 +48,26 @@ struct InterLds {
   uint8_t newmv[256];                        // per 8x8 unit of the tile: its block was coded as NEWMV
 };
 __shared__ InterLds g_inter;
+// The wide rows' layout of the REGULAR variants: a regular tile has one luma and one chroma transform size, so the tables the full
+// layout (Av1miCdfLayout) keeps per size - a third of the wide rows - shrink to one slice per plane type: 3.2 instead of 4.9 KB, which
+// takes the key-frame variant from 5 to 6 waves per SIMD and the inter-frame variant from 4 to 5.  PARTITION .. SKIP keep their offsets.
+struct CC {
+  enum {
+    LEAD = CL::TX_SET1,
+    TXSET = LEAD,                        // the luma size's slice of TX_SET1 ([13][8]) or TX_SET2 ([13][6]), if it has one
+    TXB_SKIP = TXSET + 13 * 8,           // [2 plane types][13][3]
+    EOB = TXB_SKIP + 2 * 13 * 3,         // [2][12]: the row (context 0) of the plane type's size
+    EOB_EXTRA = EOB + 2 * 12,            // [2][9][3]
+    DC_SIGN = EOB_EXTRA + 2 * 9 * 3,     // [2][3][3] as in the full layout
+    COEFF_BASE_EOB = DC_SIGN + 18,       // [2][4][4]
+    USE_WIENER = COEFF_BASE_EOB + 2 * 16, RESTORE_SW = USE_WIENER + 3, CFL_SIGN = RESTORE_SW + 4, CFL_ALPHA = CFL_SIGN + 9,
+    TOTAL = CFL_ALPHA + 6 * 17
+  };
+};
+static_assert(CL::COEFF_BASE - CL::USE_WIENER == CC::TOTAL - CC::USE_WIENER, "the trailing tables are copied as one piece");
+__shared__ uint16_t g_cdfw_full[CL::COEFF_BASE + 18];   // wide rows; + 18: whole-row reads by 17 lanes may run past the last row
+__shared__ uint16_t g_cdfw_compact[CC::TOTAL + 18];
 struct SymLds {
-  uint16_t cdf[CL::COEFF_BASE + 18];   // wide rows; + 18: whole-row reads by 17 lanes may run past the last row
   alignas(16) int16_t lv[32 * 32];
   uint8_t left_lvl[3][16], left_dc[3][16];   // per superblock row of the tile
 };
@@ -71,6 +89,7 @@ template <> struct TileSel<2> { static __device__ __forceinline__ TileLds<2> &ge
 #define TW (8 * TSB)   // tile width in 8x8 units
 
 struct Sym {
+  uint16_t *cdf;     // the variant's wide rows (LDS)
   uint32_t *out;     // this tile's stream (global)
   int pos;           // entries written (uniform)
   int cap;
@@ -90,10 +109,10 @@ __device__ __forceinline__ void emit1(Sym &y, int lane, uint32_t ent) {
 
 // Wide-alphabet / rare symbol: adapt the n-symbol row at LDS offset `off` cooperatively (lane j =
 // entry j) and emit the RESOLVED entry.
-template <int ARR = 0>  // 0: S->cdf (key-frame syntax), 1: g_cdf_inter (offsets relative to CL::INTER_BASE)
+template <int ARR = 0>  // 0: y.cdf (key-frame syntax), 1: g_cdf_inter (offsets relative to CL::INTER_BASE)
 __device__ __forceinline__ void sym_wide(Sym &y, int lane, int adapt, int s, int off, int n) {
   s = uni(s); off = uni(off) - (ARR ? CL::INTER_BASE : 0); n = uni(n);
-  const int v = ARR ? g_cdf_inter[off + (lane < 17 ? lane : 16)] : S->cdf[off + (lane < 17 ? lane : 16)];
+  const int v = ARR ? g_cdf_inter[off + (lane < 17 ? lane : 16)] : y.cdf[off + (lane < 17 ? lane : 16)];
   const uint32_t fl = s > 0 ? (uint32_t)__builtin_amdgcn_readlane(v, s - 1) : 32768u;
   const uint32_t fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
   if (adapt) {
@@ -101,7 +120,7 @@ __device__ __forceinline__ void sym_wide(Sym &y, int lane, int adapt, int s, int
     const int rate = 3 + (cntr > 15) + (cntr > 31) + (n > 3 ? 2 : 1);
     int nv = lane < s ? v + ((32768 - v) >> rate) : v - (v >> rate);
     nv = lane == n ? cntr + (cntr < 32) : nv;
-    if (lane <= n) { if (ARR) g_cdf_inter[off + lane] = (uint16_t)nv; else S->cdf[off + lane] = (uint16_t)nv; }
+    if (lane <= n) { if (ARR) g_cdf_inter[off + lane] = (uint16_t)nv; else y.cdf[off + lane] = (uint16_t)nv; }
   }
   emit1(y, lane, ENT_RESOLVED(fl >> 6, fh >> 6, n - 1 - s));
 }
@@ -230,7 +249,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
   nb_or = uni(nb_or); dsum = uni(dsum);
   // luma: TX_MODE_LARGEST with square blocks => transform == block => ctx 0
   const int zctx = plane == 0 ? 0 : 7 + (nb_or & 1) + (nb_or >> 1);
-  sym_wide(y, lane, adapt, eob == 0, CL::TXB_SKIP + (txs * 13 + zctx) * 3, 2);
+  sym_wide(y, lane, adapt, eob == 0, FULL ? CL::TXB_SKIP + (txs * 13 + zctx) * 3 : CC::TXB_SKIP + (ptype * 13 + zctx) * 3, 2);
   int cul = 0, dc_cat = 0;
   if (eob != 0) {
     {
@@ -249,8 +268,8 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
     } else if (plane == 0 && log2n <= 4) {
       // intra_tx_type: the mode's default type, or IDTX (symbol 0 of both intra sets) when the reconstruction chose it
       const int tt = mode_txfm(ymode);
-      if (log2n <= 3) sym_wide(y, lane, adapt, idtx ? 0 : txsym_set1(tt), CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8, 7);
-      else sym_wide(y, lane, adapt, idtx ? 0 : txsym_set2(tt), CL::TX_SET2 + ((log2n - 2) * 13 + ymode) * 6, 5);
+      if (log2n <= 3) sym_wide(y, lane, adapt, idtx ? 0 : txsym_set1(tt), FULL ? CL::TX_SET1 + ((log2n - 2) * 13 + ymode) * 8 : CC::TXSET + ymode * 8, 7);
+      else sym_wide(y, lane, adapt, idtx ? 0 : txsym_set2(tt), FULL ? CL::TX_SET2 + ((log2n - 2) * 13 + ymode) * 6 : CC::TXSET + ymode * 6, 5);
     }
     {
       const int eob_pt = eob <= 2 ? eob : floor_log2((unsigned)(eob - 1)) + 2;
@@ -259,10 +278,10 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       const int msz = 2 * bwl - 4;
       const int nsy = 5 + msz;
       const int eoff = CL::EOB16 + 4 * (msz * 6 + (msz * (msz - 1)) / 2);
-      sym_wide(y, lane, adapt, eob_pt - 1, eoff + (ptype * 2 + 0) * (nsy + 1), nsy);
+      sym_wide(y, lane, adapt, eob_pt - 1, FULL ? eoff + (ptype * 2 + 0) * (nsy + 1) : CC::EOB + ptype * 12, nsy);
       if (eob_pt >= 3) {
         const int nbits = eob_pt - 2;
-        sym_wide(y, lane, adapt, (extra >> (nbits - 1)) & 1, CL::EOB_EXTRA + ((txs * 2 + ptype) * 9 + (eob_pt - 3)) * 3, 2);
+        sym_wide(y, lane, adapt, (extra >> (nbits - 1)) & 1, FULL ? CL::EOB_EXTRA + ((txs * 2 + ptype) * 9 + (eob_pt - 3)) * 3 : CC::EOB_EXTRA + (ptype * 9 + (eob_pt - 3)) * 3, 2);
         for (int i = 1; i < nbits; i++) emit1(y, lane, ENT_LITERAL((extra >> (nbits - 1 - i)) & 1));
       }
     }
@@ -288,7 +307,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
       const int cc = eob - 1;
       const int lvl_last = uni(iabs((int)S->lv[__builtin_amdgcn_readfirstlane(pos_nx)]));   // (lane 0 holds scan index eob - 1)
       const int cctx = cc == 0 ? 0 : (cc <= (n * n) / 8 ? 1 : (cc <= (n * n) / 4 ? 2 : 3));
-      sym_wide(y, lane, adapt, imin(lvl_last, 3) - 1, CL::COEFF_BASE_EOB + ((txs * 2 + ptype) * 4 + cctx) * 4, 3);
+      sym_wide(y, lane, adapt, imin(lvl_last, 3) - 1, FULL ? CL::COEFF_BASE_EOB + ((txs * 2 + ptype) * 4 + cctx) * 4 : CC::COEFF_BASE_EOB + (ptype * 4 + cctx) * 4, 3);
     }
     // ---- all coefficients in reverse scan order, 64 at a time: lane i owns scan index c_hi - i
     for (int c_hi = eob - 1; c_hi >= 0; c_hi -= 64) {
@@ -400,7 +419,7 @@ __device__ __forceinline__ void sym_coeffs(Sym &y, const int lane, const int ada
         const int v0 = __builtin_amdgcn_readlane(v, 0);
         if (v0 != 0) {
           const int dctx = dsum < 0 ? 1 : (dsum > 0 ? 2 : 0);
-          sym_wide(y, lane, adapt, v0 < 0, CL::DC_SIGN + (ptype * 3 + dctx) * 3, 2);
+          sym_wide(y, lane, adapt, v0 < 0, (FULL ? CL::DC_SIGN : CC::DC_SIGN) + (ptype * 3 + dctx) * 3, 2);
           dc_cat = v0 < 0 ? 1 : 2;
           const int l0 = iabs(v0);
           if (l0 > 14) {  // its golomb tail (rare) right behind it
@@ -594,7 +613,7 @@ __device__ __forceinline__ void sym_mv_component(Sym &y, int lane, int adapt, in
   }
 }
 
-__device__ __forceinline__ int icdf_prob(int off, int el) { return (el > 0 ? S->cdf[off + el - 1] : 32768) - S->cdf[off + el]; }
+__device__ __forceinline__ int icdf_prob(const Sym &y, int off, int el) { return (el > 0 ? y.cdf[off + el - 1] : 32768) - y.cdf[off + el]; }
 
 // Under a content-driven partition (P.part_map): does the superblock keep one block size throughout - no node between min_bs_log2
 // and max_bs_log2 splits by its mask?  (Only then does a tile hold exactly two (transform size, plane type) classes.)
@@ -644,8 +663,28 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
       }
     if (regular == FULL) return;
   }
-  for (int i = lane; i < CL::COEFF_BASE; i += 64) S->cdf[i] = cdf_init[i];
-  if (lane < 18) S->cdf[CL::COEFF_BASE + lane] = 0;
+  if constexpr (FULL) {
+    for (int i = lane; i < CL::COEFF_BASE; i += 64) g_cdfw_full[i] = cdf_init[i];
+    if (lane < 18) g_cdfw_full[CL::COEFF_BASE + lane] = 0;
+  } else {
+    // the compact layout (struct CC): the tile's leaves have one size, so one luma and one chroma transform size
+    const int l2y = P.max_bs_log2 > 6 ? 6 : P.max_bs_log2, l2c = l2y - 1 > 5 ? 5 : l2y - 1;
+    uint16_t *const w = g_cdfw_compact;
+    for (int i = lane; i < CC::LEAD; i += 64) w[i] = cdf_init[i];
+    for (int i = lane; i < 13 * 8; i += 64)
+      w[CC::TXSET + i] = l2y <= 3 ? cdf_init[CL::TX_SET1 + (l2y - 2) * 13 * 8 + i] : ((l2y == 4 && i < 13 * 6) ? cdf_init[CL::TX_SET2 + (l2y - 2) * 13 * 6 + i] : (uint16_t)0);
+    for (int i = lane; i < 2 * 39; i += 64) { const int p = i / 39, txs = (p ? l2c : l2y) - 2; w[CC::TXB_SKIP + i] = cdf_init[CL::TXB_SKIP + txs * 39 + i % 39]; }
+    if (lane < 24) {
+      const int p = lane / 12, k = lane % 12, bwl = (p ? l2c : l2y) > 5 ? 5 : (p ? l2c : l2y), msz = 2 * bwl - 4, nsy = 5 + msz;
+      const int eoff = CL::EOB16 + 4 * (msz * 6 + (msz * (msz - 1)) / 2) + (p * 2 + 0) * (nsy + 1);
+      w[CC::EOB + lane] = k <= nsy ? cdf_init[eoff + k] : (uint16_t)0;
+    }
+    if (lane < 2 * 27) { const int p = lane / 27, txs = (p ? l2c : l2y) - 2; w[CC::EOB_EXTRA + lane] = cdf_init[CL::EOB_EXTRA + (txs * 2 + p) * 27 + lane % 27]; }
+    if (lane < 18) w[CC::DC_SIGN + lane] = cdf_init[CL::DC_SIGN + lane];
+    if (lane < 2 * 16) { const int p = lane / 16, txs = (p ? l2c : l2y) - 2; w[CC::COEFF_BASE_EOB + lane] = cdf_init[CL::COEFF_BASE_EOB + (txs * 2 + p) * 16 + lane % 16]; }
+    for (int i = lane; i < CC::TOTAL - CC::USE_WIENER; i += 64) w[CC::USE_WIENER + i] = cdf_init[CL::USE_WIENER + i];
+    if (lane < 18) w[CC::TOTAL + lane] = 0;
+  }
   if (FULL) {
     for (int i = lane; i < CL::INTRA_TOTAL - CL::COEFF_BASE; i += 64) g_cdf_narrow[i] = cdf_init[CL::COEFF_BASE + i];
     g_cdf_narrow[CL::INTRA_TOTAL - CL::COEFF_BASE + lane] = 0;
@@ -668,6 +707,7 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
   }
   __syncthreads();
   Sym y;
+  y.cdf = FULL ? g_cdfw_full : g_cdfw_compact;
   y.out = streams + (size_t)gt * P.stream_cap;
   y.pos = 0; y.cap = P.stream_cap;
   y.combo0 = -1; y.combo1 = -1;
@@ -705,8 +745,8 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
     if (sbr < urows && sbc < ucols) {
       const int ch = uni(lr_choice[(size_t)f * urows * ucols + sbr * ucols + sbc]);
       // choice: 0 = off, 1..3 = Wiener candidate, 4..6 = self-guided candidate (RESTORE_SWITCHABLE frames only)
-      if (P.enable_lr == 2) sym_wide(y, lane, adapt, ch == 0 ? 0 : (ch <= 3 ? 1 : 2), CL::RESTORE_SW, 3);
-      else sym_wide(y, lane, adapt, ch != 0, CL::USE_WIENER, 2);
+      if (P.enable_lr == 2) sym_wide(y, lane, adapt, ch == 0 ? 0 : (ch <= 3 ? 1 : 2), FULL ? CL::RESTORE_SW : CC::RESTORE_SW, 3);
+      else sym_wide(y, lane, adapt, ch != 0, FULL ? CL::USE_WIENER : CC::USE_WIENER, 2);
       if (ch > 3) {
         const int len = P.sgr_code_len[sgr_prev][ch - 4];
         const unsigned long long bits = P.sgr_code_bits[sgr_prev][ch - 4];
@@ -745,12 +785,12 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
         if (has_rows && has_cols) {
           sym_wide(y, lane, adapt, split ? 3 : 0, off, bsl == 3 ? 4 : 10);
         } else if (has_cols) {
-          int p = icdf_prob(off, 2) + icdf_prob(off, 3);
-          if (bsl != 3) p += icdf_prob(off, 4) + icdf_prob(off, 6) + icdf_prob(off, 7) + icdf_prob(off, 9);
+          int p = icdf_prob(y, off, 2) + icdf_prob(y, off, 3);
+          if (bsl != 3) p += icdf_prob(y, off, 4) + icdf_prob(y, off, 6) + icdf_prob(y, off, 7) + icdf_prob(y, off, 9);
           sym_bool(y, lane, 1, (uint32_t)uni(p));
         } else if (has_rows) {
-          int p = icdf_prob(off, 1) + icdf_prob(off, 3);
-          if (bsl != 3) p += icdf_prob(off, 4) + icdf_prob(off, 5) + icdf_prob(off, 6) + icdf_prob(off, 8);
+          int p = icdf_prob(y, off, 1) + icdf_prob(y, off, 3);
+          if (bsl != 3) p += icdf_prob(y, off, 4) + icdf_prob(y, off, 5) + icdf_prob(y, off, 6) + icdf_prob(y, off, 8);
           sym_bool(y, lane, 1, (uint32_t)uni(p));
         }
       }
@@ -826,9 +866,9 @@ __global__ void __launch_bounds__(64) symbolize_tile_kernel(Av1miDevParams P, co
           if (cfl) {   // read_cfl_alphas (spec 5.11.45)
             const int au = ((ainfo >> 4) & 63) - 2 * ((ainfo >> 4) & 32), av = ((ainfo >> 10) & 63) - 2 * ((ainfo >> 10) & 32);   // 6-bit two's complement
             const int su = au == 0 ? 0 : (au < 0 ? 1 : 2), sv = av == 0 ? 0 : (av < 0 ? 1 : 2);
-            sym_wide(y, lane, adapt, su * 3 + sv - 1, CL::CFL_SIGN, 8);
-            if (su) sym_wide(y, lane, adapt, iabs(au) - 1, CL::CFL_ALPHA + ((su - 1) * 3 + sv) * 17, 16);
-            if (sv) sym_wide(y, lane, adapt, iabs(av) - 1, CL::CFL_ALPHA + ((sv - 1) * 3 + su) * 17, 16);
+            sym_wide(y, lane, adapt, su * 3 + sv - 1, FULL ? CL::CFL_SIGN : CC::CFL_SIGN, 8);
+            if (su) sym_wide(y, lane, adapt, iabs(au) - 1, (FULL ? CL::CFL_ALPHA : CC::CFL_ALPHA) + ((su - 1) * 3 + sv) * 17, 16);
+            if (sv) sym_wide(y, lane, adapt, iabs(av) - 1, (FULL ? CL::CFL_ALPHA : CC::CFL_ALPHA) + ((sv - 1) * 3 + su) * 17, 16);
           }
           if (uvmode >= 1 && uvmode <= 8) sym_wide(y, lane, adapt, adelta, CL::ANGLE_DELTA + (uvmode - 1) * 8, 7);
         }
